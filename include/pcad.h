@@ -1,0 +1,151 @@
+/*
+ * pcad.h — C ABI of the MI355X-native PlantCaduceus forward engine (libpcad.so).
+ *
+ * Drop-in boundary for ONE path of kuleshov-group/PlantCaduceus: the masked-LM forward that
+ * `src/zero_shot_score.py:115` (`model(input_ids=curIDs)`) and `src/train_XGBoost.py:104`
+ * (`model(input_ids=..., output_hidden_states=True)`) run, i.e. the third-party operators
+ *   mamba_ssm.ops.selective_scan_interface.selective_scan_fn / mamba_inner_fn   (mamba-ssm==2.2.2)
+ *   causal_conv1d.causal_conv1d_fn                                              (causal-conv1d==1.4.0)
+ *   mamba_ssm.ops.triton.layer_norm.rms_norm_fn                                 (Triton fused add-norm)
+ *   CaduceusMixer / RCPS wrappers                                               (HF-hub remote code)
+ * pinned by reference env/requirements.txt:9-10 and env/environment.yml:12.
+ *
+ * Conventions
+ *   - plain C: pointers and sizes only; no torch / HIP types in any signature (`pcad_stream` is a
+ *     hipStream_t passed as void*).
+ *   - every buffer is OWNED BY THE CALLER (ids, outputs, weights, weight arena, workspace); the library
+ *     owns only the opaque handle.  No allocation, no host synchronisation inside pcad_forward.
+ *   - all work is enqueued on the caller's stream; a handle is bound to the current device and is not
+ *     thread-safe; distinct handles on distinct devices are independent (one process per GPU).
+ *   - status: 0 = OK, negative = error (enum below); message via thread-local pcad_last_error().
+ *   - activation layout is token-major: [strand, position, channel] (channel contiguous).
+ */
+#ifndef PCAD_H
+#define PCAD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PCAD_VERSION 100 /* 0.1.0 */
+#define PCAD_MAX_VOCAB 8
+#define PCAD_MAX_POSITIONS 16
+
+typedef void* pcad_stream;            /* hipStream_t */
+typedef struct pcad_engine* pcad_handle;
+
+enum pcad_status {
+    PCAD_OK = 0,
+    PCAD_ERR_INVALID = -1,      /* bad argument / unsupported shape */
+    PCAD_ERR_UNBOUND = -2,      /* weights not bound */
+    PCAD_ERR_WORKSPACE = -3,    /* workspace or arena too small / misaligned */
+    PCAD_ERR_MISSING = -4,      /* a required tensor name was not supplied */
+    PCAD_ERR_HIP = -5           /* HIP runtime error (launch failure, ...) */
+};
+
+enum pcad_dtype { PCAD_F32 = 0, PCAD_BF16 = 1 };
+
+/* Model geometry (HF config.json of the snapshot; replaces CaduceusConfig -> Mamba(**ssm_cfg)). */
+typedef struct pcad_config {
+    int32_t d_model;            /* D */
+    int32_t n_layer;
+    int32_t d_state;            /* N, must be 16 */
+    int32_t d_conv;             /* W, must be 4 */
+    int32_t expand;             /* E = expand * D */
+    int32_t dt_rank;            /* R */
+    int32_t vocab;              /* padded vocabulary, must be 8 */
+    float   eps;                /* RMSNorm epsilon (1e-5) */
+    int32_t dtype;              /* pcad_dtype of activations / GEMM operands (torch_dtype of the model) */
+    int32_t residual_in_fp32;   /* residual stream kept in fp32 (reference default) */
+    int32_t complement[PCAD_MAX_VOCAB]; /* token id -> complementary base id (RCPS) */
+} pcad_config;
+
+/* A named tensor in the reference's state-dict naming, device memory, row-major. */
+typedef struct pcad_tensor {
+    const char* name;
+    const void* data;
+    int32_t     dtype;          /* pcad_dtype */
+    int32_t     ndim;
+    int64_t     shape[4];
+} pcad_tensor;
+
+int         pcad_version(void);
+const char* pcad_last_error(void);
+
+/* Replaces: AutoModelForMaskedLM.from_pretrained(...).to(device)  (src/zero_shot_score.py:91-97) */
+int    pcad_create(const pcad_config* cfg, pcad_handle* out);
+void   pcad_destroy(pcad_handle h);
+
+/* Bytes of caller-owned device memory that pcad_bind_weights packs the model into. */
+size_t pcad_weight_arena_bytes(pcad_handle h);
+
+/* Pack the reference-named tensors (fp32 or bf16, device pointers) into `arena` in the engine's layouts
+ * (padded x_proj / dt_proj, pre-exponentiated A, tied in_proj/out_proj stored once).  Tied duplicates
+ * (`mamba_rev.in_proj/out_proj`, `lm_head`) may be absent.  The arena must outlive the handle. */
+int    pcad_bind_weights(pcad_handle h, const pcad_tensor* tensors, int n,
+                         void* arena, size_t arena_bytes, pcad_stream stream);
+
+/* Workspace needed by pcad_forward for `batch` sequences of `seqlen` tokens (both strands). */
+size_t pcad_workspace_bytes(pcad_handle h, int batch, int seqlen);
+
+/* Replaces: outputs = model(input_ids=ids[, output_hidden_states=True])
+ *           (src/zero_shot_score.py:115; src/train_XGBoost.py:104).
+ *   ids        device int32 [B, L] token ids (0..7)
+ *   positions  HOST int32 [P] sequence positions to evaluate, or NULL with P == 0 for all L positions
+ *              (P <= PCAD_MAX_POSITIONS).  Let Q = P ? P : L.
+ *   hidden_out device [B, Q, 2*D] in cfg.dtype, or NULL: hidden_states[-1] rows
+ *              (= cat(H(ids)[p], reverse_channels(H(rc ids)[L-1-p])))
+ *   logits_out device fp32 [B, Q, vocab], or NULL: RCPS LM-head logits (`.logits.float()`)
+ */
+int    pcad_forward(pcad_handle h, const int32_t* ids, int B, int L,
+                    const int32_t* positions, int P,
+                    void* hidden_out, float* logits_out,
+                    void* workspace, size_t workspace_bytes, pcad_stream stream);
+
+/* Per-layer mixer outputs for the last pcad_forward are not kept; this variant additionally writes
+ * hidden_states[0..n_layer-1] (the inputs of every block) to `all_hidden` ([n_layer, B, L, 2*D],
+ * cfg.dtype) — the `output_hidden_states=True` tuple of the reference minus its last entry. */
+int    pcad_forward_all_hidden(pcad_handle h, const int32_t* ids, int B, int L,
+                               void* all_hidden, void* hidden_out, float* logits_out,
+                               void* workspace, size_t workspace_bytes, pcad_stream stream);
+
+/* ---- per-operator entry points (unit parity against the operators they replace) ------------------ */
+
+/* rms_norm_fn(x, weight, None, residual=residual, eps, prenorm=True, residual_in_fp32)
+ *   x [rows, D] dtype; residual_in [rows, D] res_dtype or NULL; weight fp32 [D];
+ *   y [rows, D] dtype; residual_out [rows, D] res_dtype or NULL.  D % 8 == 0, D <= 2048. */
+int pcad_add_rmsnorm(const void* x, const void* residual_in, const float* weight,
+                     void* y, void* residual_out, int64_t rows, int D, float eps,
+                     int dtype, int res_dtype, pcad_stream stream);
+
+/* causal_conv1d_fn(x, weight, bias, activation="silu"), both directions in one pass, token-major:
+ *   x [S, L, ldx>=E] dtype (channel-contiguous rows); w_fwd/w_rev fp32 [E, 4]; b_fwd/b_rev fp32 [E]
+ *   y_fwd[t] = silu(b + sum_k w[k] x[t-3+k])   (causal),  y_rev[t] = silu(b + sum_k w[k] x[t+3-k]) (anti-causal)
+ *   y_fwd / y_rev [S, L, E] dtype; either may be NULL. */
+int pcad_causal_conv1d_silu(const void* x, int64_t ldx, const float* w_fwd, const float* b_fwd,
+                            const float* w_rev, const float* b_rev, void* y_fwd, void* y_rev,
+                            int S, int L, int E, int dtype, pcad_stream stream);
+
+/* selective_scan_fn(u, delta, A, B, C, D, z, delta_bias, delta_softplus=True), token-major:
+ *   u, delta [S, L, E] dtype; z [S, L, ldz>=E] dtype or NULL; Bm, Cm dtype rows of stride ldbc ([S*L, ldbc], 16 used);
+ *   A fp32 [E, 16] (negative real, NOT pre-scaled); Dskip, delta_bias fp32 [E];
+ *   reverse != 0 walks t = L-1..0;  accumulate != 0 adds into y (bi-directional "add" strategy).
+ *   y [S, L, E] dtype. */
+int pcad_selective_scan(const void* u, const void* delta, const void* z, int64_t ldz,
+                        const void* Bm, const void* Cm, int64_t ldbc,
+                        const float* A, const float* Dskip, const float* delta_bias,
+                        void* y, int S, int L, int E, int reverse, int accumulate,
+                        int dtype, pcad_stream stream);
+
+/* F.linear(a, w): C[M,N] = A[M,K] . W[N,K]^T on MFMA.  lda/ldw/ldc in elements; K % (128/sizeof(elem)) == 0,
+ * lda, ldw multiples of 16 bytes.  out_dtype: PCAD_F32 or `dtype`. */
+int pcad_gemm_nt(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc,
+                 int64_t M, int N, int K, int dtype, int out_dtype, pcad_stream stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PCAD_H */

@@ -1,0 +1,133 @@
+"""CaduceusConfig — the `config.json` schema of the `kuleshov-group/PlantCaduceus_l*` snapshots.
+
+The reference loads this class through `trust_remote_code=True`
+(reference `src/zero_shot_score.py:91`, `src/train_XGBoost.py:87`); the field set is the one the
+reference's own pre-training wrapper passes to `AutoConfig`
+(reference `pretrain/llmlib/architectures/models/mamba/caduceus.py:100-128`: `complement_map`,
+vocab padded to a multiple of 8) and the one implied by the module tree printed at
+reference `notebooks/examples.ipynb:61-100`.  Model hyper-parameters are always read from the
+snapshot's `config.json`, never hard-coded.
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional
+
+from transformers import PretrainedConfig
+
+# id → id of the complementary base; vocabulary `[PAD]0 [MASK]1 [UNK]2 a3 c4 g5 t6 (pad row)7`
+DEFAULT_COMPLEMENT_MAP = {0: 0, 1: 1, 2: 2, 3: 6, 4: 5, 5: 4, 6: 3, 7: 7}
+
+
+class CaduceusConfig(PretrainedConfig):
+    model_type = "caduceus"
+
+    def __init__(
+        self,
+        d_model: int = 384,
+        n_layer: int = 20,
+        vocab_size: int = 8,
+        ssm_cfg: Optional[dict] = None,
+        rms_norm: bool = True,
+        residual_in_fp32: bool = True,
+        fused_add_norm: bool = True,
+        pad_vocab_size_multiple: int = 8,
+        norm_epsilon: float = 1e-5,
+        initializer_cfg: Optional[dict] = None,
+        bidirectional: bool = True,
+        bidirectional_strategy: str = "add",
+        bidirectional_weight_tie: bool = True,
+        rcps: bool = True,
+        complement_map: Optional[dict] = None,
+        **kwargs,
+    ):
+        super().__init__(**kwargs)
+        self.d_model = d_model
+        self.n_layer = n_layer
+        self.vocab_size = vocab_size
+        self.ssm_cfg = dict(ssm_cfg) if ssm_cfg else {}
+        self.rms_norm = rms_norm
+        self.residual_in_fp32 = residual_in_fp32
+        self.fused_add_norm = fused_add_norm
+        self.pad_vocab_size_multiple = pad_vocab_size_multiple
+        self.norm_epsilon = norm_epsilon
+        self.initializer_cfg = initializer_cfg
+        self.bidirectional = bidirectional
+        self.bidirectional_strategy = bidirectional_strategy
+        self.bidirectional_weight_tie = bidirectional_weight_tie
+        self.rcps = rcps
+        if complement_map is None:
+            complement_map = DEFAULT_COMPLEMENT_MAP
+        # json round-trips dict keys as strings
+        self.complement_map = {int(k): int(v) for k, v in dict(complement_map).items()}
+
+    # ---- derived Mamba dimensions (mamba_ssm.Mamba defaults) -------------------------------
+    @property
+    def padded_vocab_size(self) -> int:
+        m = self.pad_vocab_size_multiple
+        return ((self.vocab_size + m - 1) // m) * m if m else self.vocab_size
+
+    @property
+    def d_state(self) -> int:
+        return int(self.ssm_cfg.get("d_state", 16))
+
+    @property
+    def d_conv(self) -> int:
+        return int(self.ssm_cfg.get("d_conv", 4))
+
+    @property
+    def expand(self) -> int:
+        return int(self.ssm_cfg.get("expand", 2))
+
+    @property
+    def d_inner(self) -> int:
+        return self.expand * self.d_model
+
+    @property
+    def dt_rank(self) -> int:
+        r = self.ssm_cfg.get("dt_rank", "auto")
+        return math.ceil(self.d_model / 16) if r == "auto" else int(r)
+
+    def complement_list(self) -> list:
+        v = self.padded_vocab_size
+        out = list(range(v))
+        for k, c in self.complement_map.items():
+            if k < v:
+                out[k] = c
+        return out
+
+    def check_supported(self) -> None:
+        """The MI355X engine implements exactly the PlantCaduceus family's configuration."""
+        bad = []
+        if not self.rcps:
+            bad.append("rcps=False")
+        if not self.bidirectional or self.bidirectional_strategy != "add":
+            bad.append("bidirectional must be True with strategy 'add'")
+        if not self.bidirectional_weight_tie:
+            bad.append("bidirectional_weight_tie=False")
+        if not self.rms_norm:
+            bad.append("rms_norm=False")
+        if self.d_conv != 4:
+            bad.append(f"d_conv={self.d_conv} (only 4)")
+        if self.d_state != 16:
+            bad.append(f"d_state={self.d_state} (only 16)")
+        if self.ssm_cfg.get("bias", False):
+            bad.append("ssm_cfg.bias=True")
+        if not self.ssm_cfg.get("conv_bias", True):
+            bad.append("ssm_cfg.conv_bias=False")
+        if self.d_model % 64:
+            bad.append(f"d_model={self.d_model} not a multiple of 64")
+        if self.padded_vocab_size != 8:
+            bad.append(f"padded vocab {self.padded_vocab_size} != 8")
+        if bad:
+            raise ValueError("unsupported Caduceus configuration for the MI355X engine: " + "; ".join(bad))
+
+
+# Published PlantCaduceus sizes (reference README.md:58-63); l20 dims confirmed by
+# notebooks/examples.ipynb:66,74-79.  Used only to build synthetic checkpoints.
+PLANTCADUCEUS_SIZES = {
+    "l20": dict(d_model=384, n_layer=20),
+    "l24": dict(d_model=512, n_layer=24),
+    "l28": dict(d_model=768, n_layer=28),
+    "l32": dict(d_model=1024, n_layer=32),
+}

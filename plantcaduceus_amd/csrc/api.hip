@@ -1,0 +1,413 @@
+// C-ABI of libpcad.so (see include/pcad.h): handle, weight binding, the per-layer launch sequence of the
+// PlantCaduceus forward on the 2B-strand batch, and the per-operator entry points.
+//
+// Forward = CaduceusForMaskedLM.forward restated per SURVEY.md Appendix A ("2B-strand form"): the RCPS
+// network equals a plain bi-directional Mamba stack applied to [ids ; reverse_complement(ids)], so no flip
+// or concatenation kernel exists here; the tied in_proj / out_proj run once per strand-layer.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/pcad.h"
+#include "kernels.hpp"
+
+using namespace pcad;
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                             \
+    do {                                                                                          \
+        hipError_t _e = (expr);                                                                   \
+        if (_e != hipSuccess) return fail(PCAD_ERR_HIP, "%s: %s", #expr, hipGetErrorString(_e)); \
+    } while (0)
+
+inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
+inline int round_up(int v, int a) { return (v + a - 1) / a * a; }
+
+struct DirWeights {
+    float *conv_w, *conv_b;   // [E,4], [E]
+    void* Wx;                 // [XP, E] dtype
+    void* Wdt;                // [E, Rp] dtype
+    float *dt_bias, *A2, *Dskip;
+};
+
+struct LayerWeights {
+    float* norm_w;   // [D]
+    void* W_in;      // [2E, D]
+    void* W_out;     // [D, E]
+    DirWeights dir[2];
+};
+
+}  // namespace
+
+struct pcad_engine {
+    pcad_config cfg;
+    int D, E, N, R, Rp, XP, V, nl;
+    int esz;        // bytes per activation element
+    int rdt;        // residual dtype
+    int chunk;      // sequences per pass through the layer stack
+    bool bound = false;
+    std::vector<LayerWeights> layers;
+    void* emb = nullptr;        // [V, D] dtype
+    float* emb_f32 = nullptr;   // [V, D] fp32 copy of the dtype-rounded table
+    float* normf_w = nullptr;
+    int32_t* comp = nullptr;    // [8] device
+};
+
+namespace {
+
+// ---- arena carving (identical walk for size query and binding) ------------------------------------
+struct Carver {
+    char* base;
+    size_t off = 0;
+    explicit Carver(void* b) : base((char*)b) {}
+    void* take(size_t bytes) {
+        void* p = base ? base + off : nullptr;
+        off += align_up(bytes);
+        return p;
+    }
+};
+
+void carve_weights(pcad_engine* e, Carver& c) {
+    const size_t D = e->D, E = e->E, N = e->N, V = e->V, esz = e->esz;
+    e->emb = c.take(V * D * esz);
+    e->emb_f32 = (float*)c.take(V * D * 4);
+    e->normf_w = (float*)c.take(D * 4);
+    e->comp = (int32_t*)c.take(8 * 4);
+    e->layers.resize(e->nl);
+    for (auto& L : e->layers) {
+        L.norm_w = (float*)c.take(D * 4);
+        L.W_in = c.take(2 * E * D * esz);
+        L.W_out = c.take(D * E * esz);
+        for (int d = 0; d < 2; ++d) {
+            DirWeights& w = L.dir[d];
+            w.conv_w = (float*)c.take(E * 4 * 4);
+            w.conv_b = (float*)c.take(E * 4);
+            w.Wx = c.take((size_t)e->XP * E * esz);
+            w.Wdt = c.take(E * (size_t)e->Rp * esz);
+            w.dt_bias = (float*)c.take(E * 4);
+            w.A2 = (float*)c.take(E * N * 4);
+            w.Dskip = (float*)c.take(E * 4);
+        }
+    }
+}
+
+struct Workspace {
+    void *res, *u, *h, *xz, *xc[2], *dbl[2], *delta, *y;
+    size_t bytes;
+};
+
+Workspace carve_workspace(const pcad_engine* e, void* base, int Bc, int L) {
+    Carver c(base);
+    const size_t rows = (size_t)2 * Bc * L;
+    const size_t D = e->D, E = e->E, esz = e->esz;
+    Workspace w;
+    w.res = c.take(rows * D * (e->rdt == F32 ? 4 : esz));
+    w.u = c.take(rows * D * esz);
+    w.h = c.take(rows * D * esz);
+    w.xz = c.take(rows * 2 * E * esz);
+    w.xc[0] = c.take(rows * E * esz);
+    w.xc[1] = c.take(rows * E * esz);
+    w.dbl[0] = c.take(rows * e->XP * esz);
+    w.dbl[1] = c.take(rows * e->XP * esz);
+    w.delta = c.take(rows * E * esz);
+    w.y = c.take(rows * E * esz);
+    w.bytes = c.off;
+    return w;
+}
+
+const pcad_tensor* find(const std::map<std::string, const pcad_tensor*>& m, const std::string& k) {
+    auto it = m.find(k);
+    return it == m.end() ? nullptr : it->second;
+}
+
+int64_t numel(const pcad_tensor* t) {
+    int64_t n = 1;
+    for (int i = 0; i < t->ndim; ++i) n *= t->shape[i];
+    return n;
+}
+
+}  // namespace
+
+extern "C" {
+
+int pcad_version(void) { return PCAD_VERSION; }
+const char* pcad_last_error(void) { return g_err; }
+
+int pcad_create(const pcad_config* cfg, pcad_handle* out) {
+    if (!cfg || !out) return fail(PCAD_ERR_INVALID, "pcad_create: null argument");
+    if (cfg->d_state != 16) return fail(PCAD_ERR_INVALID, "d_state=%d unsupported (16 only)", cfg->d_state);
+    if (cfg->d_conv != 4) return fail(PCAD_ERR_INVALID, "d_conv=%d unsupported (4 only)", cfg->d_conv);
+    if (cfg->vocab != 8) return fail(PCAD_ERR_INVALID, "padded vocab=%d unsupported (8 only)", cfg->vocab);
+    if (cfg->d_model <= 0 || cfg->d_model % 64 || cfg->d_model > 2048)
+        return fail(PCAD_ERR_INVALID, "d_model=%d must be a multiple of 64, <= 2048", cfg->d_model);
+    if (cfg->expand < 1 || cfg->n_layer < 1 || cfg->dt_rank < 1 || cfg->dt_rank > 256)
+        return fail(PCAD_ERR_INVALID, "bad expand/n_layer/dt_rank");
+    if (cfg->dtype != PCAD_F32 && cfg->dtype != PCAD_BF16) return fail(PCAD_ERR_INVALID, "bad dtype %d", cfg->dtype);
+    for (int i = 0; i < 8; ++i)
+        if (cfg->complement[i] < 0 || cfg->complement[i] > 7) return fail(PCAD_ERR_INVALID, "bad complement map");
+    pcad_engine* e = new pcad_engine();
+    e->cfg = *cfg;
+    e->D = cfg->d_model; e->E = cfg->expand * cfg->d_model; e->N = 16; e->R = cfg->dt_rank; e->V = 8;
+    e->nl = cfg->n_layer;
+    e->Rp = round_up(e->R, 64);          // K of dt_proj padded to the 128-byte K tile of either dtype
+    e->XP = e->Rp + 2 * e->N;            // x_proj rows: [dt (R) | 0-pad | B (16) | C (16)]
+    e->esz = cfg->dtype == PCAD_BF16 ? 2 : 4;
+    e->rdt = (cfg->residual_in_fp32 || cfg->dtype == PCAD_F32) ? F32 : BF16;
+    const char* ck = getenv("PCAD_CHUNK_SEQS");
+    e->chunk = ck ? atoi(ck) : 64;
+    if (e->chunk < 1) e->chunk = 1;
+    *out = e;
+    return PCAD_OK;
+}
+
+void pcad_destroy(pcad_handle h) { delete h; }
+
+size_t pcad_weight_arena_bytes(pcad_handle h) {
+    if (!h) return 0;
+    pcad_engine tmp = *h;
+    Carver c(nullptr);
+    carve_weights(&tmp, c);
+    return c.off;
+}
+
+int pcad_bind_weights(pcad_handle h, const pcad_tensor* tensors, int n, void* arena, size_t arena_bytes,
+                      pcad_stream stream) {
+    if (!h || !tensors || !arena) return fail(PCAD_ERR_INVALID, "pcad_bind_weights: null argument");
+    if (((uintptr_t)arena) % 256) return fail(PCAD_ERR_WORKSPACE, "weight arena must be 256-byte aligned");
+    if (arena_bytes < pcad_weight_arena_bytes(h))
+        return fail(PCAD_ERR_WORKSPACE, "weight arena too small: %zu < %zu", arena_bytes, pcad_weight_arena_bytes(h));
+    hipStream_t s = (hipStream_t)stream;
+    pcad_engine* e = h;
+    Carver c(arena);
+    carve_weights(e, c);
+    std::map<std::string, const pcad_tensor*> m;
+    for (int i = 0; i < n; ++i) {
+        if (!tensors[i].name || !tensors[i].data) return fail(PCAD_ERR_INVALID, "tensor %d has null name/data", i);
+        if (tensors[i].dtype != PCAD_F32 && tensors[i].dtype != PCAD_BF16)
+            return fail(PCAD_ERR_INVALID, "tensor %s: bad dtype", tensors[i].name);
+        m[tensors[i].name] = &tensors[i];
+    }
+    const int D = e->D, E = e->E, N = e->N, R = e->R, Rp = e->Rp, XP = e->XP, V = e->V, dt = e->cfg.dtype;
+    const std::string pre = "caduceus.backbone.";
+
+    auto need = [&](const std::string& k, int64_t expect) -> const pcad_tensor* {
+        const pcad_tensor* t = find(m, k);
+        if (!t) { fail(PCAD_ERR_MISSING, "missing tensor %s", k.c_str()); return nullptr; }
+        if (numel(t) != expect) {
+            fail(PCAD_ERR_INVALID, "tensor %s has %lld elements, expected %lld", k.c_str(), (long long)numel(t),
+                 (long long)expect);
+            return nullptr;
+        }
+        return t;
+    };
+#define NEED(var, key, cnt)                      \
+    const pcad_tensor* var = need((key), (cnt)); \
+    if (!var) return g_err[0] == 'm' ? PCAD_ERR_MISSING : PCAD_ERR_INVALID
+
+    NEED(t_emb, pre + "embeddings.word_embeddings.embedding.weight", (int64_t)V * D);
+    HIP_TRY(launch_pack2d(t_emb->data, t_emb->dtype, D, e->emb, dt, D, V, D, V, D, s));
+    // fp32 copy of the dtype-rounded table (what F.linear sees through the tied lm_head weight)
+    HIP_TRY(launch_pack2d(e->emb, dt, D, e->emb_f32, F32, D, V, D, V, D, s));
+    NEED(t_nf, pre + "norm_f.weight", (int64_t)D);
+    HIP_TRY(launch_pack2d(t_nf->data, t_nf->dtype, D, e->normf_w, F32, D, 1, D, 1, D, s));
+    HIP_TRY(hipMemcpyAsync(e->comp, e->cfg.complement, 8 * sizeof(int32_t), hipMemcpyHostToDevice, s));
+    // the source array lives in the handle, so the async copy's host buffer stays valid
+
+    for (int i = 0; i < e->nl; ++i) {
+        LayerWeights& L = e->layers[i];
+        const std::string lp = pre + "layers." + std::to_string(i) + ".";
+        NEED(t_norm, lp + "norm.weight", (int64_t)D);
+        HIP_TRY(launch_pack2d(t_norm->data, t_norm->dtype, D, L.norm_w, F32, D, 1, D, 1, D, s));
+        const std::string mf = lp + "mixer.submodule.mamba_fwd.";
+        NEED(t_in, mf + "in_proj.weight", (int64_t)2 * E * D);
+        HIP_TRY(launch_pack2d(t_in->data, t_in->dtype, D, L.W_in, dt, D, 2 * E, D, 2 * E, D, s));
+        NEED(t_out, mf + "out_proj.weight", (int64_t)D * E);
+        HIP_TRY(launch_pack2d(t_out->data, t_out->dtype, E, L.W_out, dt, E, D, E, D, E, s));
+        for (int d = 0; d < 2; ++d) {
+            DirWeights& w = L.dir[d];
+            const std::string mp = lp + "mixer.submodule.mamba_" + (d == 0 ? "fwd." : "rev.");
+            NEED(t_cw, mp + "conv1d.weight", (int64_t)E * 4);
+            HIP_TRY(launch_pack2d(t_cw->data, t_cw->dtype, 4, w.conv_w, F32, 4, E, 4, E, 4, s));
+            NEED(t_cb, mp + "conv1d.bias", (int64_t)E);
+            HIP_TRY(launch_pack2d(t_cb->data, t_cb->dtype, E, w.conv_b, F32, E, 1, E, 1, E, s));
+            NEED(t_x, mp + "x_proj.weight", (int64_t)(R + 2 * N) * E);
+            // rows [0,R) -> [0,R); zero rows [R,Rp); rows [R, R+2N) -> [Rp, Rp+2N)
+            const size_t esz_src = t_x->dtype == PCAD_BF16 ? 2 : 4;
+            HIP_TRY(launch_pack2d(t_x->data, t_x->dtype, E, w.Wx, dt, E, R, E, Rp, E, s));
+            HIP_TRY(launch_pack2d((const char*)t_x->data + (size_t)R * E * esz_src, t_x->dtype, E,
+                                  (char*)w.Wx + (size_t)Rp * E * e->esz, dt, E, 2 * N, E, 2 * N, E, s));
+            NEED(t_dw, mp + "dt_proj.weight", (int64_t)E * R);
+            HIP_TRY(launch_pack2d(t_dw->data, t_dw->dtype, R, w.Wdt, dt, Rp, E, R, E, Rp, s));
+            NEED(t_db, mp + "dt_proj.bias", (int64_t)E);
+            HIP_TRY(launch_pack2d(t_db->data, t_db->dtype, E, w.dt_bias, F32, E, 1, E, 1, E, s));
+            NEED(t_A, mp + "A_log", (int64_t)E * N);
+            HIP_TRY(launch_pack_A(t_A->data, t_A->dtype, w.A2, (int64_t)E * N, 1.4426950408889634f, s));
+            NEED(t_D, mp + "D", (int64_t)E);
+            HIP_TRY(launch_pack2d(t_D->data, t_D->dtype, E, w.Dskip, F32, E, 1, E, 1, E, s));
+        }
+    }
+#undef NEED
+    e->bound = true;
+    return PCAD_OK;
+}
+
+size_t pcad_workspace_bytes(pcad_handle h, int batch, int seqlen) {
+    if (!h || batch <= 0 || seqlen <= 0) return 0;
+    const int Bc = batch < h->chunk ? batch : h->chunk;
+    return carve_workspace(h, nullptr, Bc, seqlen).bytes;
+}
+
+static int forward_impl(pcad_handle h, const int32_t* ids, int B, int L, const int32_t* positions, int P,
+                        void* all_hidden, void* hidden_out, float* logits_out, void* workspace, size_t ws_bytes,
+                        pcad_stream stream) {
+    if (!h) return fail(PCAD_ERR_INVALID, "pcad_forward: null handle");
+    pcad_engine* e = h;
+    if (!e->bound) return fail(PCAD_ERR_UNBOUND, "pcad_forward: weights not bound");
+    if (B < 0 || L <= 0) return fail(PCAD_ERR_INVALID, "pcad_forward: bad B=%d L=%d", B, L);
+    if (B == 0) return PCAD_OK;
+    if (!ids || !workspace) return fail(PCAD_ERR_INVALID, "pcad_forward: null ids/workspace");
+    if (P < 0 || P > PCAD_MAX_POSITIONS || (P > 0 && !positions))
+        return fail(PCAD_ERR_INVALID, "pcad_forward: bad positions (P=%d)", P);
+    Positions pos;
+    pos.n = P;
+    for (int i = 0; i < 16; ++i) pos.p[i] = 0;
+    for (int i = 0; i < P; ++i) {
+        if (positions[i] < 0 || positions[i] >= L)
+            return fail(PCAD_ERR_INVALID, "pcad_forward: position %d out of range [0,%d)", positions[i], L);
+        pos.p[i] = positions[i];
+    }
+    if (((uintptr_t)workspace) % 256) return fail(PCAD_ERR_WORKSPACE, "workspace must be 256-byte aligned");
+    const size_t need = pcad_workspace_bytes(h, B, L);
+    if (ws_bytes < need) return fail(PCAD_ERR_WORKSPACE, "workspace too small: %zu < %zu", ws_bytes, need);
+
+    hipStream_t s = (hipStream_t)stream;
+    const int D = e->D, E = e->E, N = e->N, Rp = e->Rp, XP = e->XP, dt = e->cfg.dtype, rdt = e->rdt;
+    const size_t esz = e->esz;
+    const float eps = e->cfg.eps;
+    const int Q = P ? P : L;
+
+    for (int b0 = 0; b0 < B; b0 += e->chunk) {
+        const int Bc = (B - b0) < e->chunk ? (B - b0) : e->chunk;
+        const int S = 2 * Bc;
+        const int64_t rows = (int64_t)S * L;
+        Workspace w = carve_workspace(e, workspace, Bc, L);
+        const int32_t* ids_c = ids + (int64_t)b0 * L;
+
+        if (all_hidden) {   // hidden_states[0] = RCPSEmbedding output
+            HIP_TRY(launch_embed_only(ids_c, e->emb, e->comp, w.h, Bc, L, D, dt, s));
+            HIP_TRY(launch_assemble_hidden(w.h, (char*)all_hidden + ((size_t)b0 * L * 2 * D) * esz, Bc, L, D, dt, s));
+        }
+        for (int li = 0; li < e->nl; ++li) {
+            const LayerWeights& W = e->layers[li];
+            if (li == 0) {
+                HIP_TRY(launch_embed_rmsnorm(ids_c, e->emb, e->comp, W.norm_w, w.u, w.res, Bc, L, D, eps, dt, rdt, s));
+            } else {
+                HIP_TRY(launch_add_rmsnorm(w.h, w.res, W.norm_w, w.u, w.res, rows, D, eps, dt, rdt, s));
+            }
+            // in_proj (tied between directions: once per strand)
+            HIP_TRY(launch_gemm_nt(w.u, D, W.W_in, D, w.xz, 2 * E, rows, 2 * E, D, dt, dt, false, s));
+            // conv1d + SiLU, causal and anti-causal from one read of x
+            HIP_TRY(launch_conv_bidir(w.xz, 2 * E, W.dir[0].conv_w, W.dir[0].conv_b, W.dir[1].conv_w, W.dir[1].conv_b,
+                                      w.xc[0], w.xc[1], S, L, E, dt, s));
+            for (int d = 0; d < 2; ++d) {
+                const DirWeights& dw = W.dir[d];
+                // x_proj -> [dt_low (Rp, zero padded) | B | C]
+                HIP_TRY(launch_gemm_nt(w.xc[d], E, dw.Wx, E, w.dbl[d], XP, rows, XP, E, dt, dt, false, s));
+                // dt_proj (bias + softplus are applied inside the scan)
+                HIP_TRY(launch_gemm_nt(w.dbl[d], XP, dw.Wdt, Rp, w.delta, E, rows, E, Rp, dt, dt, false, s));
+                const char* bc = (const char*)w.dbl[d];
+                HIP_TRY(launch_scan(w.xc[d], w.delta, (const char*)w.xz + (size_t)E * esz, 2 * E, bc + (size_t)Rp * esz,
+                                    bc + (size_t)(Rp + N) * esz, XP, dw.A2, 1.0f, dw.Dskip, dw.dt_bias, w.y, S, L, E, d == 1,
+                                    d == 1, dt, s));
+            }
+            // out_proj on (y_fwd + y_rev): the two tied out_proj calls folded by linearity
+            HIP_TRY(launch_gemm_nt(w.y, E, W.W_out, E, w.h, D, rows, D, E, dt, dt, false, s));
+            if (all_hidden && li + 1 < e->nl) {
+                char* dst = (char*)all_hidden + ((size_t)(li + 1) * B * L * 2 * D + (size_t)b0 * L * 2 * D) * esz;
+                HIP_TRY(launch_assemble_hidden(w.h, dst, Bc, L, D, dt, s));
+            }
+        }
+        void* hout = hidden_out ? (char*)hidden_out + ((size_t)b0 * Q * 2 * D) * esz : nullptr;
+        float* lout = logits_out ? logits_out + (size_t)b0 * Q * e->V : nullptr;
+        if (hout || lout)
+            HIP_TRY(launch_final_head(w.h, w.res, e->normf_w, e->emb, e->emb_f32, e->comp, hout, lout, Bc, L, D, eps, pos,
+                                      dt, rdt, s));
+    }
+    return PCAD_OK;
+}
+
+int pcad_forward(pcad_handle h, const int32_t* ids, int B, int L, const int32_t* positions, int P, void* hidden_out,
+                 float* logits_out, void* workspace, size_t workspace_bytes, pcad_stream stream) {
+    return forward_impl(h, ids, B, L, positions, P, nullptr, hidden_out, logits_out, workspace, workspace_bytes, stream);
+}
+
+int pcad_forward_all_hidden(pcad_handle h, const int32_t* ids, int B, int L, void* all_hidden, void* hidden_out,
+                            float* logits_out, void* workspace, size_t workspace_bytes, pcad_stream stream) {
+    if (!all_hidden) return fail(PCAD_ERR_INVALID, "pcad_forward_all_hidden: null all_hidden");
+    return forward_impl(h, ids, B, L, nullptr, 0, all_hidden, hidden_out, logits_out, workspace, workspace_bytes,
+                        stream);
+}
+
+// ---- per-operator entry points -------------------------------------------------------------------
+int pcad_add_rmsnorm(const void* x, const void* residual_in, const float* weight, void* y, void* residual_out,
+                     int64_t rows, int D, float eps, int dtype, int res_dtype, pcad_stream stream) {
+    if (!x || !weight || !y) return fail(PCAD_ERR_INVALID, "pcad_add_rmsnorm: null argument");
+    if (rows < 0 || D <= 0 || D % 8 || D > 2048) return fail(PCAD_ERR_INVALID, "pcad_add_rmsnorm: bad rows/D");
+    HIP_TRY(launch_add_rmsnorm(x, residual_in, weight, y, residual_out, rows, D, eps, dtype, res_dtype,
+                               (hipStream_t)stream));
+    return PCAD_OK;
+}
+
+int pcad_causal_conv1d_silu(const void* x, int64_t ldx, const float* w_fwd, const float* b_fwd, const float* w_rev,
+                            const float* b_rev, void* y_fwd, void* y_rev, int S, int L, int E, int dtype,
+                            pcad_stream stream) {
+    if (!x || !w_fwd || !b_fwd || !w_rev || !b_rev) return fail(PCAD_ERR_INVALID, "pcad_causal_conv1d_silu: null argument");
+    if (S < 0 || L < 0 || E <= 0 || E % 8 || ldx < E || ldx % 8)
+        return fail(PCAD_ERR_INVALID, "pcad_causal_conv1d_silu: bad shape (E and ldx must be multiples of 8)");
+    HIP_TRY(launch_conv_bidir(x, ldx, w_fwd, b_fwd, w_rev, b_rev, y_fwd, y_rev, S, L, E, dtype, (hipStream_t)stream));
+    return PCAD_OK;
+}
+
+int pcad_selective_scan(const void* u, const void* delta, const void* z, int64_t ldz, const void* Bm, const void* Cm,
+                        int64_t ldbc, const float* A, const float* Dskip, const float* delta_bias, void* y, int S, int L,
+                        int E, int reverse, int accumulate, int dtype, pcad_stream stream) {
+    if (!u || !delta || !Bm || !Cm || !A || !Dskip || !delta_bias || !y)
+        return fail(PCAD_ERR_INVALID, "pcad_selective_scan: null argument");
+    if (S < 0 || L < 0 || E <= 0 || E % 64) return fail(PCAD_ERR_INVALID, "pcad_selective_scan: E must be a multiple of 64");
+    if (ldbc % 2 || ((uintptr_t)Bm) % 4 || ((uintptr_t)Cm) % 4)
+        return fail(PCAD_ERR_INVALID, "pcad_selective_scan: B/C rows must be 4-byte aligned");
+    if (S == 0 || L == 0) return PCAD_OK;
+    // raw A is scaled by log2(e) when the kernel loads it into registers (the engine passes pre-scaled A)
+    HIP_TRY(launch_scan(u, delta, z, ldz, Bm, Cm, ldbc, A, 1.4426950408889634f, Dskip, delta_bias, y, S, L, E,
+                        reverse != 0, accumulate != 0, dtype, (hipStream_t)stream));
+    return PCAD_OK;
+}
+
+int pcad_gemm_nt(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc, int64_t M, int N, int K,
+                 int dtype, int out_dtype, pcad_stream stream) {
+    if (!A || !W || !C) return fail(PCAD_ERR_INVALID, "pcad_gemm_nt: null argument");
+    hipError_t err = launch_gemm_nt(A, lda, W, ldw, C, ldc, M, N, K, dtype, out_dtype, false, (hipStream_t)stream);
+    if (err == hipErrorInvalidValue)
+        return fail(PCAD_ERR_INVALID, "pcad_gemm_nt: K*elem must be a multiple of 128 bytes; A/W 16-byte aligned rows");
+    if (err != hipSuccess) return fail(PCAD_ERR_HIP, "pcad_gemm_nt: %s", hipGetErrorString(err));
+    return PCAD_OK;
+}
+
+}  // extern "C"

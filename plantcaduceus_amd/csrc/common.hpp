@@ -1,0 +1,94 @@
+// Shared device helpers for the gfx950 kernels (wave64, bf16 bit tricks, wave reductions).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace pcad {
+
+typedef uint16_t bf16_t;   // raw bfloat16 bits
+
+typedef float    f32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+__device__ __forceinline__ float bf16lo_to_f32(uint32_t v) { return __uint_as_float(v << 16); }
+__device__ __forceinline__ float bf16hi_to_f32(uint32_t v) { return __uint_as_float(v & 0xffff0000u); }
+
+// round-to-nearest-even fp32 -> bf16 (finite inputs; NaN payloads are not preserved)
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
+    uint32_t u = __float_as_uint(f);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (bf16_t)(u >> 16);
+}
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+    return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+}
+__device__ __forceinline__ float round_to_bf16(float f) { return bf16_to_f32(f32_to_bf16(f)); }
+
+// storage-type traits: T is `float` or `bf16_t`
+template <typename T> struct Elem;
+template <> struct Elem<float> {
+    static __device__ __forceinline__ float load(const float* p) { return *p; }
+    static __device__ __forceinline__ void store(float* p, float v) { *p = v; }
+    static __device__ __forceinline__ float round(float v) { return v; }
+};
+template <> struct Elem<bf16_t> {
+    static __device__ __forceinline__ float load(const bf16_t* p) { return bf16_to_f32(*p); }
+    static __device__ __forceinline__ void store(bf16_t* p, float v) { *p = f32_to_bf16(v); }
+    static __device__ __forceinline__ float round(float v) { return round_to_bf16(v); }
+};
+
+// 8 consecutive elements <-> 8 floats (16-byte accesses for bf16, 2x16 bytes for fp32)
+template <typename T> __device__ __forceinline__ void load8(const T* p, float (&v)[8]);
+template <> __device__ __forceinline__ void load8<float>(const float* p, float (&v)[8]) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(p);
+    const f32x4 b = *reinterpret_cast<const f32x4*>(p + 4);
+    v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3];
+    v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
+}
+template <> __device__ __forceinline__ void load8<bf16_t>(const bf16_t* p, float (&v)[8]) {
+    const u32x4 a = *reinterpret_cast<const u32x4*>(p);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { v[2 * i] = bf16lo_to_f32(a[i]); v[2 * i + 1] = bf16hi_to_f32(a[i]); }
+}
+template <typename T> __device__ __forceinline__ void store8(T* p, const float (&v)[8]);
+template <> __device__ __forceinline__ void store8<float>(float* p, const float (&v)[8]) {
+    f32x4 a = {v[0], v[1], v[2], v[3]}, b = {v[4], v[5], v[6], v[7]};
+    *reinterpret_cast<f32x4*>(p) = a;
+    *reinterpret_cast<f32x4*>(p + 4) = b;
+}
+template <> __device__ __forceinline__ void store8<bf16_t>(bf16_t* p, const float (&v)[8]) {
+    u32x4 a;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a[i] = pack_bf16x2(v[2 * i], v[2 * i + 1]);
+    *reinterpret_cast<u32x4*>(p) = a;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }   // v_exp_f32
+__device__ __forceinline__ float fast_log2(float x) { return __builtin_amdgcn_logf(x); }    // v_log_f32
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }     // v_rcp_f32
+
+constexpr float kLog2e = 1.4426950408889634f;
+constexpr float kLn2 = 0.6931471805599453f;
+
+// silu(v) = v / (1 + exp(-v))
+__device__ __forceinline__ float silu(float v) { return v * fast_rcp(1.0f + fast_exp2(-v * kLog2e)); }
+
+// softplus with torch's threshold (20); log1p evaluated with Kahan's correction so that small
+// time-steps (softplus(-7) ~ 1e-3) keep full fp32 relative accuracy.
+__device__ __forceinline__ float softplus(float x) {
+    const float e = fast_exp2(x * kLog2e);
+    const float w = 1.0f + e;
+    const float d = w - 1.0f;
+    const float l = (d == 0.0f) ? e : fast_log2(w) * kLn2 * (e * fast_rcp(d));
+    return x > 20.0f ? x : l;
+}
+
+}  // namespace pcad

@@ -1,0 +1,55 @@
+// Host-side launcher declarations (one per kernel family). All launch on the given stream; no sync.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace pcad {
+
+enum DType { F32 = 0, BF16 = 1 };
+
+struct Positions {            // by-value kernel argument: the positions evaluated by the head kernel
+    int n;                    // 0 => all L positions
+    int p[16];
+};
+
+// norm.hip --------------------------------------------------------------------------------------
+// fused residual add + RMSNorm (rms_norm_fn prenorm=True).  x/y dtype `dt`; residuals `rdt`.
+hipError_t launch_add_rmsnorm(const void* x, const void* res_in, const float* w, void* y, void* res_out,
+                              int64_t rows, int D, float eps, int dt, int rdt, hipStream_t s);
+// layer-0 variant: x = Emb[strand token] gathered on the fly (RCPS strands by index arithmetic).
+hipError_t launch_embed_rmsnorm(const int32_t* ids, const void* emb, const int32_t* comp8, const float* w,
+                                void* y, void* res_out, int B, int L, int D, float eps, int dt, int rdt,
+                                hipStream_t s);
+// final add + norm_f + RC re-assembly + tied RCPS LM head, only at the requested positions.
+hipError_t launch_final_head(const void* h, const void* res, const float* w, const void* emb,
+                             const float* emb_f32, const int32_t* comp8, void* hidden_out, float* logits_out,
+                             int B, int L, int D, float eps, Positions pos, int dt, int rdt, hipStream_t s);
+// hidden_states[i] (block input = previous mixer output / embedding) assembled in RCPS layout.
+hipError_t launch_assemble_hidden(const void* h, void* out, int B, int L, int D, int dt, hipStream_t s);
+hipError_t launch_embed_only(const int32_t* ids, const void* emb, const int32_t* comp8, void* h, int B, int L,
+                             int D, int dt, hipStream_t s);
+
+// gemm.hip --------------------------------------------------------------------------------------
+// C[M,N] = A[M,K] W[N,K]^T.  K multiple of 128 bytes; lda/ldw multiples of 16 bytes.
+// out_dt: F32 or == dt.  round_bf16: round the fp32 result to bf16 precision before an F32 store.
+hipError_t launch_gemm_nt(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc,
+                          int64_t M, int N, int K, int dt, int out_dt, bool round_bf16, hipStream_t s);
+
+// conv.hip --------------------------------------------------------------------------------------
+hipError_t launch_conv_bidir(const void* x, int64_t ldx, const float* wf, const float* bf, const float* wr,
+                             const float* br, void* yf, void* yr, int S, int L, int E, int dt, hipStream_t s);
+
+// scan.hip --------------------------------------------------------------------------------------
+// The recurrence uses A2 * a_scale as the base-2 decay rate: pass (A * log2(e), 1) or (A, log2(e)).
+hipError_t launch_scan(const void* u, const void* delta, const void* z, int64_t ldz, const void* Bm,
+                       const void* Cm, int64_t ldbc, const float* A2, float a_scale, const float* Dskip, const float* dbias,
+                       void* y, int S, int L, int E, bool reverse, bool accumulate, int dt, hipStream_t s);
+
+// pack.hip --------------------------------------------------------------------------------------
+// generic 2-D copy/convert with zero padding: dst[r, c] (dst_dt, ld = dst_ld) = src[r, c] for r < rows, c < cols else 0
+hipError_t launch_pack2d(const void* src, int src_dt, int64_t src_ld, void* dst, int dst_dt, int64_t dst_ld,
+                         int rows, int cols, int dst_rows, int dst_cols, hipStream_t s);
+// A2[e, n] = -exp(A_log[e, n]) * log2(e)   (A_log read through its storage dtype)
+hipError_t launch_pack_A(const void* A_log, int src_dt, float* A2, int64_t n, float scale, hipStream_t s);
+
+}  // namespace pcad

@@ -1,0 +1,309 @@
+// Fused residual-add + RMSNorm family (HBM-bound; one wave per token row, 16-byte accesses).
+//
+// Replaces mamba_ssm.ops.triton.layer_norm.rms_norm_fn as called by RCPSMambaBlock (fused_add_norm=True)
+// and the final norm_f.  The reference runs it twice per layer — once per RC
+// half, the rc half on a flipped copy; here both strands are plain rows of the 2B-strand batch, so one
+// launch covers them and no flip copy exists.  The layer-0 variant gathers the embedding rows on the fly
+// (RCPSEmbedding: rc strand = complement of the reversed ids, by index arithmetic), and the final variant
+// fuses norm_f, the RC re-assembly of hidden_states[-1] and the tied RCPS LM head at the requested
+// positions only.
+#include "common.hpp"
+#include "kernels.hpp"
+
+namespace pcad {
+
+template <typename T, typename RT, int MAXC, bool EMBED>
+__global__ __launch_bounds__(256) void add_rmsnorm_kernel(const T* __restrict__ x, const RT* __restrict__ res_in,
+                                                          const float* __restrict__ w, T* __restrict__ y,
+                                                          RT* __restrict__ res_out, int64_t rows, int D, float eps,
+                                                          const int32_t* __restrict__ ids,
+                                                          const int32_t* __restrict__ comp8, int B, int L) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int nchunk = D >> 3;
+    const T* xr;
+    if constexpr (EMBED) {
+        const int s = (int)(row / L), t = (int)(row - (int64_t)s * L);
+        int tok;
+        if (s < B) tok = ids[(int64_t)s * L + t];
+        else tok = comp8[ids[(int64_t)(s - B) * L + (L - 1 - t)] & 7];
+        xr = x + (int64_t)(tok & 7) * D;
+    } else {
+        xr = x + row * D;
+    }
+    float v[MAXC][8];
+    float ss = 0.f;
+#pragma unroll
+    for (int j = 0; j < MAXC; ++j) {
+        const int c = lane + 64 * j;
+        if (c < nchunk) {
+            load8<T>(xr + c * 8, v[j]);
+            if (res_in != nullptr) {
+                float r[8];
+                load8<RT>(res_in + row * D + c * 8, r);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[j][i] += r[i];
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) ss += v[j][i] * v[j][i];
+            if (res_out != nullptr) store8<RT>(res_out + row * D + c * 8, v[j]);
+        }
+    }
+    ss = wave_sum(ss);
+    const float rstd = rsqrtf(ss / (float)D + eps);
+#pragma unroll
+    for (int j = 0; j < MAXC; ++j) {
+        const int c = lane + 64 * j;
+        if (c < nchunk) {
+            float wv[8], o[8];
+            load8<float>(w + c * 8, wv);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) o[i] = v[j][i] * rstd * wv[i];
+            store8<T>(y + row * D + c * 8, o);
+        }
+    }
+}
+
+template <typename T, typename RT, bool EMBED>
+static hipError_t launch_norm_t(const T* x, const RT* res_in, const float* w, T* y, RT* res_out, int64_t rows, int D,
+                                float eps, const int32_t* ids, const int32_t* comp8, int B, int L, hipStream_t s) {
+    if (rows <= 0) return hipSuccess;
+    dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+    if (D <= 512)
+        hipLaunchKernelGGL((add_rmsnorm_kernel<T, RT, 1, EMBED>), grid, block, 0, s, x, res_in, w, y, res_out, rows, D,
+                           eps, ids, comp8, B, L);
+    else if (D <= 1024)
+        hipLaunchKernelGGL((add_rmsnorm_kernel<T, RT, 2, EMBED>), grid, block, 0, s, x, res_in, w, y, res_out, rows, D,
+                           eps, ids, comp8, B, L);
+    else
+        hipLaunchKernelGGL((add_rmsnorm_kernel<T, RT, 4, EMBED>), grid, block, 0, s, x, res_in, w, y, res_out, rows, D,
+                           eps, ids, comp8, B, L);
+    return hipGetLastError();
+}
+
+template <bool EMBED>
+static hipError_t dispatch_norm(const void* x, const void* res_in, const float* w, void* y, void* res_out,
+                                int64_t rows, int D, float eps, int dt, int rdt, const int32_t* ids,
+                                const int32_t* comp8, int B, int L, hipStream_t s) {
+    if (D % 8 || D > 2048) return hipErrorInvalidValue;
+    if (dt == BF16 && rdt == F32)
+        return launch_norm_t<bf16_t, float, EMBED>((const bf16_t*)x, (const float*)res_in, w, (bf16_t*)y,
+                                                    (float*)res_out, rows, D, eps, ids, comp8, B, L, s);
+    if (dt == BF16 && rdt == BF16)
+        return launch_norm_t<bf16_t, bf16_t, EMBED>((const bf16_t*)x, (const bf16_t*)res_in, w, (bf16_t*)y,
+                                                     (bf16_t*)res_out, rows, D, eps, ids, comp8, B, L, s);
+    if (dt == F32 && rdt == F32)
+        return launch_norm_t<float, float, EMBED>((const float*)x, (const float*)res_in, w, (float*)y,
+                                                   (float*)res_out, rows, D, eps, ids, comp8, B, L, s);
+    return hipErrorInvalidValue;
+}
+
+hipError_t launch_add_rmsnorm(const void* x, const void* res_in, const float* w, void* y, void* res_out, int64_t rows,
+                              int D, float eps, int dt, int rdt, hipStream_t s) {
+    return dispatch_norm<false>(x, res_in, w, y, res_out, rows, D, eps, dt, rdt, nullptr, nullptr, 0, 1, s);
+}
+
+hipError_t launch_embed_rmsnorm(const int32_t* ids, const void* emb, const int32_t* comp8, const float* w, void* y,
+                                void* res_out, int B, int L, int D, float eps, int dt, int rdt, hipStream_t s) {
+    return dispatch_norm<true>(emb, nullptr, w, y, res_out, (int64_t)2 * B * L, D, eps, dt, rdt, ids, comp8, B, L, s);
+}
+
+// ------------------------------------------------------------------------------------------------
+// final: res = h + res ; H = norm_f(res) ; hidden[b,q] = cat(Hf[b,p], reverse_channels(Hr[b,L-1-p])) ;
+// logits[b,q,v] = Hf[b,p].Emb[v] + Hr[b,L-1-p].Emb[comp[v]]   (RCPSLMHead, weight tied to the embedding)
+// block = 2 waves: wave 0 the forward strand row, wave 1 the rc strand row.
+// ------------------------------------------------------------------------------------------------
+template <typename T, typename RT, int MAXC>
+__global__ __launch_bounds__(128) void final_head_kernel(const T* __restrict__ h, const RT* __restrict__ res,
+                                                         const float* __restrict__ w, const float* __restrict__ emb,
+                                                         const int32_t* __restrict__ comp8, T* __restrict__ hidden_out,
+                                                         float* __restrict__ logits_out, int B, int L, int D, float eps,
+                                                         Positions pos) {
+    __shared__ float part[8];
+    const int lane = threadIdx.x & 63;
+    const int wv = threadIdx.x >> 6;   // 0: forward strand, 1: rc strand
+    const int Q = pos.n ? pos.n : L;
+    const int b = blockIdx.x / Q, q = blockIdx.x - b * Q;
+    int p = q;
+    if (pos.n) {
+        // uniform select from the by-value array (avoids runtime-indexed kernarg scratch)
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+            if (i == q) p = pos.p[i];
+    }
+    const int64_t row = wv == 0 ? ((int64_t)b * L + p) : ((int64_t)(B + b) * L + (L - 1 - p));
+    const int nchunk = D >> 3;
+    float v[MAXC][8];
+    float ss = 0.f;
+#pragma unroll
+    for (int j = 0; j < MAXC; ++j) {
+        const int c = lane + 64 * j;
+        if (c < nchunk) {
+            float r[8];
+            load8<T>(h + row * D + c * 8, v[j]);
+            load8<RT>(res + row * D + c * 8, r);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { v[j][i] += r[i]; ss += v[j][i] * v[j][i]; }
+        }
+    }
+    ss = wave_sum(ss);
+    const float rstd = rsqrtf(ss / (float)D + eps);
+    float acc[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc[k] = 0.f;
+#pragma unroll
+    for (int j = 0; j < MAXC; ++j) {
+        const int c = lane + 64 * j;
+        if (c < nchunk) {
+            float wvv[8], o[8];
+            load8<float>(w + c * 8, wvv);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) o[i] = Elem<T>::round(v[j][i] * rstd * wvv[i]);
+            if (hidden_out != nullptr) {
+                T* dst = hidden_out + ((int64_t)b * Q + q) * 2 * D;
+                if (wv == 0) {
+                    store8<T>(dst + c * 8, o);
+                } else {
+                    float rv[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) rv[i] = o[7 - i];
+                    store8<T>(dst + D + (D - 8 - c * 8), rv);
+                }
+            }
+            if (logits_out != nullptr) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int er = wv == 0 ? k : (comp8[k] & 7);
+                    float e[8];
+                    load8<float>(emb + (int64_t)er * D + c * 8, e);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) acc[k] += o[i] * e[i];
+                }
+            }
+        }
+    }
+    if (logits_out != nullptr) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc[k] = Elem<T>::round(wave_sum(acc[k]));
+        if (wv == 1 && lane < 8) {
+            float mine = acc[0];
+#pragma unroll
+            for (int k = 1; k < 8; ++k) mine = (lane == k) ? acc[k] : mine;
+            part[lane] = mine;
+        }
+        __syncthreads();
+        if (wv == 0 && lane < 8) {
+            float mine = acc[0];
+#pragma unroll
+            for (int k = 1; k < 8; ++k) mine = (lane == k) ? acc[k] : mine;
+            logits_out[((int64_t)b * Q + q) * 8 + lane] = Elem<T>::round(mine + part[lane]);
+        }
+    }
+}
+
+template <typename T, typename RT>
+static hipError_t launch_final_t(const void* h, const void* res, const float* w, const float* emb_f32,
+                                 const int32_t* comp8, void* hidden_out, float* logits_out, int B, int L, int D,
+                                 float eps, Positions pos, hipStream_t s) {
+    const int Q = pos.n ? pos.n : L;
+    dim3 grid((unsigned)(B * Q)), block(128);
+    if (B * Q == 0) return hipSuccess;
+#define PCAD_FH(MC)                                                                                          \
+    hipLaunchKernelGGL((final_head_kernel<T, RT, MC>), grid, block, 0, s, (const T*)h, (const RT*)res, w, emb_f32, \
+                       comp8, (T*)hidden_out, logits_out, B, L, D, eps, pos)
+    if (D <= 512) PCAD_FH(1);
+    else if (D <= 1024) PCAD_FH(2);
+    else PCAD_FH(4);
+#undef PCAD_FH
+    return hipGetLastError();
+}
+
+hipError_t launch_final_head(const void* h, const void* res, const float* w, const void* /*emb*/,
+                             const float* emb_f32, const int32_t* comp8, void* hidden_out, float* logits_out, int B,
+                             int L, int D, float eps, Positions pos, int dt, int rdt, hipStream_t s) {
+    if (D % 8 || D > 2048) return hipErrorInvalidValue;
+    if (dt == BF16 && rdt == F32)
+        return launch_final_t<bf16_t, float>(h, res, w, emb_f32, comp8, hidden_out, logits_out, B, L, D, eps, pos, s);
+    if (dt == BF16 && rdt == BF16)
+        return launch_final_t<bf16_t, bf16_t>(h, res, w, emb_f32, comp8, hidden_out, logits_out, B, L, D, eps, pos, s);
+    if (dt == F32 && rdt == F32)
+        return launch_final_t<float, float>(h, res, w, emb_f32, comp8, hidden_out, logits_out, B, L, D, eps, pos, s);
+    return hipErrorInvalidValue;
+}
+
+// ------------------------------------------------------------------------------------------------
+// hidden_states[i] in the reference's RCPS layout from the 2B-strand tensor:
+// out[b,l,:D] = h[b,l,:] ; out[b,l,D+j] = h[B+b, L-1-l, D-1-j]
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void assemble_hidden_kernel(const T* __restrict__ h, T* __restrict__ out, int B,
+                                                              int L, int D) {
+    const int nchunk = D >> 3;
+    const int64_t total = (int64_t)2 * B * L * nchunk;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % nchunk);
+        const int64_t row = i / nchunk;
+        const int s = (int)(row / L), t = (int)(row - (int64_t)s * L);
+        float v[8];
+        load8<T>(h + row * D + c * 8, v);
+        if (s < B) {
+            store8<T>(out + ((int64_t)s * L + t) * 2 * D + c * 8, v);
+        } else {
+            float rv[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) rv[k] = v[7 - k];
+            store8<T>(out + ((int64_t)(s - B) * L + (L - 1 - t)) * 2 * D + D + (D - 8 - c * 8), rv);
+        }
+    }
+}
+
+hipError_t launch_assemble_hidden(const void* h, void* out, int B, int L, int D, int dt, hipStream_t s) {
+    if (B * L == 0) return hipSuccess;
+    const int64_t total = (int64_t)2 * B * L * (D >> 3);
+    const unsigned grid = (unsigned)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
+    if (dt == BF16)
+        hipLaunchKernelGGL(assemble_hidden_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)h, (bf16_t*)out,
+                           B, L, D);
+    else
+        hipLaunchKernelGGL(assemble_hidden_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)h, (float*)out, B,
+                           L, D);
+    return hipGetLastError();
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void embed_only_kernel(const int32_t* __restrict__ ids, const T* __restrict__ emb,
+                                                         const int32_t* __restrict__ comp8, T* __restrict__ h, int B,
+                                                         int L, int D) {
+    const int nchunk = D >> 3;
+    const int64_t total = (int64_t)2 * B * L * nchunk;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % nchunk);
+        const int64_t row = i / nchunk;
+        const int s = (int)(row / L), t = (int)(row - (int64_t)s * L);
+        int tok;
+        if (s < B) tok = ids[(int64_t)s * L + t];
+        else tok = comp8[ids[(int64_t)(s - B) * L + (L - 1 - t)] & 7];
+        float v[8];
+        load8<T>(emb + (int64_t)(tok & 7) * D + c * 8, v);
+        store8<T>(h + row * D + c * 8, v);
+    }
+}
+
+hipError_t launch_embed_only(const int32_t* ids, const void* emb, const int32_t* comp8, void* h, int B, int L, int D,
+                             int dt, hipStream_t s) {
+    if (B * L == 0) return hipSuccess;
+    const int64_t total = (int64_t)2 * B * L * (D >> 3);
+    const unsigned grid = (unsigned)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
+    if (dt == BF16)
+        hipLaunchKernelGGL(embed_only_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, ids, (const bf16_t*)emb, comp8,
+                           (bf16_t*)h, B, L, D);
+    else
+        hipLaunchKernelGGL(embed_only_kernel<float>, dim3(grid), dim3(256), 0, s, ids, (const float*)emb, comp8,
+                           (float*)h, B, L, D);
+    return hipGetLastError();
+}
+
+}  // namespace pcad

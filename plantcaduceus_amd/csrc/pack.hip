@@ -1,0 +1,57 @@
+// Weight packing (run once at bind time): dtype conversion, zero padding, pre-exponentiated A.
+#include "common.hpp"
+#include "kernels.hpp"
+
+namespace pcad {
+
+template <typename SrcT, typename DstT>
+__global__ __launch_bounds__(256) void pack2d_kernel(const SrcT* __restrict__ src, int64_t src_ld,
+                                                     DstT* __restrict__ dst, int64_t dst_ld, int rows, int cols,
+                                                     int dst_rows, int dst_cols) {
+    const int64_t total = (int64_t)dst_rows * dst_cols;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int r = (int)(i / dst_cols), c = (int)(i - (int64_t)r * dst_cols);
+        float v = 0.f;
+        if (r < rows && c < cols) v = Elem<SrcT>::load(src + (int64_t)r * src_ld + c);
+        Elem<DstT>::store(dst + (int64_t)r * dst_ld + c, v);
+    }
+}
+
+hipError_t launch_pack2d(const void* src, int src_dt, int64_t src_ld, void* dst, int dst_dt, int64_t dst_ld, int rows,
+                         int cols, int dst_rows, int dst_cols, hipStream_t s) {
+    const int64_t total = (int64_t)dst_rows * dst_cols;
+    if (total <= 0) return hipSuccess;
+    int64_t nb = (total + 255) / 256;
+    if (nb > 4096) nb = 4096;
+    dim3 grid((unsigned)nb), block(256);
+#define PCAD_PACK(ST, DT)                                                                                      \
+    hipLaunchKernelGGL((pack2d_kernel<ST, DT>), grid, block, 0, s, (const ST*)src, src_ld, (DT*)dst, dst_ld, rows, \
+                       cols, dst_rows, dst_cols)
+    if (src_dt == F32 && dst_dt == F32) PCAD_PACK(float, float);
+    else if (src_dt == F32 && dst_dt == BF16) PCAD_PACK(float, bf16_t);
+    else if (src_dt == BF16 && dst_dt == F32) PCAD_PACK(bf16_t, float);
+    else if (src_dt == BF16 && dst_dt == BF16) PCAD_PACK(bf16_t, bf16_t);
+    else return hipErrorInvalidValue;
+#undef PCAD_PACK
+    return hipGetLastError();
+}
+
+// A = -exp(A_log.float())  (mamba_ssm.Mamba.forward), then pre-scaled by log2(e) so that the scan's
+// exp(delta * A) is a single v_exp_f32 (2^x) — the same folding selective_scan_fwd_kernel.cuh does.
+template <typename SrcT>
+__global__ __launch_bounds__(256) void pack_A_kernel(const SrcT* __restrict__ A_log, float* __restrict__ A2, int64_t n,
+                                                     float scale) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) A2[i] = -expf(Elem<SrcT>::load(A_log + i)) * scale;
+}
+
+hipError_t launch_pack_A(const void* A_log, int src_dt, float* A2, int64_t n, float scale, hipStream_t s) {
+    if (n <= 0) return hipSuccess;
+    dim3 grid((unsigned)((n + 255) / 256)), block(256);
+    if (src_dt == F32) hipLaunchKernelGGL(pack_A_kernel<float>, grid, block, 0, s, (const float*)A_log, A2, n, scale);
+    else hipLaunchKernelGGL(pack_A_kernel<bf16_t>, grid, block, 0, s, (const bf16_t*)A_log, A2, n, scale);
+    return hipGetLastError();
+}
+
+}  // namespace pcad

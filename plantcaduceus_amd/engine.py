@@ -1,0 +1,209 @@
+"""ctypes binding of libpcad.so (include/pcad.h) — PyTorch is plumbing only: device memory + streams.
+
+The product path has NO CPU fallback: if the HIP library is missing, `load_library()` raises, and
+`Engine.forward` refuses tensors that are not on a ROCm device.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from typing import Dict, Optional, Sequence
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpcad.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+PCAD_F32, PCAD_BF16 = 0, 1
+_DT = {torch.float32: PCAD_F32, torch.bfloat16: PCAD_BF16}
+
+
+class PcadConfig(C.Structure):
+    _fields_ = [
+        ("d_model", C.c_int32), ("n_layer", C.c_int32), ("d_state", C.c_int32), ("d_conv", C.c_int32),
+        ("expand", C.c_int32), ("dt_rank", C.c_int32), ("vocab", C.c_int32), ("eps", C.c_float),
+        ("dtype", C.c_int32), ("residual_in_fp32", C.c_int32), ("complement", C.c_int32 * 8),
+    ]
+
+
+class PcadTensor(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("data", C.c_void_p), ("dtype", C.c_int32), ("ndim", C.c_int32),
+                ("shape", C.c_int64 * 4)]
+
+
+# name -> (restype, argtypes): every symbol include/pcad.h declares
+SIGNATURES = {
+    "pcad_version": (C.c_int, []),
+    "pcad_last_error": (C.c_char_p, []),
+    "pcad_create": (C.c_int, [C.POINTER(PcadConfig), C.POINTER(C.c_void_p)]),
+    "pcad_destroy": (None, [C.c_void_p]),
+    "pcad_weight_arena_bytes": (C.c_size_t, [C.c_void_p]),
+    "pcad_bind_weights": (C.c_int, [C.c_void_p, C.POINTER(PcadTensor), C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "pcad_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int, C.c_int]),
+    "pcad_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int32), C.c_int,
+                               C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "pcad_forward_all_hidden": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                          C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "pcad_add_rmsnorm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int,
+                                   C.c_float, C.c_int, C.c_int, C.c_void_p]),
+    "pcad_causal_conv1d_silu": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                          C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "pcad_selective_scan": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
+                                      C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                      C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "pcad_gemm_nt": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64,
+                               C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+}
+
+_lib = None
+
+
+def build_library(force: bool = False) -> str:
+    """Compile the HIP sources in-tree (`hipcc --offload-arch=gfx950`, cross-compiles without a GPU)."""
+    if force:
+        subprocess.run(["make", "-C", CSRC, "clean"], check=True, capture_output=True)
+    r = subprocess.run(["make", "-C", CSRC, "-j", "6"], capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("building libpcad.so failed:\n" + r.stdout[-4000:] + "\n" + r.stderr[-4000:])
+    return LIB_PATH
+
+
+def load_library():
+    """Load libpcad.so; fails loudly if it is missing (no CPU fallback on the product path)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} not found: the MI355X HIP extension is not built. Run "
+            "`python -c 'import __graft_entry__ as g; g.build()'` (or `make -C plantcaduceus_amd/csrc`). "
+            "There is deliberately no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)   # AttributeError if the symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def _check(code: int, what: str):
+    if code != 0:
+        msg = load_library().pcad_last_error()
+        raise RuntimeError(f"{what} failed ({code}): {msg.decode() if msg else ''}")
+
+
+def _stream_ptr() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _require_gpu(t: torch.Tensor, name: str):
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} must live on a ROCm device (got {t.device}); the MI355X engine has no CPU path")
+
+
+class Engine:
+    """One handle = one model on one GPU.  Owns (as torch tensors) the weight arena and workspace."""
+
+    def __init__(self, config, state_dict: Dict[str, torch.Tensor], dtype: torch.dtype, device: torch.device):
+        if dtype not in _DT:
+            raise ValueError(f"unsupported dtype {dtype}: the engine computes in bf16 or fp32")
+        config.check_supported()
+        self.lib = load_library()
+        self.config = config
+        self.dtype = dtype
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("the MI355X engine needs a ROCm device ('cuda:N'); there is no CPU path")
+        cfg = PcadConfig(
+            d_model=config.d_model, n_layer=config.n_layer, d_state=config.d_state, d_conv=config.d_conv,
+            expand=config.expand, dt_rank=config.dt_rank, vocab=config.padded_vocab_size, eps=config.norm_epsilon,
+            dtype=_DT[dtype], residual_in_fp32=int(bool(config.residual_in_fp32)),
+            complement=(C.c_int32 * 8)(*config.complement_list()[:8]))
+        self._h = C.c_void_p()
+        _check(self.lib.pcad_create(C.byref(cfg), C.byref(self._h)), "pcad_create")
+        self._ws: Optional[torch.Tensor] = None
+        with torch.cuda.device(self.device):
+            nbytes = self.lib.pcad_weight_arena_bytes(self._h)
+            self._arena = torch.empty(nbytes + 256, dtype=torch.uint8, device=self.device)
+            self._bind(state_dict)
+
+    def _aligned(self, t: torch.Tensor) -> int:
+        return (t.data_ptr() + 255) // 256 * 256
+
+    def _bind(self, sd: Dict[str, torch.Tensor]):
+        keep = []
+        arr = (PcadTensor * len(sd))()
+        n = 0
+        for name, t in sd.items():
+            if not torch.is_tensor(t) or not t.is_floating_point():
+                continue
+            tt = t.detach()
+            if tt.dtype not in _DT:
+                tt = tt.float()
+            tt = tt.to(self.device).contiguous()
+            keep.append(tt)
+            shape = list(tt.shape)[:4] + [1] * (4 - min(4, tt.dim()))
+            if tt.dim() > 4:
+                raise ValueError(name)
+            arr[n] = PcadTensor(name.encode(), tt.data_ptr(), _DT[tt.dtype], min(4, tt.dim()), (C.c_int64 * 4)(*shape))
+            n += 1
+        base = self._aligned(self._arena)
+        _check(self.lib.pcad_bind_weights(self._h, arr, n, base, self._arena.numel() - (base - self._arena.data_ptr()),
+                                          _stream_ptr()), "pcad_bind_weights")
+        torch.cuda.current_stream().synchronize()   # source tensors in `keep` may be freed after this
+        del keep
+
+    def _workspace(self, B: int, L: int):
+        need = self.lib.pcad_workspace_bytes(self._h, B, L)
+        if self._ws is None or self._ws.numel() < need + 256:
+            self._ws = None
+            self._ws = torch.empty(need + 256, dtype=torch.uint8, device=self.device)
+        base = self._aligned(self._ws)
+        return base, self._ws.numel() - (base - self._ws.data_ptr())
+
+    def forward(self, input_ids: torch.Tensor, positions: Optional[Sequence[int]] = None,
+                want_hidden: bool = False, want_logits: bool = True, all_hidden: bool = False):
+        """ids [B, L] (any int dtype, on this device) -> (logits fp32 [B,Q,8] | None, hidden [B,Q,2D] | None[, all])."""
+        _require_gpu(input_ids, "input_ids")
+        if input_ids.dim() != 2:
+            raise ValueError(f"input_ids must be [B, L], got {tuple(input_ids.shape)}")
+        if input_ids.device != self.device:
+            raise RuntimeError(f"input_ids on {input_ids.device}, engine on {self.device}")
+        ids = input_ids.to(torch.int32).contiguous()
+        B, L = ids.shape
+        D = self.config.d_model
+        P = 0 if positions is None else len(positions)
+        Q = P if P else L
+        with torch.cuda.device(self.device):
+            logits = torch.empty((B, Q, 8), dtype=torch.float32, device=self.device) if want_logits else None
+            hidden = torch.empty((B, Q, 2 * D), dtype=self.dtype, device=self.device) if want_hidden else None
+            if B == 0:
+                return (logits, hidden, None) if all_hidden else (logits, hidden)
+            ws, ws_bytes = self._workspace(B, L)
+            lp = logits.data_ptr() if logits is not None else None
+            hp = hidden.data_ptr() if hidden is not None else None
+            if all_hidden:
+                if positions is not None:
+                    raise ValueError("all_hidden requires positions=None")
+                allh = torch.empty((self.config.n_layer, B, L, 2 * D), dtype=self.dtype, device=self.device)
+                _check(self.lib.pcad_forward_all_hidden(self._h, ids.data_ptr(), B, L, allh.data_ptr(), hp, lp, ws,
+                                                        ws_bytes, _stream_ptr()), "pcad_forward_all_hidden")
+                return logits, hidden, allh
+            pos_arr = (C.c_int32 * P)(*[int(p) for p in positions]) if P else None
+            _check(self.lib.pcad_forward(self._h, ids.data_ptr(), B, L, pos_arr, P, hp, lp, ws, ws_bytes,
+                                         _stream_ptr()), "pcad_forward")
+        return logits, hidden
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            self.lib.pcad_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,125 @@
+"""Operator-level mirrors of the third-party functions the reference's hot path calls, running on the
+MI355X HIP kernels through the C ABI.  Same names, argument meaning and layouts as the originals
+ so the parity tests read like the upstream operators' own tests:
+
+  rms_norm_fn(x, weight, bias, residual, eps, prenorm, residual_in_fp32)   mamba_ssm.ops.triton.layer_norm
+  causal_conv1d_fn(x, weight, bias, activation)                            causal_conv1d 1.4.0
+  selective_scan_fn(u, delta, A, B, C, D, z, delta_bias, delta_softplus)   mamba_ssm 2.2.2
+  linear(x, weight)                                                        F.linear (no bias)
+
+Inputs use the reference's channels-first (B, E, L) layout where the originals do; they are transposed
+to the engine's token-major layout here (test plumbing — the engine itself never transposes).
+All tensors must be ROCm tensors; there is no CPU fallback.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from .engine import _DT, _check, _require_gpu, _stream_ptr, load_library
+
+
+def _dt(t: torch.Tensor) -> int:
+    if t.dtype not in _DT:
+        raise ValueError(f"unsupported dtype {t.dtype}")
+    return _DT[t.dtype]
+
+
+def rms_norm_fn(x, weight, bias=None, residual=None, eps=1e-6, prenorm=False, residual_in_fp32=False):
+    _require_gpu(x, "x")
+    if bias is not None:
+        raise NotImplementedError("RMSNorm bias is not used by Caduceus")
+    lib = load_library()
+    D = x.shape[-1]
+    xf = x.contiguous().view(-1, D)
+    rows = xf.shape[0]
+    rdt = torch.float32 if (residual_in_fp32 or x.dtype == torch.float32) else x.dtype
+    res_in = None
+    if residual is not None:
+        res_in = residual.to(rdt).contiguous().view(-1, D)
+    y = torch.empty_like(xf)
+    res_out = torch.empty((rows, D), dtype=rdt, device=x.device)
+    w = weight.float().contiguous()
+    with torch.cuda.device(x.device):
+        _check(lib.pcad_add_rmsnorm(xf.data_ptr(), res_in.data_ptr() if res_in is not None else None, w.data_ptr(),
+                                    y.data_ptr(), res_out.data_ptr(), rows, D, float(eps), _dt(xf), _DT[rdt],
+                                    _stream_ptr()), "pcad_add_rmsnorm")
+    y = y.view(x.shape)
+    return (y, res_out.view(x.shape)) if prenorm else y
+
+
+def causal_conv1d_bidir(x_tm, w_fwd, b_fwd, w_rev, b_rev):
+    """Token-major both-direction form used by the engine: x_tm [S, L, E] -> (y_fwd, y_rev) [S, L, E]."""
+    _require_gpu(x_tm, "x")
+    lib = load_library()
+    S, L, E = x_tm.shape
+    x_tm = x_tm.contiguous()
+    yf = torch.empty_like(x_tm)
+    yr = torch.empty_like(x_tm)
+    args = [t.float().contiguous() for t in (w_fwd.reshape(E, -1), b_fwd, w_rev.reshape(E, -1), b_rev)]
+    with torch.cuda.device(x_tm.device):
+        _check(lib.pcad_causal_conv1d_silu(x_tm.data_ptr(), E, args[0].data_ptr(), args[1].data_ptr(),
+                                           args[2].data_ptr(), args[3].data_ptr(), yf.data_ptr(), yr.data_ptr(),
+                                           S, L, E, _dt(x_tm), _stream_ptr()), "pcad_causal_conv1d_silu")
+    return yf, yr
+
+
+def causal_conv1d_fn(x, weight, bias=None, activation=None):
+    """x (B, E, L), weight (E, W=4), bias (E), activation must be "silu"."""
+    if activation not in ("silu", "swish"):
+        raise NotImplementedError("only activation='silu' is on the Caduceus path")
+    if weight.shape[-1] != 4:
+        raise NotImplementedError("only conv width 4")
+    if bias is None:
+        bias = torch.zeros(weight.shape[0], device=x.device)
+    yf, _ = causal_conv1d_bidir(x.transpose(1, 2), weight, bias, weight, bias)
+    return yf.transpose(1, 2)
+
+
+def selective_scan_fn(u, delta, A, B, C, D=None, z=None, delta_bias=None, delta_softplus=False,
+                      return_last_state=False, reverse=False, accumulate_into=None):
+    """u, delta, z: (B, E, L); A: (E, 16); B, C: (B, 16, L); D, delta_bias: (E).  Returns (B, E, L)."""
+    _require_gpu(u, "u")
+    if not delta_softplus:
+        raise NotImplementedError("the Caduceus path always uses delta_softplus=True")
+    if return_last_state:
+        raise NotImplementedError("return_last_state is not on the Caduceus path")
+    lib = load_library()
+    Bsz, E, L = u.shape
+    dt = u.dtype
+    u_tm = u.transpose(1, 2).contiguous()
+    d_tm = delta.to(dt).transpose(1, 2).contiguous()
+    z_tm = z.to(dt).transpose(1, 2).contiguous() if z is not None else None
+    bc = torch.cat([B.to(dt).transpose(1, 2), C.to(dt).transpose(1, 2)], dim=-1).contiguous()   # [B, L, 32]
+    A32 = A.float().contiguous()
+    Dv = (D.float() if D is not None else torch.zeros(E, device=u.device)).contiguous()
+    db = (delta_bias.float() if delta_bias is not None else torch.zeros(E, device=u.device)).contiguous()
+    if accumulate_into is not None:
+        y = accumulate_into.transpose(1, 2).contiguous()
+    else:
+        y = torch.empty_like(u_tm)
+    esz = u_tm.element_size()
+    with torch.cuda.device(u.device):
+        _check(lib.pcad_selective_scan(u_tm.data_ptr(), d_tm.data_ptr(), z_tm.data_ptr() if z_tm is not None else None,
+                                       E, bc.data_ptr(), bc.data_ptr() + 16 * esz, 32, A32.data_ptr(), Dv.data_ptr(),
+                                       db.data_ptr(), y.data_ptr(), Bsz, L, E, int(bool(reverse)),
+                                       int(accumulate_into is not None), _dt(u_tm), _stream_ptr()),
+               "pcad_selective_scan")
+    return y.transpose(1, 2)
+
+
+def linear(x, weight, out_dtype: Optional[torch.dtype] = None):
+    """F.linear(x, weight) on MFMA: x [..., K], weight [N, K] (same dtype), K*elem a multiple of 128 bytes."""
+    _require_gpu(x, "x")
+    lib = load_library()
+    K = x.shape[-1]
+    N = weight.shape[0]
+    xf = x.contiguous().view(-1, K)
+    wf = weight.to(x.dtype).contiguous()
+    od = out_dtype or x.dtype
+    out = torch.empty((xf.shape[0], N), dtype=od, device=x.device)
+    with torch.cuda.device(x.device):
+        _check(lib.pcad_gemm_nt(xf.data_ptr(), K, wf.data_ptr(), K, out.data_ptr(), N, xf.shape[0], N, K, _dt(xf),
+                                _DT[od], _stream_ptr()), "pcad_gemm_nt")
+    return out.view(*x.shape[:-1], N)

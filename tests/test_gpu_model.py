@@ -1,0 +1,123 @@
+"""-m gpu: model-level parity of the HIP forward (through the C ABI + HF surface) vs the CPU oracle."""
+import pytest
+import torch
+
+from oracle import caduceus_oracle as O
+from plantcaduceus_amd.checkpoint import make_config, synthetic_state_dict
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def build(cfg, sd, dtype):
+    from plantcaduceus_amd.modeling_caduceus import CaduceusForMaskedLM
+    m = CaduceusForMaskedLM(cfg)
+    m.load_state_dict(sd, strict=False)
+    m.tie_weights()
+    return m.to(dtype).to(DEV)
+
+
+def rand_ids(B, L, seed, mask=None):
+    g = torch.Generator().manual_seed(seed)
+    ids = torch.randint(3, 7, (B, L), generator=g)
+    ids[0, 0] = 2   # an N -> [UNK]
+    if mask is not None:
+        ids[:, mask] = 1
+    return ids
+
+
+@pytest.mark.parametrize("D,nl,B,L", [(64, 3, 2, 24), (128, 2, 5, 64), (384, 2, 3, 512), (1024, 1, 2, 512)])
+def test_forward_fp32_matches_oracle(D, nl, B, L):
+    """north_star tolerance: <=1e-4 relative on fp32 logits, exact argmax of the nucleotide call."""
+    cfg = make_config("x", d_model=D, n_layer=nl)
+    sd = synthetic_state_dict(cfg, seed=D + nl)
+    ids = rand_ids(B, L, 5, mask=L // 2 - 1)
+    ref = O.forward_strands(ids, O.params_from_state_dict(sd, cfg))
+    m = build(cfg, sd, torch.float32)
+    out = m(input_ids=ids.to(DEV), output_hidden_states=True)
+    lg = out.logits.cpu()
+    assert lg.dtype == torch.float32 and lg.shape == (B, L, 8)
+    scale = ref["logits"].abs().max()
+    assert ((lg - ref["logits"]).abs().max() / scale).item() < 1e-4
+    hid = out.hidden_states[-1].cpu()
+    assert hid.shape == (B, L, 2 * D)
+    assert ((hid - ref["hidden"]).abs().max() / ref["hidden"].abs().max()).item() < 1e-4
+    p = L // 2 - 1
+    assert torch.equal(lg[:, p, 3:7].argmax(-1), ref["logits"][:, p, 3:7].argmax(-1))
+    # positions fast path == slicing the full output
+    out_p = m(input_ids=ids.to(DEV), output_hidden_states=True, positions=[p, 0, L - 1])
+    assert torch.equal(out_p.logits.cpu(), lg[:, [p, 0, L - 1]])
+    assert torch.equal(out_p.hidden_states[-1].cpu(), hid[:, [p, 0, L - 1]])
+
+
+def test_forward_bf16_vs_bf16_emulating_oracle():
+    """bf16 path: compared with the oracle rounding to bf16 at the reference's tensor boundaries.
+    Tolerance 3e-2 of the logit range (bf16 eps = 7.8e-3 through 4 layers), argmax exact where the
+    top-2 margin exceeds that noise."""
+    cfg = make_config("x", d_model=256, n_layer=4)
+    sd = synthetic_state_dict(cfg, seed=3)
+    ids = rand_ids(4, 128, 9, mask=63)
+    P = O.params_from_state_dict(sd, cfg, dtype=torch.bfloat16)
+    ref = O.forward_strands(ids, P, rnd=O.round_bf16)
+    ref32 = O.forward_strands(ids, O.params_from_state_dict(sd, cfg))
+    m = build(cfg, sd, torch.bfloat16)
+    out = m(input_ids=ids.to(DEV), output_hidden_states=True)
+    lg = out.logits.cpu()
+    assert out.hidden_states[-1].dtype == torch.bfloat16 and lg.dtype == torch.float32
+    scale = ref["logits"].abs().max()
+    err_emul = ((lg - ref["logits"]).abs().max() / scale).item()
+    err_fp32 = ((lg - ref32["logits"]).abs().max() / scale).item()
+    print(f"bf16 path: err vs bf16-emulating oracle {err_emul:.3e}, vs fp32 oracle {err_fp32:.3e}")
+    assert err_emul < 3e-2
+    top2 = ref["logits"][:, 63, 3:7].topk(2, dim=-1).values
+    confident = (top2[:, 0] - top2[:, 1]) > 3e-2 * scale
+    assert torch.equal(lg[:, 63, 3:7].argmax(-1)[confident], ref["logits"][:, 63, 3:7].argmax(-1)[confident])
+
+
+def test_rc_equivariance_property_full_size():
+    """size-independent property at the real l20 width/length: logits(rc x)[L-1-l, comp v] == logits(x)[l, v]
+    and hidden(rc x) == flip_{seq,chan}(hidden(x)).  Exact in exact arithmetic; fp32 tolerance 1e-4."""
+    cfg = make_config("l20", n_layer=2)
+    sd = synthetic_state_dict(cfg, seed=1)
+    ids = rand_ids(4, 512, 13)
+    comp = torch.tensor(cfg.complement_list())
+    rc = comp[ids.flip(-1)]
+    m = build(cfg, sd, torch.float32)
+    a = m(input_ids=ids.to(DEV), output_hidden_states=True)
+    b = m(input_ids=rc.to(DEV), output_hidden_states=True)
+    la, lb = a.logits.cpu(), b.logits.cpu()
+    assert ((lb.flip(1)[:, :, comp] - la).abs().max() / la.abs().max()).item() < 1e-4
+    ha, hb = a.hidden_states[-1].cpu(), b.hidden_states[-1].cpu()
+    assert ((hb.flip(1, 2) - ha).abs().max() / ha.abs().max()).item() < 1e-4
+
+
+def test_batch_chunking_and_empty_and_all_hidden(monkeypatch):
+    cfg = make_config("x", d_model=64, n_layer=2)
+    sd = synthetic_state_dict(cfg, seed=2)
+    ids = rand_ids(7, 32, 21)
+    monkeypatch.setenv("PCAD_CHUNK_SEQS", "3")   # 7 sequences -> chunks 3,3,1
+    m = build(cfg, sd, torch.float32)
+    lg = m(input_ids=ids.to(DEV)).logits.cpu()
+    monkeypatch.setenv("PCAD_CHUNK_SEQS", "64")
+    m2 = build(cfg, sd, torch.float32)
+    assert torch.equal(lg, m2(input_ids=ids.to(DEV)).logits.cpu())
+    # ragged / empty
+    assert m2(input_ids=ids[:0].to(DEV)).logits.shape == (0, 32, 8)
+    # full hidden-state tuple vs literal-RCPS oracle
+    cfg.materialize_all_hidden_states = True
+    m3 = build(cfg, sd, torch.float32)
+    out = m3(input_ids=ids.to(DEV), output_hidden_states=True)
+    ref = O.forward_literal(ids, O.params_from_state_dict(sd, cfg), output_hidden_states=True)
+    assert len(out.hidden_states) == cfg.n_layer + 1
+    for got, want in zip(out.hidden_states, ref["all_hidden"]):
+        assert ((got.cpu() - want).abs().max() / want.abs().max()).item() < 1e-4
+
+
+def test_no_cpu_fallback():
+    cfg = make_config("x", d_model=64, n_layer=1)
+    sd = synthetic_state_dict(cfg, seed=2)
+    from plantcaduceus_amd.modeling_caduceus import CaduceusForMaskedLM
+    m = CaduceusForMaskedLM(cfg)
+    m.load_state_dict(sd, strict=False)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m(input_ids=rand_ids(1, 16, 0))
