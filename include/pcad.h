@@ -112,6 +112,22 @@ int    pcad_forward_all_hidden(pcad_handle h, const int32_t* ids, int B, int L,
                                void* all_hidden, void* hidden_out, float* logits_out,
                                void* workspace, size_t workspace_bytes, pcad_stream stream);
 
+/* ---- measurement: per-kernel-class timing with HIP events on the caller's stream -------------------- */
+enum pcad_kernel_class {
+    PCAD_K_NORM = 0, PCAD_K_GEMM_IN, PCAD_K_CONV, PCAD_K_GEMM_X, PCAD_K_GEMM_DT, PCAD_K_SCAN,
+    PCAD_K_GEMM_OUT, PCAD_K_HEAD, PCAD_NUM_KERNEL_CLASSES
+};
+typedef struct pcad_kernel_stat {
+    char    name[32];
+    int64_t launches;
+    double  total_ms;           /* sum of (stop - start) event times of this class's launches */
+} pcad_kernel_stat;
+/* When on, every launch of pcad_forward is bracketed by a pair of hipEvents recorded on `stream`. */
+int pcad_profile_enable(pcad_handle h, int on);
+/* Waits for the recorded events, writes one entry per kernel class (<= max_out), resets the counters.
+ * Returns the number of entries written (>= 0) or a negative status. */
+int pcad_profile_read(pcad_handle h, pcad_kernel_stat* out, int max_out);
+
 /* ---- per-operator entry points (unit parity against the operators they replace) ------------------ */
 
 /* rms_norm_fn(x, weight, None, residual=residual, eps, prenorm=True, residual_in_fp32)

@@ -1,0 +1,101 @@
+"""ctypes wrapper of oracle/c/liboracle.so — TEST INFRASTRUCTURE ONLY (see oracle/c/pcad_oracle.c).
+
+Used by tests/ (cross-check against the torch oracle and against the HIP path at sizes the torch
+oracle is too slow for), by __graft_entry__.smoke() and by bench.py's `cpu_baseline` leg.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB = os.path.join(_HERE, "c", "liboracle.so")
+FP = C.POINTER(C.c_float)
+
+
+class OracleLayer(C.Structure):
+    _fields_ = [("norm_w", FP), ("in_proj", FP), ("out_proj", FP), ("conv_w", FP * 2), ("conv_b", FP * 2),
+                ("x_proj", FP * 2), ("dt_w", FP * 2), ("dt_b", FP * 2), ("A_log", FP * 2), ("Dskip", FP * 2)]
+
+
+class OracleModel(C.Structure):
+    _fields_ = [("d_model", C.c_int32), ("n_layer", C.c_int32), ("d_inner", C.c_int32), ("dt_rank", C.c_int32),
+                ("eps", C.c_float), ("complement", C.c_int32 * 8), ("emb", FP), ("norm_f", FP),
+                ("layers", C.POINTER(OracleLayer))]
+
+
+def build():
+    r = subprocess.run(["make", "-C", os.path.join(_HERE, "c")], capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(r.stdout + r.stderr)
+
+
+def _lib():
+    if not os.path.exists(LIB):
+        build()
+    lib = C.CDLL(LIB)
+    lib.oracle_forward.restype = C.c_int
+    lib.oracle_forward.argtypes = [C.POINTER(OracleModel), C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    lib.oracle_num_threads.restype = C.c_int
+    return lib
+
+
+class COracle:
+    """fp32 C/OpenMP forward from a reference-named state dict (values rounded through `dtype` first,
+    emulating from_pretrained(torch_dtype=...); arithmetic is always fp32)."""
+
+    def __init__(self, state_dict, config, dtype=None):
+        import torch
+        self.lib = _lib()
+        self.config = config
+        self._keep = []
+
+        def arr(name):
+            t = state_dict[name]
+            if dtype is not None:
+                t = t.to(dtype)
+            a = np.ascontiguousarray(t.float().cpu().numpy(), dtype=np.float32)
+            self._keep.append(a)
+            return a.ctypes.data_as(FP)
+
+        pre = "caduceus.backbone."
+        self.layers = (OracleLayer * config.n_layer)()
+        for i in range(config.n_layer):
+            lp = f"{pre}layers.{i}."
+            ly = self.layers[i]
+            ly.norm_w = arr(lp + "norm.weight")
+            ly.in_proj = arr(lp + "mixer.submodule.mamba_fwd.in_proj.weight")
+            ly.out_proj = arr(lp + "mixer.submodule.mamba_fwd.out_proj.weight")
+            for d, nm in enumerate(("fwd", "rev")):
+                mp = f"{lp}mixer.submodule.mamba_{nm}."
+                ly.conv_w[d] = arr(mp + "conv1d.weight")
+                ly.conv_b[d] = arr(mp + "conv1d.bias")
+                ly.x_proj[d] = arr(mp + "x_proj.weight")
+                ly.dt_w[d] = arr(mp + "dt_proj.weight")
+                ly.dt_b[d] = arr(mp + "dt_proj.bias")
+                ly.A_log[d] = arr(mp + "A_log")
+                ly.Dskip[d] = arr(mp + "D")
+        self.model = OracleModel(
+            d_model=config.d_model, n_layer=config.n_layer, d_inner=config.d_inner, dt_rank=config.dt_rank,
+            eps=config.norm_epsilon, complement=(C.c_int32 * 8)(*config.complement_list()[:8]),
+            emb=arr(pre + "embeddings.word_embeddings.embedding.weight"), norm_f=arr(pre + "norm_f.weight"),
+            layers=self.layers)
+
+    @property
+    def threads(self) -> int:
+        return int(self.lib.oracle_num_threads())
+
+    def forward(self, ids, want_logits=True, want_hidden=False):
+        ids = np.ascontiguousarray(np.asarray(ids), dtype=np.int32)
+        B, L = ids.shape
+        logits = np.empty((B, L, 8), dtype=np.float32) if want_logits else None
+        hidden = np.empty((B, L, 2 * self.config.d_model), dtype=np.float32) if want_hidden else None
+        rc = self.lib.oracle_forward(C.byref(self.model), ids.ctypes.data, B, L,
+                                     logits.ctypes.data if want_logits else None,
+                                     hidden.ctypes.data if want_hidden else None)
+        if rc != 0:
+            raise MemoryError("oracle_forward failed")
+        return logits, hidden

@@ -68,6 +68,12 @@ struct pcad_engine {
     float* emb_f32 = nullptr;   // [V, D] fp32 copy of the dtype-rounded table
     float* normf_w = nullptr;
     int32_t* comp = nullptr;    // [8] device
+    // optional per-kernel-class timing with HIP events recorded on the caller's stream
+    bool prof = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_ev[PCAD_NUM_KERNEL_CLASSES];
+    std::vector<hipEvent_t> prof_pool;
+    double prof_ms[PCAD_NUM_KERNEL_CLASSES] = {0};
+    int64_t prof_n[PCAD_NUM_KERNEL_CLASSES] = {0};
 };
 
 namespace {
@@ -132,6 +138,31 @@ Workspace carve_workspace(const pcad_engine* e, void* base, int Bc, int L) {
     return w;
 }
 
+const char* const kClassNames[PCAD_NUM_KERNEL_CLASSES] = {
+    "add_rmsnorm", "gemm_in_proj", "conv1d_bidir", "gemm_x_proj", "gemm_dt_proj", "selective_scan",
+    "gemm_out_proj", "final_head"};
+
+hipEvent_t prof_event(pcad_engine* e) {
+    if (!e->prof_pool.empty()) {
+        hipEvent_t ev = e->prof_pool.back();
+        e->prof_pool.pop_back();
+        return ev;
+    }
+    hipEvent_t ev = nullptr;
+    if (hipEventCreate(&ev) != hipSuccess) return nullptr;
+    return ev;
+}
+
+struct ProfScope {   // records start/stop events around one launch when profiling is on
+    pcad_engine* e; int cls; hipStream_t s; hipEvent_t a = nullptr, b = nullptr;
+    ProfScope(pcad_engine* e_, int cls_, hipStream_t s_) : e(e_), cls(cls_), s(s_) {
+        if (e->prof) { a = prof_event(e); b = prof_event(e); if (a) (void)hipEventRecord(a, s); }
+    }
+    ~ProfScope() {
+        if (a && b) { (void)hipEventRecord(b, s); e->prof_ev[cls].push_back({a, b}); }
+    }
+};
+
 const pcad_tensor* find(const std::map<std::string, const pcad_tensor*>& m, const std::string& k) {
     auto it = m.find(k);
     return it == m.end() ? nullptr : it->second;
@@ -177,7 +208,13 @@ int pcad_create(const pcad_config* cfg, pcad_handle* out) {
     return PCAD_OK;
 }
 
-void pcad_destroy(pcad_handle h) { delete h; }
+void pcad_destroy(pcad_handle h) {
+    if (!h) return;
+    for (int c = 0; c < PCAD_NUM_KERNEL_CLASSES; ++c)
+        for (auto& pr : h->prof_ev[c]) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
+    for (auto ev : h->prof_pool) (void)hipEventDestroy(ev);
+    delete h;
+}
 
 size_t pcad_weight_arena_bytes(pcad_handle h) {
     if (!h) return 0;
@@ -317,28 +354,36 @@ static int forward_impl(pcad_handle h, const int32_t* ids, int B, int L, const i
         for (int li = 0; li < e->nl; ++li) {
             const LayerWeights& W = e->layers[li];
             if (li == 0) {
+                ProfScope ps(e, PCAD_K_NORM, s);
                 HIP_TRY(launch_embed_rmsnorm(ids_c, e->emb, e->comp, W.norm_w, w.u, w.res, Bc, L, D, eps, dt, rdt, s));
             } else {
+                ProfScope ps(e, PCAD_K_NORM, s);
                 HIP_TRY(launch_add_rmsnorm(w.h, w.res, W.norm_w, w.u, w.res, rows, D, eps, dt, rdt, s));
             }
             // in_proj (tied between directions: once per strand)
-            HIP_TRY(launch_gemm_nt(w.u, D, W.W_in, D, w.xz, 2 * E, rows, 2 * E, D, dt, dt, false, s));
+            { ProfScope ps(e, PCAD_K_GEMM_IN, s);
+            HIP_TRY(launch_gemm_nt(w.u, D, W.W_in, D, w.xz, 2 * E, rows, 2 * E, D, dt, dt, false, s)); }
             // conv1d + SiLU, causal and anti-causal from one read of x
+            { ProfScope ps(e, PCAD_K_CONV, s);
             HIP_TRY(launch_conv_bidir(w.xz, 2 * E, W.dir[0].conv_w, W.dir[0].conv_b, W.dir[1].conv_w, W.dir[1].conv_b,
-                                      w.xc[0], w.xc[1], S, L, E, dt, s));
+                                      w.xc[0], w.xc[1], S, L, E, dt, s)); }
             for (int d = 0; d < 2; ++d) {
                 const DirWeights& dw = W.dir[d];
                 // x_proj -> [dt_low (Rp, zero padded) | B | C]
-                HIP_TRY(launch_gemm_nt(w.xc[d], E, dw.Wx, E, w.dbl[d], XP, rows, XP, E, dt, dt, false, s));
+                { ProfScope ps(e, PCAD_K_GEMM_X, s);
+                HIP_TRY(launch_gemm_nt(w.xc[d], E, dw.Wx, E, w.dbl[d], XP, rows, XP, E, dt, dt, false, s)); }
                 // dt_proj (bias + softplus are applied inside the scan)
-                HIP_TRY(launch_gemm_nt(w.dbl[d], XP, dw.Wdt, Rp, w.delta, E, rows, E, Rp, dt, dt, false, s));
+                { ProfScope ps(e, PCAD_K_GEMM_DT, s);
+                HIP_TRY(launch_gemm_nt(w.dbl[d], XP, dw.Wdt, Rp, w.delta, E, rows, E, Rp, dt, dt, false, s)); }
                 const char* bc = (const char*)w.dbl[d];
+                ProfScope ps(e, PCAD_K_SCAN, s);
                 HIP_TRY(launch_scan(w.xc[d], w.delta, (const char*)w.xz + (size_t)E * esz, 2 * E, bc + (size_t)Rp * esz,
                                     bc + (size_t)(Rp + N) * esz, XP, dw.A2, 1.0f, dw.Dskip, dw.dt_bias, w.y, S, L, E, d == 1,
                                     d == 1, dt, s));
             }
             // out_proj on (y_fwd + y_rev): the two tied out_proj calls folded by linearity
-            HIP_TRY(launch_gemm_nt(w.y, E, W.W_out, E, w.h, D, rows, D, E, dt, dt, false, s));
+            { ProfScope ps(e, PCAD_K_GEMM_OUT, s);
+            HIP_TRY(launch_gemm_nt(w.y, E, W.W_out, E, w.h, D, rows, D, E, dt, dt, false, s)); }
             if (all_hidden && li + 1 < e->nl) {
                 char* dst = (char*)all_hidden + ((size_t)(li + 1) * B * L * 2 * D + (size_t)b0 * L * 2 * D) * esz;
                 HIP_TRY(launch_assemble_hidden(w.h, dst, Bc, L, D, dt, s));
@@ -346,9 +391,11 @@ static int forward_impl(pcad_handle h, const int32_t* ids, int B, int L, const i
         }
         void* hout = hidden_out ? (char*)hidden_out + ((size_t)b0 * Q * 2 * D) * esz : nullptr;
         float* lout = logits_out ? logits_out + (size_t)b0 * Q * e->V : nullptr;
-        if (hout || lout)
+        if (hout || lout) {
+            ProfScope ps(e, PCAD_K_HEAD, s);
             HIP_TRY(launch_final_head(w.h, w.res, e->normf_w, e->emb, e->emb_f32, e->comp, hout, lout, Bc, L, D, eps, pos,
                                       dt, rdt, s));
+        }
     }
     return PCAD_OK;
 }
@@ -363,6 +410,37 @@ int pcad_forward_all_hidden(pcad_handle h, const int32_t* ids, int B, int L, voi
     if (!all_hidden) return fail(PCAD_ERR_INVALID, "pcad_forward_all_hidden: null all_hidden");
     return forward_impl(h, ids, B, L, nullptr, 0, all_hidden, hidden_out, logits_out, workspace, workspace_bytes,
                         stream);
+}
+
+int pcad_profile_enable(pcad_handle h, int on) {
+    if (!h) return fail(PCAD_ERR_INVALID, "pcad_profile_enable: null handle");
+    h->prof = on != 0;
+    return PCAD_OK;
+}
+
+int pcad_profile_read(pcad_handle h, pcad_kernel_stat* out, int max_out) {
+    if (!h || !out) return fail(PCAD_ERR_INVALID, "pcad_profile_read: null argument");
+    for (int c = 0; c < PCAD_NUM_KERNEL_CLASSES; ++c) {
+        for (auto& pr : h->prof_ev[c]) {
+            HIP_TRY(hipEventSynchronize(pr.second));
+            float ms = 0.f;
+            HIP_TRY(hipEventElapsedTime(&ms, pr.first, pr.second));
+            h->prof_ms[c] += ms;
+            h->prof_n[c] += 1;
+            h->prof_pool.push_back(pr.first);
+            h->prof_pool.push_back(pr.second);
+        }
+        h->prof_ev[c].clear();
+    }
+    int n = 0;
+    for (int c = 0; c < PCAD_NUM_KERNEL_CLASSES && n < max_out; ++c, ++n) {
+        snprintf(out[n].name, sizeof(out[n].name), "%s", kClassNames[c]);
+        out[n].launches = h->prof_n[c];
+        out[n].total_ms = h->prof_ms[c];
+        h->prof_n[c] = 0;
+        h->prof_ms[c] = 0.0;
+    }
+    return n;
 }
 
 // ---- per-operator entry points -------------------------------------------------------------------

@@ -28,6 +28,10 @@ class PcadConfig(C.Structure):
     ]
 
 
+class PcadKernelStat(C.Structure):
+    _fields_ = [("name", C.c_char * 32), ("launches", C.c_int64), ("total_ms", C.c_double)]
+
+
 class PcadTensor(C.Structure):
     _fields_ = [("name", C.c_char_p), ("data", C.c_void_p), ("dtype", C.c_int32), ("ndim", C.c_int32),
                 ("shape", C.c_int64 * 4)]
@@ -46,6 +50,8 @@ SIGNATURES = {
                                C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "pcad_forward_all_hidden": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                           C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "pcad_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
+    "pcad_profile_read": (C.c_int, [C.c_void_p, C.POINTER(PcadKernelStat), C.c_int]),
     "pcad_add_rmsnorm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int,
                                    C.c_float, C.c_int, C.c_int, C.c_void_p]),
     "pcad_causal_conv1d_silu": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
@@ -196,6 +202,17 @@ class Engine:
             _check(self.lib.pcad_forward(self._h, ids.data_ptr(), B, L, pos_arr, P, hp, lp, ws, ws_bytes,
                                          _stream_ptr()), "pcad_forward")
         return logits, hidden
+
+    def profile(self, on: bool):
+        _check(self.lib.pcad_profile_enable(self._h, int(on)), "pcad_profile_enable")
+
+    def profile_read(self):
+        """-> {kernel class: (launches, total_ms)} since the last read (waits for the events)."""
+        arr = (PcadKernelStat * 16)()
+        n = self.lib.pcad_profile_read(self._h, arr, 16)
+        if n < 0:
+            _check(n, "pcad_profile_read")
+        return {arr[i].name.decode(): (int(arr[i].launches), float(arr[i].total_ms)) for i in range(n)}
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h:
