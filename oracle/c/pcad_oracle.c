@@ -12,8 +12,10 @@
  * src/train_XGBoost.py:104.  "Parity unpinned" by the reference's own tests (it has none); pinned by
  * the fixtures described in oracle/caduceus_oracle.py.
  *
- * Parallelisation: one strand per OpenMP thread (strands are independent); inside a strand plain
- * blocked loops the compiler vectorises.  No BLAS, no intrinsics: this is a scalar-source port.
+ * Parallelisation: the 2B-strand batch walks the stack layer by layer and every operator is an OpenMP
+ * parallel loop (GEMM: weight-panel x row-block tiles; conv/norm: token rows; scan: strand x 16-channel
+ * blocks), so even a small sample uses all host cores.  Plain blocked loops the compiler vectorises; no
+ * BLAS, no intrinsics: this is a scalar-source port.
  */
 #include <math.h>
 #include <stdint.h>
@@ -110,51 +112,64 @@ static inline float softplus_f(float v) {
     return v > 20.0f ? v : l;
 }
 
-/* C[M,N] = A[M,K] . W[N,K]^T  (F.linear without bias).  4x4 register block of VL-wide partial sums. */
-static void linear_nt(const float* A, int lda, const float* W, int K, float* C, int ldc, int M, int N) {
+/* C[M,N] = A[M,K] . W[N,K]^T  (F.linear without bias).  Cache-blocked: a panel of NB weight rows stays in
+ * L2 while all row blocks of A stream past it; inside, a 4x4 register block of VL-wide partial sums. */
+static void linear_micro(const float* A, int lda, const float* W, int K, float* C, int ldc, int mi, int nj) {
     const int Kv = K - K % VL;
-    for (int i0 = 0; i0 < M; i0 += 4) {
-        const int mi = M - i0 < 4 ? M - i0 : 4;
-        for (int j0 = 0; j0 < N; j0 += 4) {
-            const int nj = N - j0 < 4 ? N - j0 : 4;
-            if (mi == 4 && nj == 4) {
-                float acc[4][4][VL] = {{{0.f}}};
-                const float* a0 = A + (size_t)i0 * lda;
-                const float* w0 = W + (size_t)j0 * K;
-                for (int k = 0; k < Kv; k += VL)
-                    for (int i = 0; i < 4; ++i)
-                        for (int j = 0; j < 4; ++j)
+    if (mi == 4 && nj == 4) {
+        float acc[4][4][VL] = {{{0.f}}};
+        for (int k = 0; k < Kv; k += VL)
+            for (int i = 0; i < 4; ++i)
+                for (int j = 0; j < 4; ++j)
 #pragma omp simd
-                            for (int l = 0; l < VL; ++l)
-                                acc[i][j][l] += a0[(size_t)i * lda + k + l] * w0[(size_t)j * K + k + l];
-                for (int i = 0; i < 4; ++i)
-                    for (int j = 0; j < 4; ++j) {
-                        float s = 0.f;
-                        for (int l = 0; l < VL; ++l) s += acc[i][j][l];
-                        for (int kk = Kv; kk < K; ++kk) s += a0[(size_t)i * lda + kk] * w0[(size_t)j * K + kk];
-                        C[(size_t)(i0 + i) * ldc + j0 + j] = s;
-                    }
-            } else {
-                for (int i = 0; i < mi; ++i)
-                    for (int j = 0; j < nj; ++j) {
-                        const float* a = A + (size_t)(i0 + i) * lda;
-                        const float* w = W + (size_t)(j0 + j) * K;
-                        float part[VL] = {0.f};
-                        for (int k = 0; k < Kv; k += VL)
-                            for (int l = 0; l < VL; ++l) part[l] += a[k + l] * w[k + l];
-                        float s = 0.f;
-                        for (int l = 0; l < VL; ++l) s += part[l];
-                        for (int kk = Kv; kk < K; ++kk) s += a[kk] * w[kk];
-                        C[(size_t)(i0 + i) * ldc + j0 + j] = s;
-                    }
+                    for (int l = 0; l < VL; ++l)
+                        acc[i][j][l] += A[(size_t)i * lda + k + l] * W[(size_t)j * K + k + l];
+        for (int i = 0; i < 4; ++i)
+            for (int j = 0; j < 4; ++j) {
+                float s = 0.f;
+                for (int l = 0; l < VL; ++l) s += acc[i][j][l];
+                for (int kk = Kv; kk < K; ++kk) s += A[(size_t)i * lda + kk] * W[(size_t)j * K + kk];
+                C[(size_t)i * ldc + j] = s;
             }
+        return;
+    }
+    for (int i = 0; i < mi; ++i)
+        for (int j = 0; j < nj; ++j) {
+            const float* a = A + (size_t)i * lda;
+            const float* w = W + (size_t)j * K;
+            float part[VL] = {0.f};
+            for (int k = 0; k < Kv; k += VL)
+                for (int l = 0; l < VL; ++l) part[l] += a[k + l] * w[k + l];
+            float s = 0.f;
+            for (int l = 0; l < VL; ++l) s += part[l];
+            for (int kk = Kv; kk < K; ++kk) s += a[kk] * w[kk];
+            C[(size_t)i * ldc + j] = s;
+        }
+}
+
+static void linear_nt(const float* A, int lda, const float* W, int K, float* C, int ldc, int M, int N) {
+    enum { MB = 32, NB = 32 };
+    const int nib = (M + MB - 1) / MB, njb = (N + NB - 1) / NB;
+    /* static schedule over (weight panel, row block): a thread's consecutive items share the weight panel */
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int jbi = 0; jbi < njb; ++jbi) {
+        for (int ibi = 0; ibi < nib; ++ibi) {
+            const int jb = jbi * NB, ib = ibi * MB;
+            const int je = jb + NB < N ? jb + NB : N;
+            const int ie = ib + MB < M ? ib + MB : M;
+            for (int i0 = ib; i0 < ie; i0 += 4)
+                for (int j0 = jb; j0 < je; j0 += 4)
+                    linear_micro(A + (size_t)i0 * lda, lda, W + (size_t)j0 * K, K, C + (size_t)i0 * ldc + j0, ldc,
+                                 ie - i0 < 4 ? ie - i0 : 4, je - j0 < 4 ? je - j0 : 4);
         }
     }
 }
 
-/* rms_norm_fn(prenorm=True): res = x (+ res); y = res * rsqrt(mean(res^2)+eps) * w */
-static void add_rmsnorm(const float* x, float* res, int has_res, const float* w, float* y, int L, int D, float eps) {
-    for (int t = 0; t < L; ++t) {
+/* rms_norm_fn(prenorm=True) over `rows` token rows: res = x (+ res); y = res * rsqrt(mean(res^2)+eps) * w */
+static void add_rmsnorm(const float* x, float* res, int has_res, const float* w, float* y, int64_t rows, int D,
+                        float eps) {
+#pragma omp parallel for schedule(static)
+    for (int64_t t = 0; t < rows; ++t) {
         float ss = 0.f;
         float* r = res + (size_t)t * D;
         const float* xr = x + (size_t)t * D;
@@ -168,82 +183,63 @@ static void add_rmsnorm(const float* x, float* res, int has_res, const float* w,
     }
 }
 
-/* one strand through the whole stack; H out: final normalised hidden [L, D] */
-static void strand_forward(const oracle_model* m, const int32_t* tok /*[L]*/, int L, float* H, float* scratch) {
-    const int D = m->d_model, E = m->d_inner, R = m->dt_rank, XP = R + 2 * NST;
-    float* res = scratch;                         /* [L, D] */
-    float* u = res + (size_t)L * D;               /* [L, D] */
-    float* h = u + (size_t)L * D;                 /* [L, D] */
-    float* xz = h + (size_t)L * D;                /* [L, 2E] */
-    float* xc = xz + (size_t)L * 2 * E;           /* [L, E] */
-    float* dbl = xc + (size_t)L * E;              /* [L, XP] */
-    float* delta = dbl + (size_t)L * XP;          /* [L, E] */
-    float* y = delta + (size_t)L * E;             /* [L, E] */
-    float* A = y + (size_t)L * E;                 /* [E, N] */
-
-    for (int t = 0; t < L; ++t) memcpy(h + (size_t)t * D, m->emb + (size_t)(tok[t] & 7) * D, sizeof(float) * D);
-    for (int li = 0; li < m->n_layer; ++li) {
-        const oracle_layer* ly = &m->layers[li];
-        add_rmsnorm(h, res, li > 0, ly->norm_w, u, L, D, m->eps);
-        linear_nt(u, D, ly->in_proj, D, xz, 2 * E, L, 2 * E);
-        memset(y, 0, sizeof(float) * (size_t)L * E);
-        for (int d = 0; d < 2; ++d) {
-            /* conv1d (width 4) + SiLU; direction 1 = anti-causal (the reverse Mamba on unflipped rows) */
-            const float* cw = ly->conv_w[d];
-            const float* cb = ly->conv_b[d];
-            for (int t = 0; t < L; ++t)
-                for (int c = 0; c < E; ++c) {
-                    float a = cb[c];
-                    for (int k = 0; k < 4; ++k) {
-                        const int tt = d == 0 ? t - 3 + k : t + 3 - k;
-                        if (tt >= 0 && tt < L) a += cw[c * 4 + k] * xz[(size_t)tt * 2 * E + c];
-                    }
-                    xc[(size_t)t * E + c] = silu_f(a);
+/* conv1d (width 4) + SiLU on x = xz[..., :E]; d = 1 is the anti-causal conv (reverse Mamba on unflipped rows) */
+static void conv_silu(const float* xz, const float* cw, const float* cb, float* xc, int S, int L, int E, int d) {
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int s = 0; s < S; ++s)
+        for (int t = 0; t < L; ++t) {
+            const float* base = xz + (size_t)s * L * 2 * E;
+            float* o = xc + ((size_t)s * L + t) * E;
+            for (int c = 0; c < E; ++c) {
+                float a = cb[c];
+                for (int k = 0; k < 4; ++k) {
+                    const int tt = d == 0 ? t - 3 + k : t + 3 - k;
+                    if (tt >= 0 && tt < L) a += cw[c * 4 + k] * base[(size_t)tt * 2 * E + c];
                 }
-            linear_nt(xc, E, ly->x_proj[d], E, dbl, XP, L, XP);
-            linear_nt(dbl, XP, ly->dt_w[d], R, delta, E, L, E);
-            for (int i = 0; i < E * NST; ++i) A[i] = -expf(ly->A_log[d][i]);
-            /* selective scan, channel blocks of VL lanes, sequential in t */
-            for (int c0 = 0; c0 < E; c0 += VL) {
-                float st[NST][VL], ab[NST][VL];
-                memset(st, 0, sizeof(st));
-                for (int n = 0; n < NST; ++n)
-                    for (int l = 0; l < VL; ++l) ab[n][l] = A[(size_t)(c0 + l) * NST + n];
-                for (int step = 0; step < L; ++step) {
-                    const int t = d == 0 ? step : L - 1 - step;
-                    const float* Bt = dbl + (size_t)t * XP + R;
-                    const float* Ct = Bt + NST;
-                    float dv[VL], du[VL], yv[VL];
+                o[c] = silu_f(a);
+            }
+        }
+}
+
+/* selective scan of one direction, accumulated into y (gated by silu(z)); channel blocks of VL lanes,
+ * sequential in t; parallel over (strand, channel block) */
+static void scan_dir(const float* xc, const float* delta, const float* dbl, const float* xz, const float* A,
+                     const float* dt_b, const float* Dskip, float* y, int S, int L, int E, int R, int d) {
+    const int XP = R + 2 * NST;
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int s = 0; s < S; ++s)
+        for (int c0 = 0; c0 < E; c0 += VL) {
+            const size_t r0 = (size_t)s * L;
+            float st[NST][VL], ab[NST][VL];
+            memset(st, 0, sizeof(st));
+            for (int n = 0; n < NST; ++n)
+                for (int l = 0; l < VL; ++l) ab[n][l] = A[(size_t)(c0 + l) * NST + n];
+            for (int step = 0; step < L; ++step) {
+                const size_t t = r0 + (d == 0 ? step : L - 1 - step);
+                const float* Bt = dbl + t * XP + R;
+                const float* Ct = Bt + NST;
+                float dv[VL], du[VL], yv[VL];
+                for (int l = 0; l < VL; ++l) {
+                    const int c = c0 + l;
+                    dv[l] = softplus_f(delta[t * E + c] + dt_b[c]);
+                    const float uv = xc[t * E + c];
+                    du[l] = dv[l] * uv;
+                    yv[l] = Dskip[c] * uv;
+                }
+                for (int n = 0; n < NST; ++n) {
+                    const float bn = Bt[n], cn = Ct[n];
                     for (int l = 0; l < VL; ++l) {
-                        const int c = c0 + l;
-                        dv[l] = softplus_f(delta[(size_t)t * E + c] + ly->dt_b[d][c]);
-                        const float uv = xc[(size_t)t * E + c];
-                        du[l] = dv[l] * uv;
-                        yv[l] = ly->Dskip[d][c] * uv;
+                        const float a = vexpf(dv[l] * ab[n][l]);
+                        st[n][l] = a * st[n][l] + du[l] * bn;
+                        yv[l] += st[n][l] * cn;
                     }
-                    for (int n = 0; n < NST; ++n) {
-                        const float bn = Bt[n], cn = Ct[n];
-                        for (int l = 0; l < VL; ++l) {
-                            const float a = vexpf(dv[l] * ab[n][l]);
-                            st[n][l] = a * st[n][l] + du[l] * bn;
-                            yv[l] += st[n][l] * cn;
-                        }
-                    }
-                    for (int l = 0; l < VL; ++l) {
-                        const int c = c0 + l;
-                        y[(size_t)t * E + c] += yv[l] * silu_f(xz[(size_t)t * 2 * E + E + c]);
-                    }
+                }
+                for (int l = 0; l < VL; ++l) {
+                    const int c = c0 + l;
+                    y[t * E + c] += yv[l] * silu_f(xz[t * 2 * E + E + c]);
                 }
             }
         }
-        linear_nt(y, E, ly->out_proj, E, h, D, L, D);
-    }
-    add_rmsnorm(h, res, 1, m->norm_f, H, L, D, m->eps);
-}
-
-size_t oracle_scratch_floats(const oracle_model* m, int L) {
-    const size_t D = m->d_model, E = m->d_inner, XP = m->dt_rank + 2 * NST;
-    return (size_t)L * (3 * D + 2 * E + E + XP + E + E) + E * NST + 64;
 }
 
 /*
@@ -252,32 +248,50 @@ size_t oracle_scratch_floats(const oracle_model* m, int L) {
  * returns 0, or -1 on allocation failure.
  */
 int oracle_forward(const oracle_model* m, const int32_t* ids, int B, int L, float* logits, float* hidden) {
-    const int D = m->d_model, S = 2 * B;
-    float* Hall = (float*)malloc(sizeof(float) * (size_t)S * L * D);
-    if (!Hall) return -1;
-    int err = 0;
-#pragma omp parallel
-    {
-        float* scratch = (float*)malloc(sizeof(float) * oracle_scratch_floats(m, L));
-        int32_t* tok = (int32_t*)malloc(sizeof(int32_t) * (size_t)L);
-        if (!scratch || !tok) {
-#pragma omp atomic write
-            err = -1;
-        } else {
-#pragma omp for schedule(dynamic, 1)
-            for (int s = 0; s < S; ++s) {
-                if (s < B) {
-                    for (int t = 0; t < L; ++t) tok[t] = ids[(size_t)s * L + t] & 7;
-                } else {
-                    for (int t = 0; t < L; ++t) tok[t] = m->complement[ids[(size_t)(s - B) * L + (L - 1 - t)] & 7];
-                }
-                strand_forward(m, tok, L, Hall + (size_t)s * L * D, scratch);
-            }
+    const int D = m->d_model, E = m->d_inner, R = m->dt_rank, XP = R + 2 * NST, S = 2 * B;
+    const size_t rows = (size_t)S * L;
+    /* the whole 2B-strand batch walks the stack layer by layer (as the HIP engine does); every operator is
+     * OpenMP-parallel inside, so a small sample still uses all cores */
+    const size_t nfl = rows * ((size_t)3 * D + 2 * E + E + XP + E + E) + (size_t)E * NST;
+    float* buf = (float*)malloc(sizeof(float) * nfl);
+    int32_t* tok = (int32_t*)malloc(sizeof(int32_t) * rows);
+    if (!buf || !tok) { free(buf); free(tok); return -1; }
+    float* res = buf;
+    float* u = res + rows * D;
+    float* h = u + rows * D;
+    float* xz = h + rows * D;
+    float* xc = xz + rows * 2 * E;
+    float* dbl = xc + rows * E;
+    float* delta = dbl + rows * XP;
+    float* y = delta + rows * E;
+    float* A = y + rows * E;
+
+    for (int s = 0; s < S; ++s)
+        for (int t = 0; t < L; ++t)
+            tok[(size_t)s * L + t] = s < B ? (ids[(size_t)s * L + t] & 7)
+                                           : m->complement[ids[(size_t)(s - B) * L + (L - 1 - t)] & 7];
+#pragma omp parallel for schedule(static)
+    for (int64_t r = 0; r < (int64_t)rows; ++r)
+        memcpy(h + (size_t)r * D, m->emb + (size_t)(tok[r] & 7) * D, sizeof(float) * D);
+
+    for (int li = 0; li < m->n_layer; ++li) {
+        const oracle_layer* ly = &m->layers[li];
+        add_rmsnorm(h, res, li > 0, ly->norm_w, u, (int64_t)rows, D, m->eps);
+        linear_nt(u, D, ly->in_proj, D, xz, 2 * E, (int)rows, 2 * E);
+        memset(y, 0, sizeof(float) * rows * E);
+        for (int d = 0; d < 2; ++d) {
+            conv_silu(xz, ly->conv_w[d], ly->conv_b[d], xc, S, L, E, d);
+            linear_nt(xc, E, ly->x_proj[d], E, dbl, XP, (int)rows, XP);
+            linear_nt(dbl, XP, ly->dt_w[d], R, delta, E, (int)rows, E);
+            for (int i = 0; i < E * NST; ++i) A[i] = -expf(ly->A_log[d][i]);
+            scan_dir(xc, delta, dbl, xz, A, ly->dt_b[d], ly->Dskip[d], y, S, L, E, R, d);
         }
-        free(scratch);
-        free(tok);
+        linear_nt(y, E, ly->out_proj, E, h, D, (int)rows, D);
     }
-    if (err) { free(Hall); return err; }
+    float* Hall = u;   /* final normalised hidden [S, L, D] */
+    add_rmsnorm(h, res, 1, m->norm_f, Hall, (int64_t)rows, D, m->eps);
+
+#pragma omp parallel for collapse(2) schedule(static)
     for (int b = 0; b < B; ++b)
         for (int l = 0; l < L; ++l) {
             const float* hf = Hall + ((size_t)b * L + l) * D;
@@ -296,6 +310,7 @@ int oracle_forward(const oracle_model* m, const int32_t* ids, int B, int L, floa
                 }
             }
         }
-    free(Hall);
+    free(buf);
+    free(tok);
     return 0;
 }

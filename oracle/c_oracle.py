@@ -12,7 +12,24 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB = os.path.join(_HERE, "c", "liboracle.so")
+
+
+def _host_tag() -> str:
+    """The library is compiled -march=native, so key its file name by this host's CPU feature flags."""
+    import hashlib
+    flags = ""
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("flags"):
+                    flags = line
+                    break
+    except OSError:
+        pass
+    return hashlib.sha1(flags.encode()).hexdigest()[:10]
+
+
+LIB = os.path.join(_HERE, "c", "liboracle-%s.so" % _host_tag())
 FP = C.POINTER(C.c_float)
 
 
@@ -28,14 +45,14 @@ class OracleModel(C.Structure):
 
 
 def build():
-    r = subprocess.run(["make", "-C", os.path.join(_HERE, "c")], capture_output=True, text=True)
+    r = subprocess.run(["make", "-C", os.path.join(_HERE, "c"), "TARGET=" + os.path.basename(LIB)],
+                       capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(r.stdout + r.stderr)
 
 
 def _lib():
-    if not os.path.exists(LIB):
-        build()
+    build()   # make: no-op when this host's copy is up to date
     lib = C.CDLL(LIB)
     lib.oracle_forward.restype = C.c_int
     lib.oracle_forward.argtypes = [C.POINTER(OracleModel), C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]

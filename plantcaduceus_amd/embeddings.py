@@ -1,0 +1,71 @@
+"""Embedding extraction — host side of the hot path, mirroring reference `src/train_XGBoost.py`
+(`extract_embeddings` :96-114, `SequenceDataset` :29-49, `load_data` :51-54; `predict_XGBoost.py`
+reaches the same function through `from train_XGBoost import *`).
+
+  extract_embeddings(model, sequences, device, tokenIdx, tokenizer, batch_size)
+      forward with output_hidden_states=True, hidden_states[-1][:, tokenIdx, :] -> fp32,
+      forward half + channel-reversed rc half, / 2                                   -> fp32 [N, d_model]
+
+Host-side differences only: whole-list vectorised tokenisation (no masking on this path), the model is
+asked for position tokenIdx only (hidden [B,1,2D] instead of 33 x [B,512,2D]), the averaging runs on the
+device, and under torch.distributed the window list is block-sharded and the [N, D] result reassembled with
+one all-gather per call (= one `-chunk_size` chunk of the reference's -save_memory mode, :175-190).
+The XGBoost fit/predict and the ROC/PR plots of the reference script are CPU tree-model code and are out of
+scope; `save_embedding_cache` keeps the reference's .npz keys so they run unchanged.
+"""
+from __future__ import annotations
+
+import logging
+
+import numpy as np
+import torch
+
+from . import sharding
+from .zero_shot import tokenize_masked
+
+
+def load_data(filepath):
+    import pandas as pd
+    logging.info(f"Loading data from {filepath}")
+    data = pd.read_csv(filepath, delimiter="\t")
+    return data["sequences"].tolist(), data["label"].tolist()
+
+
+def extract_embeddings(model, sequences, device, tokenIdx: int, tokenizer=None, batch_size: int = 128) -> np.ndarray:
+    logging.info("Extracting embeddings")
+    if isinstance(sequences, (np.ndarray, torch.Tensor)):
+        ids_all = torch.as_tensor(np.asarray(sequences) if not torch.is_tensor(sequences) else sequences)
+    else:
+        ids_all = torch.from_numpy(tokenize_masked(sequences, tokenizer, None))
+    n_total = ids_all.shape[0]
+    rank, ws = sharding.world()
+    start, stop, per = sharding.shard_bounds(n_total, rank, ws)
+    ids_local = sharding.pad_rows(ids_all[start:stop], per) if ws > 1 else ids_all
+    fast = bool(getattr(model, "supports_positions", False))
+    model.eval()
+    outs = []
+    with torch.inference_mode():
+        for b0 in range(0, ids_local.shape[0], batch_size):
+            cur = ids_local[b0:b0 + batch_size].to(device, non_blocking=True)
+            if fast:
+                e = model(input_ids=cur, output_hidden_states=True, positions=[tokenIdx]).hidden_states[-1][:, 0, :]
+            else:
+                e = model(input_ids=cur, output_hidden_states=True).hidden_states[-1][:, tokenIdx, :]
+            e = e.to(torch.float32)
+            hsz = e.shape[-1] // 2
+            outs.append((e[:, :hsz] + torch.flip(e[:, hsz:], dims=[-1])) / 2)
+        if outs:
+            emb = torch.cat(outs, dim=0)
+        else:
+            d = getattr(getattr(model, "config", None), "d_model", 0)
+            emb = torch.empty((0, d), dtype=torch.float32, device=device)
+        emb = sharding.all_gather_rows(emb, n_total)
+    return emb.cpu().numpy()
+
+
+def save_embedding_cache(path: str, **arrays):
+    """np.savez_compressed with the reference's keys (`train`, `valid`, `test`: src/train_XGBoost.py:186,199,221)."""
+    bad = set(arrays) - {"train", "valid", "test"}
+    if bad:
+        raise ValueError(f"unexpected cache keys {sorted(bad)}")
+    np.savez_compressed(path, **arrays)

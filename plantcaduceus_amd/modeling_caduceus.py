@@ -104,6 +104,7 @@ class CaduceusPreTrainedModel(PreTrainedModel):
     config_class = CaduceusConfig
     base_model_prefix = "caduceus"
     supports_gradient_checkpointing = False
+    supports_positions = True     # forward(..., positions=[p, ...]) evaluates the head at those rows only
     _no_split_modules = ["_Block"]
 
     def _init_weights(self, module):   # weights always come from a checkpoint

@@ -1,0 +1,53 @@
+"""Batch sharding of independent 512-bp windows across the GPUs of one node (one process per GPU).
+
+The reference is single-process / single-device (`src/zero_shot_score.py:27,97,112`); windows are
+independent (`:111-120` is a plain loop over batches), so the path shards with NO data-path collective:
+rank r owns the contiguous block [r*ceil(N/W), (r+1)*ceil(N/W)) of the window list, the tail padded with
+a dummy window so every rank runs the same number of rows, and ONE all-gather (RCCL over xGMI on the GPU
+box, gloo in the CPU tests) per result chunk reassembles the per-SNP rows in the single-GPU order
+(SURVEY.md §8e).  Payloads are tiny (16 B/window of probabilities, 4*D B/window of embeddings).
+"""
+from __future__ import annotations
+
+from typing import Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def world() -> Tuple[int, int]:
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def shard_bounds(n: int, rank: int, world_size: int) -> Tuple[int, int, int]:
+    """-> (start, stop, per_rank): contiguous block of rank `rank`; per_rank = ceil(n / world_size)."""
+    per = -(-n // world_size) if n > 0 else 0
+    start = min(rank * per, n)
+    stop = min(start + per, n)
+    return start, stop, per
+
+
+def pad_rows(x: torch.Tensor, rows: int) -> torch.Tensor:
+    """Pad dim 0 to `rows` by repeating the last row (a dummy window; stripped after the gather)."""
+    if x.shape[0] == rows:
+        return x
+    if x.shape[0] == 0:
+        return x.new_zeros((rows,) + tuple(x.shape[1:]))
+    return torch.cat([x, x[-1:].expand(rows - x.shape[0], *x.shape[1:])], dim=0)
+
+
+def all_gather_rows(local: torch.Tensor, n_total: int) -> torch.Tensor:
+    """local [per_rank, ...] (equal on every rank) -> [n_total, ...] in rank order, padding stripped."""
+    rank, ws = world()
+    if ws == 1:
+        return local[:n_total]
+    local = local.contiguous()
+    out = torch.empty((ws * local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    if local.is_cuda:
+        dist.all_gather_into_tensor(out, local)            # RCCL
+    else:
+        parts = list(out.chunk(ws, dim=0))                 # gloo (CPU tests)
+        dist.all_gather(parts, local)
+    return out[:n_total]

@@ -1,0 +1,275 @@
+"""Zero-shot SNP scoring — host side of the hot path, mirroring reference `src/zero_shot_score.py`
+function by function (same names, argument meaning, flags and output conventions):
+
+  parse_args                 :14-37    single-dash long flags, same defaults
+  tokenize_masked            :40-62    SequenceDataset.__getitem__ (tokenise + overwrite index tokenIdx with
+                                       [MASK]) for a whole list at once: vectorised byte->id LUT, no per-sequence
+                                       Python loop, no DataLoader
+  get_optimal_dtype / load_model_and_tokenizer   :65-98   fp32 without a GPU / bf16 cap>=8 / fp16->bf16 note below
+  extract_logits             :107-121  batched forward, logits[:, tokenIdx, ids(a,c,g,t)], softmax over 4 -> [N,4]
+  zero_shot_score            :124-134  log(p[alt] / p[ref]), nucleotide order A,C,G,T
+  zero_shot_score_vcf        :137-169  INFO/plantCAD_zero_shot = comma-joined per-ALT scores, "." for non-SNV
+  seq_from_vcf               :172-214  windows [pos-tokenIdx, pos+512-tokenIdx), upper-cased, N-padded
+  main                       :217-259  TSV / BED / VCF outputs
+
+Differences, all on the host side: probabilities stay on the device until the end (one D2H copy per call
+instead of one per batch, reference :119); the model is asked for the masked position only
+(`positions=[tokenIdx]`, so the LM head runs on 1 of 512 rows); under `torch.distributed` the window list is
+block-sharded over the ranks and the [N,4] probabilities are reassembled with one all-gather
+(plantcaduceus_amd/sharding.py).  fp16 is not an engine dtype: capability 6/7 devices do not exist on this
+platform (gfx950 reports major 9 -> bf16, exactly as the reference's rule selects).
+VCF/FASTA are read with small built-in readers (PyVCF3 / BioPython are not dependencies).
+"""
+from __future__ import annotations
+
+import argparse
+import gzip
+import logging
+import sys
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import sharding
+
+NUCLEOTIDES = ["A", "C", "G", "T"]
+
+
+def parse_args(argv: Optional[Sequence[str]] = None):
+    parser = argparse.ArgumentParser()
+    g = parser.add_mutually_exclusive_group(required=True)
+    g.add_argument("-input-table", dest="inputDF", type=str, default=None,
+                   help="The directory of input tab-separated file. Required columns: ref, alt, sequences")
+    g.add_argument("-input-vcf", dest="inputVCF", type=str, default=None, help="The directory of input vcf")
+    parser.add_argument("-input-fasta", dest="inputFasta", type=str, default=None,
+                        help="The directory of input fasta. Required if using VCF")
+    parser.add_argument("-output", dest="output", default=None, help="The directory of output")
+    parser.add_argument("-outBED", action="store_true", dest="outBED", default=False,
+                        help="Output in BED format instead of tab-separated file, only works with -input-table")
+    parser.add_argument("-model", dest="model", default=None, help="The directory of pre-trained model")
+    parser.add_argument("-device", dest="device", default="cuda:0", help="The device to run the model")
+    parser.add_argument("-batchSize", dest="batchSize", default=128, type=int, help="The batch size for the model")
+    parser.add_argument("-numWorkers", dest="numWorkers", default=4, type=int,
+                        help="Accepted for compatibility (the reference parses but never uses it)")
+    parser.add_argument("-tokenIdx", dest="tokenIdx", default=255, type=int, help="The index of the nucleotide to mask")
+    args = parser.parse_args(argv)
+    if args.inputVCF is not None and args.inputFasta is None:
+        sys.exit("-input-fasta is required with -input-vcf")
+    return args
+
+
+# ---- a1: tokenisation + masking --------------------------------------------------------------------
+def tokenize_masked(sequences: Sequence[str], tokenizer, tokenIdx: Optional[int]) -> np.ndarray:
+    """[N] equal-length strings -> int32 [N, L]; column tokenIdx := [MASK] (None: no masking)."""
+    if hasattr(tokenizer, "encode_batch"):
+        return tokenizer.encode_batch(sequences, mask_index=tokenIdx)
+    ids = np.stack([np.asarray(tokenizer(s)["input_ids"], dtype=np.int32).reshape(-1) for s in sequences])
+    if tokenIdx is not None:
+        ids[:, tokenIdx] = tokenizer.mask_token_id
+    return ids
+
+
+# ---- a2: model loading ----------------------------------------------------------------------------
+def get_optimal_dtype() -> torch.dtype:
+    if not torch.cuda.is_available():
+        logging.info("Using float32 as no GPU is available.")
+        return torch.float32
+    cap = torch.cuda.get_device_capability(torch.cuda.current_device())
+    if cap[0] >= 8:
+        logging.info("Using bfloat16 as the GPU supports it (capability %d.%d)." % cap)
+        return torch.bfloat16
+    logging.info("Using float32.")
+    return torch.float32
+
+
+def load_model_and_tokenizer(model_dir: str, device: str):
+    from .modeling_caduceus import CaduceusForMaskedLM
+    from .tokenization_caduceus import CaduceusTokenizer
+    logging.info(f"Loading model and tokenizer from {model_dir}")
+    dtype = get_optimal_dtype()
+    try:
+        model = CaduceusForMaskedLM.from_pretrained(model_dir, trust_remote_code=True, torch_dtype=dtype)
+    except Exception as e:   # same fallback as the reference (:90-94)
+        logging.error(f"Failed to load model with {dtype}, falling back to float32. Error: {e}")
+        model = CaduceusForMaskedLM.from_pretrained(model_dir, trust_remote_code=True, torch_dtype=torch.float32)
+    tokenizer = CaduceusTokenizer.from_pretrained(model_dir) if _has_vocab(model_dir) else CaduceusTokenizer()
+    model.to(device)
+    return model, tokenizer
+
+
+def _has_vocab(model_dir: str) -> bool:
+    import os
+    return os.path.exists(os.path.join(model_dir, "vocab.json"))
+
+
+# ---- a3: batched forward -> [N, 4] probabilities ------------------------------------------------------
+def extract_logits(model, sequences, device, tokenIdx: int, tokenizer, batch_size: int = 128) -> np.ndarray:
+    """sequences: list of equal-length strings, or a pre-tokenised+masked integer array [N, L].
+    Returns softmax over the (a,c,g,t) logits at tokenIdx, fp32 [N, 4], rows in input order (all ranks)."""
+    logging.info("Extracting logits")
+    ids_all = sequences if isinstance(sequences, (np.ndarray, torch.Tensor)) else tokenize_masked(sequences, tokenizer, tokenIdx)
+    ids_all = torch.as_tensor(np.asarray(ids_all) if not torch.is_tensor(ids_all) else ids_all)
+    n_total = ids_all.shape[0]
+    vocab = tokenizer.get_vocab()
+    cols = [vocab[nc] for nc in "acgt"]
+    rank, ws = sharding.world()
+    start, stop, per = sharding.shard_bounds(n_total, rank, ws)
+    ids_local = sharding.pad_rows(ids_all[start:stop], per) if ws > 1 else ids_all
+    fast = bool(getattr(model, "supports_positions", False))
+    outs = []
+    with torch.inference_mode():
+        for b0 in range(0, ids_local.shape[0], batch_size):
+            cur = ids_local[b0:b0 + batch_size].to(device, non_blocking=True)
+            if fast:
+                lg = model(input_ids=cur, positions=[tokenIdx]).logits[:, 0, :]
+            else:
+                lg = model(input_ids=cur).logits[:, tokenIdx, :]
+            outs.append(torch.softmax(lg[:, cols].float(), dim=1))
+        if outs:
+            probs = torch.cat(outs, dim=0)
+        else:
+            probs = torch.empty((0, 4), dtype=torch.float32, device=device)
+        probs = sharding.all_gather_rows(probs, n_total)
+    return probs.cpu().numpy()
+
+
+# ---- a15: scores ------------------------------------------------------------------------------------
+def zero_shot_score(snpDF, logits) -> List[float]:
+    logging.info("Calculating zero-shot scores")
+    logits = np.asarray(logits)
+    ref = np.array([NUCLEOTIDES.index(r) for r in snpDF["ref"]], dtype=np.int64)
+    alt = np.array([NUCLEOTIDES.index(a) for a in snpDF["alt"]], dtype=np.int64)
+    n = len(ref)
+    rows = np.arange(n)
+    return list(np.log(logits[rows, alt] / logits[rows, ref]))
+
+
+# ---- a16: VCF + FASTA -> windows ----------------------------------------------------------------------
+def read_fasta(path: str) -> Dict[str, str]:
+    """name (first word of the header) -> sequence, case preserved."""
+    opener = gzip.open if path.endswith(".gz") else open
+    out: Dict[str, List[str]] = {}
+    name = None
+    with opener(path, "rt") as f:
+        for line in f:
+            if line.startswith(">"):
+                name = line[1:].split()[0] if len(line) > 1 and line[1:].split() else ""
+                out[name] = []
+            elif name is not None:
+                out[name].append(line.strip())
+    return {k: "".join(v) for k, v in out.items()}
+
+
+def iter_vcf(path: str):
+    """Yields (line_without_newline, fields | None): header lines have fields None."""
+    opener = gzip.open if path.endswith(".gz") else open
+    with opener(path, "rt") as f:
+        for line in f:
+            line = line.rstrip("\n")
+            if not line:
+                continue
+            if line.startswith("#"):
+                yield line, None
+            else:
+                yield line, line.split("\t")
+
+
+def _is_snv(alt: str) -> bool:
+    # PyVCF `_Substitution.type`: "SNV" for a single nucleotide; symbolic / breakend / "." / "*" are not
+    return len(alt) == 1 and alt.upper() in "ACGTN"
+
+
+def window_for(chrom_seq: str, pos0: int, tokenIdx: int, length: int = 512) -> str:
+    """reference :187-198: [pos-tokenIdx, pos+length-tokenIdx), upper-cased, N-padded to `length`."""
+    add = length - tokenIdx
+    if pos0 - tokenIdx < 0:
+        return chrom_seq[0:pos0 + add].upper().rjust(length, "N")
+    return chrom_seq[pos0 - tokenIdx:pos0 + add].upper().ljust(length, "N")
+
+
+def seq_from_vcf(args) -> Tuple[List[str], List[int]]:
+    logging.info(f"Reading input data from {args.inputVCF}")
+    fasta = read_fasta(args.inputFasta)
+    sequences, recordIndices = [], []
+    recordIdx = 0
+    for line, f in iter_vcf(args.inputVCF):
+        if f is None:
+            continue
+        alts = f[4].split(",")
+        if any(_is_snv(a) for a in alts):
+            chrom, pos0 = f[0], int(f[1]) - 1
+            if chrom not in fasta:
+                print("Error processing VCF at record " + str(recordIdx))
+                print("Check that VCF file is sorted and chromosome names match FASTA file.")
+                print(line)
+                sys.exit()
+            sequences.append(window_for(fasta[chrom], pos0, args.tokenIdx))
+            recordIndices.append(recordIdx)
+        recordIdx += 1
+    return sequences, recordIndices
+
+
+def zero_shot_score_vcf(args, recordIndices, logits):
+    """Writes the scored records (header passed through) with INFO/plantCAD_zero_shot appended."""
+    logging.info("Calculating zero-shot scores")
+    want = {ri: k for k, ri in enumerate(recordIndices)}
+    with open(args.output, "w") as out:
+        idx = 0
+        for line, f in iter_vcf(args.inputVCF):
+            if f is None:
+                out.write(line + "\n")
+                continue
+            k = want.get(idx)
+            idx += 1
+            if k is None:
+                continue
+            ref = f[3].upper()
+            scores = []
+            for alt in f[4].split(","):
+                if _is_snv(alt) and ref in NUCLEOTIDES and alt.upper() in NUCLEOTIDES:
+                    scores.append(str(np.log(logits[k][NUCLEOTIDES.index(alt.upper())] / logits[k][NUCLEOTIDES.index(ref)])))
+                else:
+                    scores.append(".")
+            tag = "plantCAD_zero_shot=" + ",".join(scores)
+            while len(f) < 8:
+                f.append(".")
+            f[7] = tag if f[7] in (".", "") else f[7] + ";" + tag
+            out.write("\t".join(f) + "\n")
+
+
+def main(argv: Optional[Sequence[str]] = None):
+    import pandas as pd
+    logging.basicConfig(level=logging.INFO, format="%(asctime)s - %(levelname)s - %(message)s",
+                        datefmt="%Y-%m-%d %H:%M:%S")
+    args = parse_args(argv)
+    if args.inputDF is not None:
+        logging.info(f"Reading input data from {args.inputDF}")
+        snpDF = pd.read_csv(args.inputDF, delimiter="\t")
+        ok = snpDF["ref"].isin(NUCLEOTIDES) & snpDF["alt"].isin(NUCLEOTIDES)
+        logging.info(f"Filtered out {len(snpDF) - int(ok.sum())} invalid SNPs")
+        snpDF = snpDF[ok].copy()
+        sequences = snpDF["sequences"].tolist()
+    else:
+        sequences, recordIndices = seq_from_vcf(args)
+    model, tokenizer = load_model_and_tokenizer(args.model, args.device)
+    logits = extract_logits(model, sequences, args.device, args.tokenIdx, tokenizer, args.batchSize)
+    rank, _ = sharding.world()
+    if rank != 0:
+        return
+    if args.inputDF is not None:
+        snpDF["zeroShotScore"] = zero_shot_score(snpDF, logits)
+        if args.outBED:
+            snpDF["start"] = snpDF["pos"] - 1
+            snpDF["end"] = snpDF["pos"]
+            snpDF[["chr", "start", "end", "ref", "alt", "zeroShotScore"]].to_csv(args.output, sep="\t", index=False,
+                                                                                header=False)
+        else:
+            snpDF.to_csv(args.output, sep="\t", index=False)
+    else:
+        zero_shot_score_vcf(args, recordIndices, logits)
+    logging.info(f"Zero-shot scores saved to {args.output}")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,89 @@
+"""-m gpu: the committed golden vectors (reference-harness outputs, model_tiny) and BASELINE config 3
+(l32 bf16 on examples/example_snp.tsv) through the HIP path behind the HF surface."""
+import os
+
+import numpy as np
+import pandas as pd
+import pytest
+import torch
+
+from plantcaduceus_amd import embeddings, zero_shot
+from plantcaduceus_amd.checkpoint import make_config, synthetic_state_dict
+from plantcaduceus_amd.tokenization_caduceus import CaduceusTokenizer
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def hip_model(cfg, sd, dtype):
+    from plantcaduceus_amd.modeling_caduceus import CaduceusForMaskedLM
+    m = CaduceusForMaskedLM(cfg)
+    m.load_state_dict(sd, strict=False)
+    m.tie_weights()
+    return m.to(dtype).to(DEV)
+
+
+def test_model_tiny_golden(golden_dir):
+    g = np.load(os.path.join(golden_dir, "model_tiny.npz"))
+    cfg = make_config("x", d_model=int(g["d_model"]), n_layer=int(g["n_layer"]))
+    cfg.materialize_all_hidden_states = True
+    m = hip_model(cfg, synthetic_state_dict(cfg, seed=int(g["seed"])), torch.float32)
+    out = m(input_ids=torch.from_numpy(g["ids"]).to(DEV), output_hidden_states=True)
+    lg = out.logits.cpu().numpy()
+    assert np.abs(lg - g["logits"]).max() / np.abs(g["logits"]).max() < 1e-4          # north_star: <=1e-4 rel
+    assert (lg[..., 3:7].argmax(-1) == g["logits"][..., 3:7].argmax(-1)).all()        # bit-exact token calls
+    hs = out.hidden_states
+    assert len(hs) == cfg.n_layer + 1
+    for got, key in ((hs[-1], "hidden"), (hs[0], "hidden0"), (hs[1], "hidden1")):
+        assert np.abs(got.cpu().numpy() - g[key]).max() / np.abs(g[key]).max() < 1e-4
+
+
+def test_reference_harness_goldens_through_hip(golden_dir):
+    z = np.load(os.path.join(golden_dir, "harness_zero_shot.npz"))
+    e = np.load(os.path.join(golden_dir, "harness_embeddings.npz"))
+    df = pd.read_csv(os.path.join(golden_dir, "example_snp.tsv"), delimiter="\t")
+    df = df[z["keep_mask"]].iloc[: int(z["model_rows"])]
+    cfg = make_config("x", d_model=int(z["model_d_model"]), n_layer=int(z["model_n_layer"]))
+    m = hip_model(cfg, synthetic_state_dict(cfg, seed=int(z["model_seed"])), torch.float32)
+    tok = CaduceusTokenizer()
+    probs = zero_shot.extract_logits(m, df["sequences"].tolist(), DEV, int(z["token_idx"]), tok, batch_size=4)
+    np.testing.assert_allclose(probs, z["model_probs"], rtol=1e-4, atol=1e-6)
+    assert (probs.argmax(1) == z["model_probs"].argmax(1)).all()
+    np.testing.assert_allclose(np.asarray(zero_shot.zero_shot_score(df, probs)), z["model_scores"], rtol=1e-3, atol=1e-4)
+    emb = embeddings.extract_embeddings(m, df["sequences"].tolist(), DEV, int(e["token_idx"]), tok, batch_size=4)
+    assert np.abs(emb - e["embeddings"]).max() / np.abs(e["embeddings"]).max() < 1e-4
+
+
+def test_config3_l32_bf16_example_snps(golden_dir):
+    """PlantCaduceus_l32 bf16 on the reference's example table (185 scored rows), synthetic checkpoint seed 1234.
+    Size-independent properties on all rows + the fp32 C oracle on a bounded sample."""
+    df = pd.read_csv(os.path.join(golden_dir, "example_snp.tsv"), delimiter="\t")
+    df = df[df["ref"].isin(list("ACGT")) & df["alt"].isin(list("ACGT"))]
+    assert len(df) == 185
+    cfg = make_config("l32")
+    sd = synthetic_state_dict(cfg, seed=1234, stress=False)
+    m = hip_model(cfg, sd, torch.bfloat16)
+    tok = CaduceusTokenizer()
+    seqs = df["sequences"].tolist()
+    probs = zero_shot.extract_logits(m, seqs, DEV, 255, tok, batch_size=128)
+    assert probs.shape == (185, 4) and np.isfinite(probs).all()
+    np.testing.assert_allclose(probs.sum(1), 1.0, rtol=1e-5)
+    scores = np.asarray(zero_shot.zero_shot_score(df, probs))
+    assert np.isfinite(scores).all()
+    # reverse-complement equivariance of the call: P(rc window masked at 511-255)[comp base] == P(window)[base]
+    comp = str.maketrans("ACGT", "TGCA")
+    rc = [s.translate(comp)[::-1] for s in seqs]
+    probs_rc = zero_shot.extract_logits(m, rc, DEV, 511 - 255, tok, batch_size=128)[:, ::-1]
+    assert np.abs(probs_rc - probs).max() < 2e-2           # bf16 path: both strands are computed, in swapped roles
+    # bounded sample against the fp32 CPU oracle (C port): bf16 tolerance on probabilities, argmax where confident
+    from oracle.c_oracle import COracle
+    n = 4
+    ids = tok.encode_batch(seqs[:n], mask_index=255)
+    lg, _ = COracle(sd, cfg, dtype=torch.bfloat16).forward(ids)
+    z = lg[:, 255, 3:7]
+    ref = np.exp(z - z.max(1, keepdims=True))
+    ref /= ref.sum(1, keepdims=True)
+    assert np.abs(probs[:n] - ref).max() < 3e-2
+    top2 = np.sort(ref, 1)[:, -2:]
+    conf = (top2[:, 1] - top2[:, 0]) > 6e-2
+    assert (probs[:n].argmax(1)[conf] == ref.argmax(1)[conf]).all()

@@ -1,0 +1,143 @@
+"""CPU: the host side of the path (plantcaduceus_amd/zero_shot.py, embeddings.py) against golden vectors
+produced by the REFERENCE's own functions (oracle/gen_golden.py imports src/zero_shot_score.py and
+src/train_XGBoost.py in the build container).  The model in the loop is the CPU oracle stand-in — test
+infrastructure; the product model class has no CPU path."""
+import json
+import os
+import types
+
+import numpy as np
+import pandas as pd
+import pytest
+import torch
+
+from oracle import caduceus_oracle as O
+from plantcaduceus_amd import embeddings, zero_shot
+from plantcaduceus_amd.checkpoint import make_config, synthetic_state_dict
+from plantcaduceus_amd.tokenization_caduceus import CaduceusTokenizer
+
+
+@pytest.fixture(scope="module")
+def snp_df(golden_dir):
+    return pd.read_csv(os.path.join(golden_dir, "example_snp.tsv"), delimiter="\t")
+
+
+def _oracle_model(g):
+    cfg = make_config("x", d_model=int(g["model_d_model"]), n_layer=int(g["model_n_layer"]))
+    sd = synthetic_state_dict(cfg, seed=int(g["model_seed"]))
+    return O.OracleForMaskedLM(O.params_from_state_dict(sd, cfg))
+
+
+def test_example_table_integrity(snp_df):
+    assert len(snp_df) == 190
+    assert set(snp_df.columns) >= {"chr", "start", "end", "pos", "ref", "alt", "sequences"}
+    assert (snp_df["sequences"].str.len() == 512).all()
+    ok = snp_df["ref"].isin(list("ACGT")) & snp_df["alt"].isin(list("ACGT"))
+    assert int(ok.sum()) == 185
+    assert all(s[255] == r for s, r in zip(snp_df["sequences"], snp_df["ref"]))
+
+
+def test_zero_shot_score_matches_reference_function(golden_dir, snp_df):
+    g = np.load(os.path.join(golden_dir, "harness_zero_shot.npz"))
+    df = snp_df[g["keep_mask"]]
+    got = np.asarray(zero_shot.zero_shot_score(df, g["dirichlet_probs"]), dtype=np.float64)
+    np.testing.assert_allclose(got, g["dirichlet_scores"], rtol=1e-6, atol=1e-7)
+
+
+def test_extract_logits_matches_reference_loop(golden_dir, snp_df):
+    g = np.load(os.path.join(golden_dir, "harness_zero_shot.npz"))
+    df = snp_df[g["keep_mask"]].iloc[: int(g["model_rows"])]
+    tok = CaduceusTokenizer()
+    probs = zero_shot.extract_logits(_oracle_model(g), df["sequences"].tolist(), "cpu", int(g["token_idx"]), tok,
+                                     batch_size=3)
+    assert probs.shape == (int(g["model_rows"]), 4) and probs.dtype == np.float32
+    np.testing.assert_allclose(probs, g["model_probs"], rtol=2e-5, atol=1e-7)
+    np.testing.assert_allclose(np.asarray(zero_shot.zero_shot_score(df, probs)), g["model_scores"], rtol=1e-4, atol=1e-5)
+
+
+def test_extract_embeddings_matches_reference_loop(golden_dir, snp_df):
+    g = np.load(os.path.join(golden_dir, "harness_embeddings.npz"))
+    z = np.load(os.path.join(golden_dir, "harness_zero_shot.npz"))
+    seqs = snp_df[z["keep_mask"]]["sequences"].tolist()[: int(g["model_rows"])]
+    emb = embeddings.extract_embeddings(_oracle_model(g), seqs, "cpu", int(g["token_idx"]), CaduceusTokenizer(), batch_size=4)
+    assert emb.shape == g["embeddings"].shape and emb.dtype == np.float32
+    np.testing.assert_allclose(emb, g["embeddings"], rtol=1e-5, atol=1e-6)
+
+
+def test_tokenize_masked_equals_per_sequence_reference_semantics(snp_df):
+    tok = CaduceusTokenizer()
+    seqs = snp_df["sequences"].tolist()[:5] + ["acgtn" * 102 + "NN"]
+    ids = zero_shot.tokenize_masked(seqs, tok, 255)
+    assert ids.shape == (6, 512) and (ids[:, 255] == tok.mask_token_id).all()
+    v = tok.get_vocab()
+    for s, row in zip(seqs, ids):
+        want = [v.get(ch.lower(), v["[UNK]"]) for ch in s]
+        want[255] = tok.mask_token_id
+        assert row.tolist() == want
+    assert tok.encode_plus("ACGTNacgt", return_tensors="pt")["input_ids"].tolist() == [[3, 4, 5, 6, 2, 3, 4, 5, 6]]
+    assert tok.mask_token_id == 1 and tok.encode_batch([]).shape == (0, 0)
+    with pytest.raises(ValueError):
+        tok.encode_batch(["ACG", "AC"])
+
+
+def test_windows_match_reference_seq_from_vcf(golden_dir, tmp_path):
+    with open(os.path.join(golden_dir, "harness_windows.json")) as f:
+        g = json.load(f)
+    fa = tmp_path / "g.fa"
+    with open(fa, "w") as f:
+        for name, seq in g["genome"].items():
+            f.write(f">{name} some description\n")
+            for i in range(0, len(seq), 60):
+                f.write(seq[i:i + 60] + "\n")
+    vcf = tmp_path / "v.vcf"
+    with open(vcf, "w") as f:
+        f.write("##fileformat=VCFv4.2\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\n")
+        for c, p, r, alts in g["records"]:
+            f.write(f"{c}\t{p}\t.\t{r}\t{','.join(alts)}\t.\tPASS\tDP=3\n")
+    for tidx, want in g["windows"].items():
+        args = types.SimpleNamespace(inputVCF=str(vcf), inputFasta=str(fa), tokenIdx=int(tidx))
+        seqs, ridx = zero_shot.seq_from_vcf(args)
+        assert ridx == want["record_indices"]
+        assert seqs == want["sequences"]
+        assert all(len(s) == 512 for s in seqs)
+    # VCF writer: per-ALT scores, "." for non-SNV alts, only scored records written, header passed through
+    args = types.SimpleNamespace(inputVCF=str(vcf), inputFasta=str(fa), tokenIdx=255, output=str(tmp_path / "o.vcf"))
+    seqs, ridx = zero_shot.seq_from_vcf(args)
+    probs = np.random.default_rng(0).dirichlet(np.ones(4), size=len(seqs))
+    zero_shot.zero_shot_score_vcf(args, ridx, probs)
+    lines = [l for l in open(args.output).read().splitlines() if not l.startswith("#")]
+    assert len(lines) == len(ridx)
+    recs = [g["records"][i] for i in ridx]
+    for line, (c, p, r, alts), pr in zip(lines, recs, probs):
+        info = line.split("\t")[7]
+        assert info.startswith("DP=3;plantCAD_zero_shot=")
+        vals = info.split("plantCAD_zero_shot=")[1].split(",")
+        assert len(vals) == len(alts)
+        for a, v in zip(alts, vals):
+            if len(a) == 1 and a in "ACGT":
+                assert abs(float(v) - np.log(pr["ACGT".index(a)] / pr["ACGT".index(r)])) < 1e-9
+            else:
+                assert v == "."
+
+
+def test_cli_table_and_bed_outputs(golden_dir, tmp_path, monkeypatch):
+    """config-1 plumbing: TSV in -> TSV/BED out through main(), with the oracle stand-in as the loaded model."""
+    g = np.load(os.path.join(golden_dir, "harness_zero_shot.npz"))
+    src = pd.read_csv(os.path.join(golden_dir, "example_snp.tsv"), delimiter="\t").iloc[:12]
+    inp = tmp_path / "in.tsv"
+    src.to_csv(inp, sep="\t", index=False)
+    model = _oracle_model(g)
+    monkeypatch.setattr(zero_shot, "load_model_and_tokenizer", lambda d, dev: (model, CaduceusTokenizer()))
+    out = tmp_path / "out.tsv"
+    zero_shot.main(["-input-table", str(inp), "-output", str(out), "-model", "unused", "-device", "cpu", "-batchSize", "5"])
+    res = pd.read_csv(out, delimiter="\t")
+    ok = src["ref"].isin(list("ACGT")) & src["alt"].isin(list("ACGT"))
+    assert len(res) == int(ok.sum()) and "zeroShotScore" in res.columns
+    n = min(len(res), int(g["model_rows"]))
+    np.testing.assert_allclose(res["zeroShotScore"].to_numpy()[:n], g["model_scores"][:n], rtol=1e-4, atol=1e-5)
+    bed = tmp_path / "out.bed"
+    zero_shot.main(["-input-table", str(inp), "-output", str(bed), "-model", "unused", "-device", "cpu", "-outBED"])
+    b = pd.read_csv(bed, delimiter="\t", header=None)
+    assert b.shape[1] == 6 and (b[2] - b[1] == 1).all()
+    with pytest.raises(SystemExit):
+        zero_shot.parse_args(["-input-vcf", "x.vcf", "-model", "m"])

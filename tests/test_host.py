@@ -1,0 +1,105 @@
+"""CPU: host logic that needs no GPU — the C-ABI library loads and exports every symbol include/pcad.h
+declares (no compute calls), config / checkpoint / HF-surface plumbing, argument validation at the ABI."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from plantcaduceus_amd import engine
+from plantcaduceus_amd.checkpoint import load_state_dict, make_config, make_synthetic_checkpoint, synthetic_state_dict
+from plantcaduceus_amd.configuration_caduceus import CaduceusConfig
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    if not os.path.exists(engine.LIB_PATH):
+        engine.build_library()
+    return engine.load_library()
+
+
+def test_abi_exports_every_declared_symbol(lib):
+    hdr = open(os.path.join(ROOT, "include", "pcad.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(pcad_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 15
+    assert declared == set(engine.SIGNATURES), declared ^ set(engine.SIGNATURES)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.pcad_version() == 100
+
+
+def test_abi_create_validates_config_without_gpu(lib):
+    def cfg(**kw):
+        base = dict(d_model=128, n_layer=2, d_state=16, d_conv=4, expand=2, dt_rank=8, vocab=8, eps=1e-5, dtype=1,
+                    residual_in_fp32=1, complement=(C.c_int32 * 8)(0, 1, 2, 6, 5, 4, 3, 7))
+        base.update(kw)
+        return engine.PcadConfig(**base)
+    h = C.c_void_p()
+    assert lib.pcad_create(C.byref(cfg()), C.byref(h)) == 0 and h
+    assert lib.pcad_weight_arena_bytes(h) > 0
+    assert lib.pcad_workspace_bytes(h, 4, 512) > 0
+    # unbound handle refuses to run (no device work is attempted)
+    assert lib.pcad_forward(h, None, 1, 8, None, 0, None, None, None, 0, None) == -2
+    assert b"not bound" in lib.pcad_last_error()
+    lib.pcad_destroy(h)
+    for bad in (dict(d_state=8), dict(d_conv=3), dict(vocab=16), dict(d_model=100), dict(dtype=7)):
+        h2 = C.c_void_p()
+        assert lib.pcad_create(C.byref(cfg(**bad)), C.byref(h2)) == -1, bad
+        assert lib.pcad_last_error()
+    assert lib.pcad_create(None, None) == -1
+
+
+def test_config_derived_dims_and_support_check():
+    for name, (D, nl, R) in {"l20": (384, 20, 24), "l24": (512, 24, 32), "l28": (768, 28, 48), "l32": (1024, 32, 64)}.items():
+        c = make_config(name)
+        assert (c.d_model, c.n_layer, c.dt_rank, c.d_inner, c.d_state, c.d_conv) == (D, nl, R, 2 * D, 16, 4)
+        assert c.padded_vocab_size == 8 and c.complement_list() == [0, 1, 2, 6, 5, 4, 3, 7]
+        c.check_supported()
+    with pytest.raises(ValueError):
+        CaduceusConfig(d_model=384, n_layer=2, rcps=False).check_supported()
+    c2 = CaduceusConfig.from_dict(make_config("l20").to_dict())      # json round trip (string keys)
+    assert c2.complement_map[3] == 6
+
+
+def test_checkpoint_roundtrip_reference_key_names(tmp_path):
+    cfg, sd = make_synthetic_checkpoint(str(tmp_path / "m"), "x", seed=5, d_model=64, n_layer=2)
+    back = load_state_dict(str(tmp_path / "m"))
+    assert "caduceus.backbone.layers.1.mixer.submodule.mamba_rev.x_proj.weight" in back
+    assert "caduceus.backbone.layers.0.mixer.submodule.mamba_rev.in_proj.weight" in back     # tied key restored
+    assert "lm_head.lm_head.weight" in back
+    for k, v in sd.items():
+        assert torch.equal(back[k], v), k
+    assert tuple(back["caduceus.backbone.layers.0.mixer.submodule.mamba_fwd.conv1d.weight"].shape) == (128, 1, 4)
+
+
+def test_hf_surface_loads_and_refuses_cpu(tmp_path):
+    import plantcaduceus_amd
+    from transformers import AutoConfig, AutoModel, AutoModelForMaskedLM
+    plantcaduceus_amd.register()
+    d = str(tmp_path / "m")
+    cfg, sd = make_synthetic_checkpoint(d, "x", seed=5, d_model=64, n_layer=2)
+    assert AutoConfig.from_pretrained(d).model_type == "caduceus"
+    m = AutoModelForMaskedLM.from_pretrained(d, trust_remote_code=True, torch_dtype=torch.bfloat16)
+    assert type(m).__name__ == "CaduceusForMaskedLM"
+    got = m.state_dict()
+    assert set(got) == set(sd), set(got) ^ set(sd)
+    assert got["caduceus.backbone.norm_f.weight"].dtype == torch.bfloat16
+    assert m.lm_head.lm_head.weight is m.caduceus.backbone.embeddings.word_embeddings.embedding.weight
+    b = AutoModel.from_pretrained(d, trust_remote_code=True)
+    assert type(b).__name__ == "Caduceus"
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m(input_ids=torch.zeros(1, 8, dtype=torch.long))
+    from plantcaduceus_amd.tokenization_caduceus import CaduceusTokenizer
+    t = CaduceusTokenizer.from_pretrained(d)
+    assert t.get_vocab()["t"] == 6 and t.mask_token_id == 1
+
+
+def test_engine_requires_gpu_and_library():
+    cfg = make_config("x", d_model=64, n_layer=1)
+    with pytest.raises(RuntimeError, match="ROCm device"):
+        engine.Engine(cfg, synthetic_state_dict(cfg), torch.float32, torch.device("cpu"))

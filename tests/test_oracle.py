@@ -1,0 +1,112 @@
+"""CPU: pins the oracle (torch restatement + C port) against the committed golden vectors and the
+weight-free structural invariants (SURVEY.md §4 iii, §8c).  No GPU, no /root/reference at run time."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import caduceus_oracle as O
+from oracle.gen_golden import mixer_param_arrays
+from plantcaduceus_amd.checkpoint import make_config, synthetic_state_dict
+
+
+def _mamba_params(D, seed):
+    p = mixer_param_arrays(D, seed)
+    t = {k: torch.from_numpy(v) for k, v in p.items()}
+    E = 2 * D
+    return O.MambaParams(in_proj=t["in_proj"], conv_w=t["conv_w"].reshape(E, 4), conv_b=t["conv_b"], x_proj=t["x_proj"],
+                         dt_proj_w=t["dt_w"], dt_proj_b=t["dt_b"], A_log=t["A_log"], D=t["D"], out_proj=t["out_proj"])
+
+
+@pytest.mark.parametrize("D", [32, 384])
+def test_mixer_matches_transformers_golden(golden_dir, D):
+    """oracle mamba_forward == transformers' independently written MambaMixer (fixture: oracle/gen_golden.py)."""
+    g = np.load(os.path.join(golden_dir, f"mixer_D{D}.npz"))
+    y = O.mamba_forward(torch.from_numpy(g["x"]), _mamba_params(D, int(g["seed"])))
+    ref = torch.from_numpy(g["y"])
+    assert ((y - ref).abs().max() / ref.abs().max()).item() < 1e-5
+
+
+def _tiny(seed=5, D=32, nl=3):
+    cfg = make_config("x", d_model=D, n_layer=nl)
+    sd = synthetic_state_dict(cfg, seed=seed)
+    return cfg, sd, O.params_from_state_dict(sd, cfg)
+
+
+def test_literal_rcps_equals_strand_form():
+    cfg, sd, P = _tiny()
+    ids = torch.from_numpy(np.random.default_rng(1).integers(0, 7, size=(3, 24)))
+    a = O.forward_literal(ids, P)
+    b = O.forward_strands(ids, P)
+    assert (a["logits"] - b["logits"]).abs().max().item() < 1e-5 * a["logits"].abs().max().item()
+    assert (a["hidden"] - b["hidden"]).abs().max().item() < 1e-5 * a["hidden"].abs().max().item()
+    c = O.forward_strands(ids, P, tie_fold=True)
+    assert (a["logits"] - c["logits"]).abs().max().item() < 1e-4 * a["logits"].abs().max().item()
+
+
+def test_reverse_complement_equivariance():
+    cfg, sd, P = _tiny(seed=8)
+    ids = torch.from_numpy(np.random.default_rng(2).integers(1, 7, size=(2, 20)))
+    comp = torch.tensor(cfg.complement_list())
+    rc = comp[ids.flip(-1)]
+    a, b = O.forward_literal(ids, P), O.forward_literal(rc, P)
+    tol = 1e-5 * a["logits"].abs().max().item()
+    assert (b["logits"].flip(1)[:, :, comp] - a["logits"]).abs().max().item() < tol
+    assert (b["hidden"].flip(1, 2) - a["hidden"]).abs().max().item() < 1e-5 * a["hidden"].abs().max().item()
+    # the XGBoost embedding is RC-invariant (up to the sequence flip), yet the halves differ
+    ea, eb = O.averaged_embedding(a["hidden"], 7), O.averaged_embedding(b["hidden"], 20 - 1 - 7)
+    assert (ea - eb).abs().max().item() < 1e-5 * ea.abs().max().item()
+    D = cfg.d_model
+    assert (a["hidden"][..., :D] - a["hidden"][..., D:].flip(-1)).abs().max().item() > 1e-2
+
+
+def test_direction_swap_symmetry():
+    """swapping mamba_fwd <-> mamba_rev parameters and flipping the input flips the output (BiMamba 'add')."""
+    cfg, sd, P = _tiny(seed=9, nl=1)
+    lp = P.layers[0]
+    x = torch.from_numpy(np.random.default_rng(3).standard_normal((2, 16, cfg.d_model)).astype(np.float32))
+    y = O.bimamba(x, lp, O._ident)
+    swapped = O.LayerParams(norm_w=lp.norm_w, fwd=lp.rev, rev=lp.fwd)
+    y2 = O.bimamba(x.flip(1), swapped, O._ident).flip(1)
+    assert (y - y2).abs().max().item() < 1e-5 * y.abs().max().item()
+
+
+def test_model_tiny_golden_and_c_port(golden_dir):
+    g = np.load(os.path.join(golden_dir, "model_tiny.npz"))
+    cfg = make_config("x", d_model=int(g["d_model"]), n_layer=int(g["n_layer"]))
+    sd = synthetic_state_dict(cfg, seed=int(g["seed"]))
+    ids = torch.from_numpy(g["ids"])
+    out = O.forward_strands(ids, O.params_from_state_dict(sd, cfg))
+    scale = np.abs(g["logits"]).max()
+    assert np.abs(out["logits"].numpy() - g["logits"]).max() / scale < 1e-5
+    assert np.abs(out["hidden"].numpy() - g["hidden"]).max() / np.abs(g["hidden"]).max() < 1e-5
+    from oracle.c_oracle import COracle
+    lg, hid = COracle(sd, cfg).forward(g["ids"], want_hidden=True)
+    assert np.abs(lg - g["logits"]).max() / scale < 1e-5
+    assert np.abs(hid - g["hidden"]).max() / np.abs(g["hidden"]).max() < 1e-5
+
+
+def test_c_port_matches_torch_oracle_wider():
+    cfg = make_config("x", d_model=128, n_layer=2)
+    sd = synthetic_state_dict(cfg, seed=3)
+    ids = np.random.default_rng(4).integers(3, 7, size=(3, 40)).astype(np.int64)
+    ids[:, 20] = 1
+    ref = O.forward_strands(torch.from_numpy(ids), O.params_from_state_dict(sd, cfg))
+    from oracle.c_oracle import COracle
+    lg, hid = COracle(sd, cfg).forward(ids, want_hidden=True)
+    assert np.abs(lg - ref["logits"].numpy()).max() / np.abs(lg).max() < 1e-5
+    assert np.abs(hid - ref["hidden"].numpy()).max() / np.abs(hid).max() < 1e-5
+
+
+def test_bf16_emulation_rounds_at_tensor_boundaries():
+    cfg, sd, _ = _tiny(seed=4)
+    P = O.params_from_state_dict(sd, cfg, dtype=torch.bfloat16)
+    ids = torch.from_numpy(np.random.default_rng(6).integers(3, 7, size=(2, 16)))
+    out = O.forward_strands(ids, P, rnd=O.round_bf16)
+    h = out["hidden"]
+    assert torch.equal(h, h.bfloat16().float())          # hidden is bf16-representable
+    ref = O.forward_strands(ids, O.params_from_state_dict(sd, cfg))
+    err = (out["logits"] - ref["logits"]).abs().max() / ref["logits"].abs().max()
+    assert 1e-5 < err.item() < 0.1                       # differs from fp32 by bf16-sized noise, not more
