@@ -114,8 +114,8 @@ int    pcad_forward_all_hidden(pcad_handle h, const int32_t* ids, int B, int L,
 
 /* ---- measurement: per-kernel-class timing with HIP events on the caller's stream -------------------- */
 enum pcad_kernel_class {
-    PCAD_K_NORM = 0, PCAD_K_GEMM_IN, PCAD_K_CONV, PCAD_K_GEMM_X, PCAD_K_GEMM_DT, PCAD_K_SCAN,
-    PCAD_K_GEMM_OUT, PCAD_K_HEAD, PCAD_NUM_KERNEL_CLASSES
+    PCAD_K_NORM = 0, PCAD_K_GEMM_IN, PCAD_K_CONV, PCAD_K_GEMM_X, PCAD_K_SCAN, PCAD_K_GEMM_OUT, PCAD_K_HEAD,
+    PCAD_NUM_KERNEL_CLASSES
 };
 typedef struct pcad_kernel_stat {
     char    name[32];
@@ -146,15 +146,23 @@ int pcad_causal_conv1d_silu(const void* x, int64_t ldx, const float* w_fwd, cons
                             int S, int L, int E, int dtype, pcad_stream stream);
 
 /* selective_scan_fn(u, delta, A, B, C, D, z, delta_bias, delta_softplus=True), token-major:
- *   u, delta [S, L, E] dtype; z [S, L, ldz>=E] dtype or NULL; Bm, Cm dtype rows of stride ldbc ([S*L, ldbc], 16 used);
+ *   u, delta [S, L, E] dtype; z [S, L, ldz>=E] dtype or NULL; bc fp32 [S*L, 32] = B_t (16) | C_t (16) per token;
  *   A fp32 [E, 16] (negative real, NOT pre-scaled); Dskip, delta_bias fp32 [E];
  *   reverse != 0 walks t = L-1..0;  accumulate != 0 adds into y (bi-directional "add" strategy).
  *   y [S, L, E] dtype. */
-int pcad_selective_scan(const void* u, const void* delta, const void* z, int64_t ldz,
-                        const void* Bm, const void* Cm, int64_t ldbc,
+int pcad_selective_scan(const void* u, const void* delta, const void* z, int64_t ldz, const float* bc,
                         const float* A, const float* Dskip, const float* delta_bias,
                         void* y, int S, int L, int E, int reverse, int accumulate,
                         int dtype, pcad_stream stream);
+
+/* The form the engine runs — mamba_inner_fn's `delta = dt_proj.weight @ x_dbl[:, :R]` fused into the scan:
+ *   delta[t, c] = round_dtype(sum_k dt_low[t, k] * Wdt[c, k]) computed on MFMA inside the kernel (never stored);
+ *   dt_low [S*L, lddt>=Rp] dtype and Wdt [E, Rp] dtype, Rp % 64 == 0 with K zero-padded past dt_rank. */
+int pcad_selective_scan_dtproj(const void* u, const void* dt_low, int64_t lddt, const void* Wdt, int Rp,
+                               const void* z, int64_t ldz, const float* bc,
+                               const float* A, const float* Dskip, const float* delta_bias,
+                               void* y, int S, int L, int E, int reverse, int accumulate,
+                               int dtype, pcad_stream stream);
 
 /* F.linear(a, w): C[M,N] = A[M,K] . W[N,K]^T on MFMA.  lda/ldw/ldc in elements; K % (128/sizeof(elem)) == 0,
  * lda, ldw multiples of 16 bytes.  out_dtype: PCAD_F32 or `dtype`. */

@@ -115,7 +115,8 @@ void carve_weights(pcad_engine* e, Carver& c) {
 }
 
 struct Workspace {
-    void *res, *u, *h, *xz, *xc[2], *dbl[2], *delta, *y;
+    void *res, *u, *h, *xz, *xc[2], *dtl[2], *y;
+    float* bc[2];
     size_t bytes;
 };
 
@@ -130,17 +131,17 @@ Workspace carve_workspace(const pcad_engine* e, void* base, int Bc, int L) {
     w.xz = c.take(rows * 2 * E * esz);
     w.xc[0] = c.take(rows * E * esz);
     w.xc[1] = c.take(rows * E * esz);
-    w.dbl[0] = c.take(rows * e->XP * esz);
-    w.dbl[1] = c.take(rows * e->XP * esz);
-    w.delta = c.take(rows * E * esz);
+    w.dtl[0] = c.take(rows * e->Rp * esz);     // dt_low (x_proj columns [0, Rp), zero padded past R)
+    w.dtl[1] = c.take(rows * e->Rp * esz);
+    w.bc[0] = (float*)c.take(rows * 2 * e->N * 4);   // B_t | C_t rows, fp32 (values rounded to the model dtype)
+    w.bc[1] = (float*)c.take(rows * 2 * e->N * 4);
     w.y = c.take(rows * E * esz);
     w.bytes = c.off;
     return w;
 }
 
 const char* const kClassNames[PCAD_NUM_KERNEL_CLASSES] = {
-    "add_rmsnorm", "gemm_in_proj", "conv1d_bidir", "gemm_x_proj", "gemm_dt_proj", "selective_scan",
-    "gemm_out_proj", "final_head"};
+    "add_rmsnorm", "gemm_in_proj", "conv1d_bidir", "gemm_x_proj", "selective_scan", "gemm_out_proj", "final_head"};
 
 hipEvent_t prof_event(pcad_engine* e) {
     if (!e->prof_pool.empty()) {
@@ -369,17 +370,13 @@ static int forward_impl(pcad_handle h, const int32_t* ids, int B, int L, const i
                                       w.xc[0], w.xc[1], S, L, E, dt, s)); }
             for (int d = 0; d < 2; ++d) {
                 const DirWeights& dw = W.dir[d];
-                // x_proj -> [dt_low (Rp, zero padded) | B | C]
+                // x_proj -> dt_low [rows, Rp] (model dtype, zero padded) and B_t | C_t [rows, 32] (fp32 side output)
                 { ProfScope ps(e, PCAD_K_GEMM_X, s);
-                HIP_TRY(launch_gemm_nt(w.xc[d], E, dw.Wx, E, w.dbl[d], XP, rows, XP, E, dt, dt, false, s)); }
-                // dt_proj (bias + softplus are applied inside the scan)
-                { ProfScope ps(e, PCAD_K_GEMM_DT, s);
-                HIP_TRY(launch_gemm_nt(w.dbl[d], XP, dw.Wdt, Rp, w.delta, E, rows, E, Rp, dt, dt, false, s)); }
-                const char* bc = (const char*)w.dbl[d];
+                HIP_TRY(launch_gemm_nt_split(w.xc[d], E, dw.Wx, E, w.dtl[d], Rp, w.bc[d], 2 * N, Rp, rows, XP, E, dt, s)); }
+                // dt_proj (on MFMA inside the scan) + bias + softplus + recurrence + D skip + SiLU(z) gate
                 ProfScope ps(e, PCAD_K_SCAN, s);
-                HIP_TRY(launch_scan(w.xc[d], w.delta, (const char*)w.xz + (size_t)E * esz, 2 * E, bc + (size_t)Rp * esz,
-                                    bc + (size_t)(Rp + N) * esz, XP, dw.A2, 1.0f, dw.Dskip, dw.dt_bias, w.y, S, L, E, d == 1,
-                                    d == 1, dt, s));
+                HIP_TRY(launch_scan(w.xc[d], (const char*)w.xz + (size_t)E * esz, 2 * E, nullptr, w.dtl[d], Rp, dw.Wdt, Rp,
+                                    w.bc[d], dw.A2, 1.0f, dw.Dskip, dw.dt_bias, w.y, S, L, E, d == 1, d == 1, dt, s));
             }
             // out_proj on (y_fwd + y_rev): the two tied out_proj calls folded by linearity
             { ProfScope ps(e, PCAD_K_GEMM_OUT, s);
@@ -463,18 +460,38 @@ int pcad_causal_conv1d_silu(const void* x, int64_t ldx, const float* w_fwd, cons
     return PCAD_OK;
 }
 
-int pcad_selective_scan(const void* u, const void* delta, const void* z, int64_t ldz, const void* Bm, const void* Cm,
-                        int64_t ldbc, const float* A, const float* Dskip, const float* delta_bias, void* y, int S, int L,
-                        int E, int reverse, int accumulate, int dtype, pcad_stream stream) {
-    if (!u || !delta || !Bm || !Cm || !A || !Dskip || !delta_bias || !y)
-        return fail(PCAD_ERR_INVALID, "pcad_selective_scan: null argument");
+static int scan_args_ok(const void* u, const float* bc, const float* A, const float* Dskip, const float* delta_bias,
+                        void* y, int S, int L, int E) {
+    if (!u || !bc || !A || !Dskip || !delta_bias || !y) return fail(PCAD_ERR_INVALID, "pcad_selective_scan: null argument");
     if (S < 0 || L < 0 || E <= 0 || E % 64) return fail(PCAD_ERR_INVALID, "pcad_selective_scan: E must be a multiple of 64");
-    if (ldbc % 2 || ((uintptr_t)Bm) % 4 || ((uintptr_t)Cm) % 4)
-        return fail(PCAD_ERR_INVALID, "pcad_selective_scan: B/C rows must be 4-byte aligned");
+    if (((uintptr_t)bc) % 16) return fail(PCAD_ERR_INVALID, "pcad_selective_scan: bc must be 16-byte aligned");
+    return PCAD_OK;
+}
+
+int pcad_selective_scan(const void* u, const void* delta, const void* z, int64_t ldz, const float* bc, const float* A,
+                        const float* Dskip, const float* delta_bias, void* y, int S, int L, int E, int reverse,
+                        int accumulate, int dtype, pcad_stream stream) {
+    if (!delta) return fail(PCAD_ERR_INVALID, "pcad_selective_scan: null delta");
+    if (int rc = scan_args_ok(u, bc, A, Dskip, delta_bias, y, S, L, E)) return rc;
     if (S == 0 || L == 0) return PCAD_OK;
     // raw A is scaled by log2(e) when the kernel loads it into registers (the engine passes pre-scaled A)
-    HIP_TRY(launch_scan(u, delta, z, ldz, Bm, Cm, ldbc, A, 1.4426950408889634f, Dskip, delta_bias, y, S, L, E,
-                        reverse != 0, accumulate != 0, dtype, (hipStream_t)stream));
+    HIP_TRY(launch_scan(u, z, ldz, delta, nullptr, 0, nullptr, 0, bc, A, 1.4426950408889634f, Dskip, delta_bias, y, S, L,
+                        E, reverse != 0, accumulate != 0, dtype, (hipStream_t)stream));
+    return PCAD_OK;
+}
+
+int pcad_selective_scan_dtproj(const void* u, const void* dt_low, int64_t lddt, const void* Wdt, int Rp, const void* z,
+                               int64_t ldz, const float* bc, const float* A, const float* Dskip,
+                               const float* delta_bias, void* y, int S, int L, int E, int reverse, int accumulate,
+                               int dtype, pcad_stream stream) {
+    if (!dt_low || !Wdt) return fail(PCAD_ERR_INVALID, "pcad_selective_scan_dtproj: null dt_low / Wdt");
+    if (Rp <= 0 || Rp % 64 || lddt < Rp || ((uintptr_t)dt_low) % 16 || ((uintptr_t)Wdt) % 16 ||
+        (lddt * (dtype == PCAD_BF16 ? 2 : 4)) % 16)
+        return fail(PCAD_ERR_INVALID, "pcad_selective_scan_dtproj: Rp must be a multiple of 64 (zero padded), rows 16-byte aligned");
+    if (int rc = scan_args_ok(u, bc, A, Dskip, delta_bias, y, S, L, E)) return rc;
+    if (S == 0 || L == 0) return PCAD_OK;
+    HIP_TRY(launch_scan(u, z, ldz, nullptr, dt_low, lddt, Wdt, Rp, bc, A, 1.4426950408889634f, Dskip, delta_bias, y, S, L,
+                        E, reverse != 0, accumulate != 0, dtype, (hipStream_t)stream));
     return PCAD_OK;
 }
 

@@ -30,11 +30,13 @@ __device__ __forceinline__ float round_to_bf16(float f) { return bf16_to_f32(f32
 template <typename T> struct Elem;
 template <> struct Elem<float> {
     static __device__ __forceinline__ float load(const float* p) { return *p; }
+    static __device__ __forceinline__ float to_f32(float v) { return v; }
     static __device__ __forceinline__ void store(float* p, float v) { *p = v; }
     static __device__ __forceinline__ float round(float v) { return v; }
 };
 template <> struct Elem<bf16_t> {
     static __device__ __forceinline__ float load(const bf16_t* p) { return bf16_to_f32(*p); }
+    static __device__ __forceinline__ float to_f32(bf16_t v) { return bf16_to_f32(v); }
     static __device__ __forceinline__ void store(bf16_t* p, float v) { *p = f32_to_bf16(v); }
     static __device__ __forceinline__ float round(float v) { return round_to_bf16(v); }
 };

@@ -54,11 +54,12 @@ __device__ __forceinline__ void glds16(const char* gsrc, char* lds_wave_base) {
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
-template <typename T, typename OutT, bool ROUND, bool VEC>
+template <typename T, typename OutT, bool ROUND, bool VEC, bool SPLIT>
 __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const T* __restrict__ A, int64_t lda,
                                                          const T* __restrict__ W, int64_t ldw,
                                                          OutT* __restrict__ C, int64_t ldc, int64_t M, int N, int K,
-                                                         int tiles_m, int tiles_n) {
+                                                         int tiles_m, int tiles_n, float* __restrict__ C2,
+                                                         int64_t ldc2, int nsplit) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -165,8 +166,23 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const T* __restrict__ A
                 if constexpr (ROUND) v = round_to_bf16(v);
                 o[j * 4 + rr] = v;
             }
+        if constexpr (SPLIT) {
+            if (nb >= nsplit) {   // fp32 side output (x_proj: B_t | C_t rows for the scan's scalar loads)
+                if (nb + 16 <= N) {
+                    float* d2 = C2 + m * ldc2 + (nb - nsplit);
+#pragma unroll
+                    for (int e = 0; e < 16; e += 4) {
+                        f32x4 v = {Elem<T>::round(o[e]), Elem<T>::round(o[e + 1]), Elem<T>::round(o[e + 2]),
+                                   Elem<T>::round(o[e + 3])};
+                        *reinterpret_cast<f32x4*>(d2 + e) = v;
+                    }
+                }
+                continue;
+            }
+        }
         OutT* dst = C + m * ldc + nb;
-        if (VEC && nb + 16 <= N) {
+        const int Nmain = SPLIT ? nsplit : N;
+        if (VEC && nb + 16 <= Nmain) {
             float lo[8], hi[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) { lo[e] = o[e]; hi[e] = o[8 + e]; }
@@ -175,7 +191,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const T* __restrict__ A
         } else {
 #pragma unroll
             for (int e = 0; e < 16; ++e)
-                if (nb + e < N) Elem<OutT>::store(dst + e, o[e]);
+                if (nb + e < Nmain) Elem<OutT>::store(dst + e, o[e]);
         }
     }
 }
@@ -188,23 +204,50 @@ static hipError_t launch_gemm_t(const void* A, int64_t lda, const void* W, int64
     dim3 grid((unsigned)(tiles_m * tiles_n)), block(256);
     static bool attr_done_v = false, attr_done_s = false;
     if (vec) {
-        auto kfn = gemm_nt_kernel<T, OutT, ROUND, true>;
+        auto kfn = gemm_nt_kernel<T, OutT, ROUND, true, false>;
         if (!attr_done_v) {
             (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
             attr_done_v = true;
         }
         hipLaunchKernelGGL(kfn, grid, block, GEMM_LDS, s, (const T*)A, lda, (const T*)W, ldw, (OutT*)C, ldc, M, N, K,
-                           tiles_m, tiles_n);
+                           tiles_m, tiles_n, (float*)nullptr, (int64_t)0, 0);
     } else {
-        auto kfn = gemm_nt_kernel<T, OutT, ROUND, false>;
+        auto kfn = gemm_nt_kernel<T, OutT, ROUND, false, false>;
         if (!attr_done_s) {
             (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
             attr_done_s = true;
         }
         hipLaunchKernelGGL(kfn, grid, block, GEMM_LDS, s, (const T*)A, lda, (const T*)W, ldw, (OutT*)C, ldc, M, N, K,
-                           tiles_m, tiles_n);
+                           tiles_m, tiles_n, (float*)nullptr, (int64_t)0, 0);
     }
     return hipGetLastError();
+}
+
+template <typename T>
+static hipError_t launch_gemm_split_t(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc,
+                                      float* C2, int64_t ldc2, int nsplit, int64_t M, int N, int K, hipStream_t s) {
+    const int tiles_m = (int)((M + BM - 1) / BM), tiles_n = (N + BN - 1) / BN;
+    dim3 grid((unsigned)(tiles_m * tiles_n)), block(256);
+    auto kfn = gemm_nt_kernel<T, T, false, true, true>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(kfn, grid, block, GEMM_LDS, s, (const T*)A, lda, (const T*)W, ldw, (T*)C, ldc, M, N, K, tiles_m,
+                       tiles_n, C2, ldc2, nsplit);
+    return hipGetLastError();
+}
+
+hipError_t launch_gemm_nt_split(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc, float* C2,
+                                int64_t ldc2, int nsplit, int64_t M, int N, int K, int dt, hipStream_t s) {
+    if (M <= 0 || N <= 0) return hipSuccess;
+    const int esz = dt == BF16 ? 2 : 4;
+    if (K <= 0 || (K * esz) % ROWB || nsplit % 16 || (N - nsplit) % 16) return hipErrorInvalidValue;
+    if ((lda * esz) % 16 || (ldw * esz) % 16 || ((uintptr_t)A) % 16 || ((uintptr_t)W) % 16) return hipErrorInvalidValue;
+    if ((ldc * esz) % 16 || ((uintptr_t)C) % 16 || (ldc2 * 4) % 16 || ((uintptr_t)C2) % 16) return hipErrorInvalidValue;
+    if (dt == BF16) return launch_gemm_split_t<bf16_t>(A, lda, W, ldw, C, ldc, C2, ldc2, nsplit, M, N, K, s);
+    return launch_gemm_split_t<float>(A, lda, W, ldw, C, ldc, C2, ldc2, nsplit, M, N, K, s);
 }
 
 hipError_t launch_gemm_nt(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc, int64_t M,

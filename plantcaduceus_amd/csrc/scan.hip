@@ -1,125 +1,232 @@
-// Selective-scan recurrence (Mamba-v1 S6), token-major, one direction per launch.
+// Selective-scan recurrence (Mamba-v1 S6) with the dt_proj contraction fused in, token-major, one
+// direction per launch.
 //
-// Replaces selective_scan_cuda.fwd behind mamba_ssm's selective_scan_fn / mamba_inner_fn
-// (mamba-ssm 2.2.2):
-//     delta = softplus(delta + delta_bias)
+// Replaces selective_scan_cuda.fwd behind mamba_ssm's selective_scan_fn / mamba_inner_fn and the
+// `delta = dt_proj.weight @ x_dbl[:, :R]` GEMM in front of it (mamba-ssm 2.2.2):
+//     delta = softplus(round(dt_low . Wdt^T) + delta_bias)
 //     h_t   = exp(delta_t * A) (.) h_{t-1} + delta_t * B_t * u_t          (A in R^{E x 16}, B_t, C_t in R^16)
 //     y_t   = <h_t, C_t> + D * u_t ;   out_t = y_t * silu(z_t)
 // The reference maps one CUDA block to a (batch, channel) pair and scans along time with a block scan.
 // With 2B*E independent (strand, channel) recurrences per layer there is no need to parallelise time on
 // MI355X: a wave owns 64 consecutive channels of one strand, lane = channel, the 16 states live in VGPRs
-// and time is walked sequentially with zero cross-lane traffic.  u/delta/z rows are 128/256-byte
-// coalesced reads of the token-major tensors, software-prefetched one 8-step chunk ahead; B_t / C_t are
-// wave-uniform and come in through the scalar unit (s_load -> SGPR operands of the VALU ops).
-// The reverse direction walks t = L-1..0 on the same rows (no flipped copy); `accumulate` adds the
-// forward direction's output (BiMambaWrapper strategy "add", tied out_proj folded by linearity).
-// The kernel is VALU/transcendental bound: 16 v_exp_f32 + ~64 fp32 ops per (t, channel).
+// as 8 packed pairs (v_pk_mul/v_pk_fma_f32) and time is walked sequentially with zero cross-lane traffic.
+//
+//   * delta never exists in HBM: per 32-timestep block the wave computes its [32 t x 64 ch] tile on the
+//     matrix cores (2 x v_mfma_f32_32x32x16_bf16 per 16 of K; fp32 model: v_mfma_f32_32x32x2_f32), 16
+//     v_permlane32_swap move every lane's own channel into place, softplus is applied once and the 32 values
+//     are parked in a wave-private LDS slab (used as dynamically indexed spill space, lane-linear, no barrier).
+//   * B_t / C_t (shared by all channels) are fp32 rows written by the x_proj GEMM epilogue; the address is
+//     wave-uniform so they arrive through the scalar unit (s_load_dwordx16) as SGPR operands of the VALU ops.
+//   * u / z (/ y of the other direction) are 128-byte coalesced row reads, prefetched one 4-step chunk ahead.
+//   * The reverse direction walks t = L-1..0 on the same rows (no flipped copy); `accumulate` adds the forward
+//     direction's output (BiMambaWrapper strategy "add", tied out_proj folded by linearity).
+// VALU/transcendental bound (measured on gfx950: v_exp_f32 8.5, v_fma_f32 3.7, v_pk_fma_f32 5.2 cycles per
+// wave-instruction at 4 waves/SIMD, not overlapping): ~19 cycles per (t, channel, state).
 #include "common.hpp"
 #include "kernels.hpp"
 
 namespace pcad {
 
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+
 constexpr int NSTATE = 16;
-constexpr int CH = 8;   // timesteps per prefetch chunk
+constexpr int TB = 32;    // timesteps per delta tile
+constexpr int CH = 4;     // timesteps per prefetch chunk
 
-// 16 wave-uniform B_t / C_t values.  The address is uniform, so these become s_load_dwordx{8,16} and the
-// bf16 unpack runs on the scalar ALU; the values are then SGPR operands of the VALU recurrence.
-template <typename T> __device__ __forceinline__ void load_state16(const T* __restrict__ p, float (&o)[NSTATE]);
-template <> __device__ __forceinline__ void load_state16<float>(const float* __restrict__ p, float (&o)[NSTATE]) {
-#pragma unroll
-    for (int n = 0; n < NSTATE; ++n) o[n] = p[n];
-}
-template <> __device__ __forceinline__ void load_state16<bf16_t>(const bf16_t* __restrict__ p, float (&o)[NSTATE]) {
-    const uint32_t* __restrict__ q = reinterpret_cast<const uint32_t*>(p);
-#pragma unroll
-    for (int k = 0; k < NSTATE / 2; ++k) {
-        const uint32_t w = q[k];
-        o[2 * k] = __uint_as_float(w << 16);
-        o[2 * k + 1] = __uint_as_float(w & 0xffff0000u);
+__device__ __forceinline__ float exp2_hw(float x) { return __builtin_amdgcn_exp2f(x); }
+
+// ---- delta tile: acc[half][r] <- sum_k dtl[t0 + tt][k] * Wdt[c][k],  tt = (r&3) + 8*(r>>2) + 4*half ------
+// After the MFMAs lane l holds column (l & 31) of channel tile q (channels 32q..32q+31) for the rows
+// 4*(l>>5) + {0..3, 8..11, 16..19, 24..27}; swapping the upper half of tile 0 with the lower half of tile 1
+// (v_permlane32_swap) leaves every lane with its own channel: acc0 = rows {0-3,8-11,..}, acc1 = rows {4-7,..}.
+template <typename T> struct DeltaTile;
+
+template <> struct DeltaTile<bf16_t> {
+    static __device__ __forceinline__ void run(const bf16_t* __restrict__ dtl, int64_t lddt, int64_t row_base, int t0,
+                                               int L, const bf16_t* __restrict__ Wdt, int c0, int Rp, int lane,
+                                               f32x16& acc0, f32x16& acc1) {
+        const int tr = max(0, min(t0 + (lane & 31), L - 1));
+        const bf16_t* arow = dtl + (row_base + tr) * lddt + (lane >> 5) * 8;
+        const bf16_t* b0 = Wdt + (int64_t)(c0 + (lane & 31)) * Rp + (lane >> 5) * 8;
+        const bf16_t* b1 = b0 + (int64_t)32 * Rp;
+#pragma unroll 4
+        for (int k = 0; k < Rp; k += 16) {
+            const u32x4 a = *reinterpret_cast<const u32x4*>(arow + k);
+            const u32x4 w0 = *reinterpret_cast<const u32x4*>(b0 + k);
+            const u32x4 w1 = *reinterpret_cast<const u32x4*>(b1 + k);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a),
+                                                           __builtin_bit_cast(bf16x8_t, w0), acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a),
+                                                           __builtin_bit_cast(bf16x8_t, w1), acc1, 0, 0, 0);
+        }
     }
-}
+};
 
-template <typename T, bool REV, bool ACC, bool HASZ>
-__global__ __launch_bounds__(64) void scan_kernel(const T* __restrict__ u, const T* __restrict__ delta,
-                                                  const T* __restrict__ z, int64_t ldz,
-                                                  const T* __restrict__ Bm, const T* __restrict__ Cm,
-                                                  int64_t ldbc, const float* __restrict__ A2, float a_scale,
+template <> struct DeltaTile<float> {
+    // exact fp32 on v_mfma_f32_32x32x2_f32; lane half kh = l>>5 owns k in [kh*Rp/2, (kh+1)*Rp/2) (same
+    // permutation of k on both operands, so the contraction is unchanged).
+    static __device__ __forceinline__ void run(const float* __restrict__ dtl, int64_t lddt, int64_t row_base, int t0,
+                                               int L, const float* __restrict__ Wdt, int c0, int Rp, int lane,
+                                               f32x16& acc0, f32x16& acc1) {
+        const int tr = max(0, min(t0 + (lane & 31), L - 1));
+        const int kh = (lane >> 5) * (Rp >> 1);
+        const float* arow = dtl + (row_base + tr) * lddt + kh;
+        const float* b0 = Wdt + (int64_t)(c0 + (lane & 31)) * Rp + kh;
+        const float* b1 = b0 + (int64_t)32 * Rp;
+        for (int k = 0; k < (Rp >> 1); k += 4) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(arow + k);
+            const f32x4 w0 = *reinterpret_cast<const f32x4*>(b0 + k);
+            const f32x4 w1 = *reinterpret_cast<const f32x4*>(b1 + k);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], w0[j], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], w1[j], acc1, 0, 0, 0);
+            }
+        }
+    }
+};
+
+// FUSED: delta comes from dt_low . Wdt^T (above);  !FUSED: delta is read from memory like u (operator entry).
+template <typename T, bool REV, bool ACC, bool HASZ, bool FUSED>
+__global__ __launch_bounds__(64, 4) void scan_kernel(const T* __restrict__ u, const T* __restrict__ z, int64_t ldz,
+                                                  const T* __restrict__ dsrc, int64_t ldd,
+                                                  const T* __restrict__ Wdt, int Rp,
+                                                  const float* __restrict__ bc,
+                                                  const float* __restrict__ A2, float a_scale,
                                                   const float* __restrict__ Dskip, const float* __restrict__ dbias,
                                                   const T* yin, T* y, int L, int E) {
-    const int c = blockIdx.x * 64 + threadIdx.x;
-    const int s = blockIdx.y;
-    const int64_t row0 = (int64_t)s * L;
+    __shared__ float dvs[TB][64];
+    const int lane = threadIdx.x;
+    const int c0 = blockIdx.x * 64;
+    const int c = c0 + lane;
+    const int64_t row0 = (int64_t)blockIdx.y * L;
 
-    float a2[NSTATE], h[NSTATE];
+    f2 a2p[NSTATE / 2], hp[NSTATE / 2];
 #pragma unroll
-    for (int n = 0; n < NSTATE; n += 4) {
-        const f32x4 v = *reinterpret_cast<const f32x4*>(A2 + (int64_t)c * NSTATE + n);
-        a2[n] = v[0] * a_scale; a2[n + 1] = v[1] * a_scale; a2[n + 2] = v[2] * a_scale; a2[n + 3] = v[3] * a_scale;
+    for (int p = 0; p < NSTATE / 2; p += 2) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(A2 + (int64_t)c * NSTATE + 2 * p);
+        a2p[p] = f2{v[0] * a_scale, v[1] * a_scale};
+        a2p[p + 1] = f2{v[2] * a_scale, v[3] * a_scale};
     }
 #pragma unroll
-    for (int n = 0; n < NSTATE; ++n) h[n] = 0.f;
+    for (int p = 0; p < NSTATE / 2; ++p) hp[p] = f2{0.f, 0.f};
     const float dsk = Dskip[c];
     const float db = dbias[c];
 
-    const int nchunks = (L + CH - 1) / CH;
-    float ub[CH], dbuf[CH], zb[CH], yb[CH];
-    auto tof = [&](int step) { return REV ? (L - 1 - step) : step; };
-    auto load_chunk = [&](int ci, float (&uu)[CH], float (&dd)[CH], float (&zz)[CH], float (&yy)[CH]) {
+    const int nblk = (L + TB - 1) / TB;
+    // walk order: step s = 0..L-1 visits t = REV ? L-1-s : s.  Block b covers walk steps [b*TB, (b+1)*TB), i.e.
+    // memory rows [tb0, tb0+TB) with tb0 = REV ? L-(b+1)*TB : b*TB (tb0 < 0 / rows >= L are clamped loads whose
+    // delta is never consumed); blocks are aligned in WALK space so the CH-step prefetch chunks never straddle.
+    // Steps past the end of the sequence (last chunk when L % CH != 0) run on clamped rows and only their store
+    // is suppressed, which keeps the chunk body branch-free.
+    // Wave-uniform per-strand bases + 32-bit in-strand offsets (L * ld < 2^31): SGPR base, lane offset in a VGPR.
+    const T* __restrict__ u_s = u + row0 * E + c0;
+    const T* __restrict__ z_s = HASZ ? z + row0 * ldz + c0 : nullptr;
+    const T* __restrict__ d_s = FUSED ? nullptr : dsrc + row0 * ldd + c0;
+    const T* yin_s = ACC ? yin + row0 * E + c0 : nullptr;
+    T* y_s = y + row0 * E + c0;
+    const float* __restrict__ bc_s = bc + row0 * (2 * NSTATE);
+    const uint32_t ldz32 = (uint32_t)ldz, ldd32 = (uint32_t)ldd;
+
+    T ub[CH], zb[CH], yb[CH], dr[CH];      // RAW prefetched values: converted at use, so no early vmcnt wait
+    auto tclamp = [&](int s) { const int sc = min(s, L - 1); return REV ? (L - 1 - sc) : sc; };
+    auto load_chunk = [&](int s0, T (&uu)[CH], T (&zz)[CH], T (&yy)[CH], T (&dd)[CH]) {
 #pragma unroll
         for (int i = 0; i < CH; ++i) {
-            int step = ci * CH + i;
-            if (step > L - 1) step = L - 1;
-            const int64_t r = row0 + tof(step);
-            uu[i] = Elem<T>::load(u + r * E + c);
-            dd[i] = Elem<T>::load(delta + r * E + c);
-            if constexpr (HASZ) zz[i] = Elem<T>::load(z + r * ldz + c);
-            if constexpr (ACC) yy[i] = Elem<T>::load(yin + r * E + c);
+            const uint32_t t = (uint32_t)tclamp(s0 + i);
+            uu[i] = (u_s + t * (uint32_t)E)[lane];
+            if constexpr (HASZ) zz[i] = (z_s + t * ldz32)[lane];
+            if constexpr (ACC) yy[i] = (yin_s + t * (uint32_t)E)[lane];
+            if constexpr (!FUSED) dd[i] = (d_s + t * ldd32)[lane];
         }
     };
-    load_chunk(0, ub, dbuf, zb, yb);
-    for (int ci = 0; ci < nchunks; ++ci) {
-        float un[CH], dn[CH], zn[CH], yn[CH];
-        if (ci + 1 < nchunks) load_chunk(ci + 1, un, dn, zn, yn);
+    load_chunk(0, ub, zb, yb, dr);
+
+    // B_t | C_t of the step being computed (SGPRs), software-pipelined one step ahead of the VALU work
+    f2 bcc[NSTATE];
+    auto load_bc = [&](int s, f2 (&dst)[NSTATE]) {
+        const f2* __restrict__ r = reinterpret_cast<const f2*>(bc_s + (uint32_t)tclamp(s) * (uint32_t)(2 * NSTATE));
 #pragma unroll
-        for (int i = 0; i < CH; ++i) {
-            const int step = ci * CH + i;
-            if (step < L) {
-                const int64_t r = row0 + tof(step);
-                float bv[NSTATE], cv[NSTATE];
-                load_state16<T>(Bm + r * ldbc, bv);
-                load_state16<T>(Cm + r * ldbc, cv);
-                const float dv = softplus(dbuf[i] + db);
-                const float uv = ub[i];
-                const float du = dv * uv;
-                float yv = dsk * uv;
+        for (int p = 0; p < NSTATE; ++p) dst[p] = r[p];
+    };
+    load_bc(0, bcc);
+
+    // one recurrence step on raw inputs (uraw, zraw, yraw, draw) at walk step s
+    auto step = [&](int s, int tb0, T uraw, T zraw, T yraw, T draw) {
+        f2 bcn[NSTATE];
+        load_bc(s + 1, bcn);
+        const uint32_t t = (uint32_t)tclamp(s);
+        float dv;
+        if constexpr (FUSED) dv = dvs[(int)t - tb0][lane];
+        else dv = softplus(Elem<T>::to_f32(draw) + db);
+        const float uv = Elem<T>::to_f32(uraw);
+        const float du = dv * uv;
+        const f2 dv2 = {dv, dv}, du2 = {du, du};
+        f2 yacc = {dsk * uv, 0.f};
 #pragma unroll
-                for (int n = 0; n < NSTATE; ++n) {
-                    const float a = fast_exp2(dv * a2[n]);
-                    h[n] = a * h[n] + du * bv[n];
-                    yv += h[n] * cv[n];
-                }
-                if constexpr (HASZ) yv *= silu(zb[i]);
-                yv = Elem<T>::round(yv);
-                if constexpr (ACC) yv += yb[i];
-                Elem<T>::store(y + r * E + c, yv);
+        for (int p = 0; p < NSTATE / 2; ++p) {
+            const f2 e = dv2 * a2p[p];
+            const f2 a = {exp2_hw(e[0]), exp2_hw(e[1])};
+            hp[p] = a * hp[p] + du2 * bcc[p];
+            yacc = hp[p] * bcc[NSTATE / 2 + p] + yacc;
+        }
+        float yv = yacc[0] + yacc[1];
+        if constexpr (HASZ) yv *= silu(Elem<T>::to_f32(zraw));
+        yv = Elem<T>::round(yv);
+        if constexpr (ACC) yv += Elem<T>::to_f32(yraw);
+        Elem<T>::store(y_s + t * (uint32_t)E + lane, yv);
+#pragma unroll
+        for (int p = 0; p < NSTATE; ++p) bcc[p] = bcn[p];
+    };
+
+    for (int b = 0; b < nblk; ++b) {
+        const int tb0 = REV ? (L - (b + 1) * TB) : b * TB;
+        if constexpr (FUSED) {
+            f32x16 acc0, acc1;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
+            DeltaTile<T>::run(dsrc, ldd, row0, tb0, L, Wdt, c0, Rp, lane, acc0, acc1);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                // lanes 32..63 of acc0[r] <-> lanes 0..31 of acc1[r]
+                const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc0[r]), __float_as_uint(acc1[r]),
+                                                                 false, false);
+                const float v0 = __uint_as_float(sw[0]), v1 = __uint_as_float(sw[1]);
+                const int tt = (r & 3) + 8 * (r >> 2);
+                dvs[tt][lane] = softplus(Elem<T>::round(v0) + db);
+                dvs[tt + 4][lane] = softplus(Elem<T>::round(v1) + db);
             }
         }
-        if (ci + 1 < nchunks) {
+        const int s_begin = b * TB;                                      // first walk step of the block
+        const int s_end = min(L, s_begin + TB);                          // one past the last
+        int s0 = s_begin;
+        for (; s0 + CH <= s_end; s0 += CH) {                             // full chunks: straight-line body
+            T un[CH], zn[CH], yn[CH], dn[CH];
+            load_chunk(s0 + CH, un, zn, yn, dn);
 #pragma unroll
-            for (int i = 0; i < CH; ++i) { ub[i] = un[i]; dbuf[i] = dn[i]; zb[i] = zn[i]; yb[i] = yn[i]; }
+            for (int i = 0; i < CH; ++i) step(s0 + i, tb0, ub[i], zb[i], yb[i], dr[i]);
+#pragma unroll
+            for (int i = 0; i < CH; ++i) { ub[i] = un[i]; zb[i] = zn[i]; yb[i] = yn[i]; dr[i] = dn[i]; }
+        }
+        if (s0 < s_end) {                                                // tail (< CH steps, end of the sequence)
+#pragma unroll
+            for (int i = 0; i < CH - 1; ++i)
+                if (s0 + i < s_end) step(s0 + i, tb0, ub[i], zb[i], yb[i], dr[i]);
         }
     }
 }
 
-template <typename T>
-static hipError_t launch_scan_t(const void* u, const void* delta, const void* z, int64_t ldz, const void* Bm,
-                                const void* Cm, int64_t ldbc, const float* A2, float a_scale, const float* Dskip,
-                                const float* dbias, void* y, int S, int L, int E, bool reverse, bool accumulate,
-                                hipStream_t s) {
+template <typename T, bool FUSED>
+static hipError_t launch_scan_t(const void* u, const void* z, int64_t ldz, const void* dsrc, int64_t ldd,
+                                const void* Wdt, int Rp, const float* bc, const float* A2, float a_scale,
+                                const float* Dskip, const float* dbias, void* y, int S, int L, int E, bool reverse,
+                                bool accumulate, hipStream_t s) {
     dim3 grid((unsigned)(E / 64), (unsigned)S), block(64);
-#define PCAD_SCAN(REV, ACC, HZ)                                                                                   \
-    hipLaunchKernelGGL((scan_kernel<T, REV, ACC, HZ>), grid, block, 0, s, (const T*)u, (const T*)delta, (const T*)z, \
-                       ldz, (const T*)Bm, (const T*)Cm, ldbc, A2, a_scale, Dskip, dbias, (const T*)y, (T*)y, L, E)
+#define PCAD_SCAN(REV, ACC, HZ)                                                                                    \
+    hipLaunchKernelGGL((scan_kernel<T, REV, ACC, HZ, FUSED>), grid, block, 0, s, (const T*)u, (const T*)z, ldz,       \
+                       (const T*)dsrc, ldd, (const T*)Wdt, Rp, bc, A2, a_scale, Dskip, dbias, (const T*)y, (T*)y, L, E)
     const bool hz = z != nullptr;
     if (!reverse && !accumulate) { if (hz) PCAD_SCAN(false, false, true); else PCAD_SCAN(false, false, false); }
     else if (!reverse && accumulate) { if (hz) PCAD_SCAN(false, true, true); else PCAD_SCAN(false, true, false); }
@@ -129,14 +236,20 @@ static hipError_t launch_scan_t(const void* u, const void* delta, const void* z,
     return hipGetLastError();
 }
 
-hipError_t launch_scan(const void* u, const void* delta, const void* z, int64_t ldz, const void* Bm, const void* Cm,
-                       int64_t ldbc, const float* A2, float a_scale, const float* Dskip, const float* dbias, void* y, int S,
-                       int L, int E, bool reverse, bool accumulate, int dt, hipStream_t s) {
+hipError_t launch_scan(const void* u, const void* z, int64_t ldz, const void* delta, const void* dt_low, int64_t lddt,
+                       const void* Wdt, int Rp, const float* bc, const float* A2, float a_scale, const float* Dskip,
+                       const float* dbias, void* y, int S, int L, int E, bool reverse, bool accumulate, int dt,
+                       hipStream_t s) {
     if (S <= 0 || L <= 0) return hipSuccess;
     if (E % 64) return hipErrorInvalidValue;
-    if (dt == BF16)
-        return launch_scan_t<bf16_t>(u, delta, z, ldz, Bm, Cm, ldbc, A2, a_scale, Dskip, dbias, y, S, L, E, reverse, accumulate, s);
-    return launch_scan_t<float>(u, delta, z, ldz, Bm, Cm, ldbc, A2, a_scale, Dskip, dbias, y, S, L, E, reverse, accumulate, s);
+    const bool fused = delta == nullptr;
+    if (fused && (!dt_low || !Wdt || Rp <= 0 || Rp % 64)) return hipErrorInvalidValue;
+    if (dt == BF16) {
+        if (fused) return launch_scan_t<bf16_t, true>(u, z, ldz, dt_low, lddt, Wdt, Rp, bc, A2, a_scale, Dskip, dbias, y, S, L, E, reverse, accumulate, s);
+        return launch_scan_t<bf16_t, false>(u, z, ldz, delta, E, nullptr, 0, bc, A2, a_scale, Dskip, dbias, y, S, L, E, reverse, accumulate, s);
+    }
+    if (fused) return launch_scan_t<float, true>(u, z, ldz, dt_low, lddt, Wdt, Rp, bc, A2, a_scale, Dskip, dbias, y, S, L, E, reverse, accumulate, s);
+    return launch_scan_t<float, false>(u, z, ldz, delta, E, nullptr, 0, bc, A2, a_scale, Dskip, dbias, y, S, L, E, reverse, accumulate, s);
 }
 
 }  // namespace pcad

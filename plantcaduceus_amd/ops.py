@@ -77,6 +77,19 @@ def causal_conv1d_fn(x, weight, bias=None, activation=None):
     return yf.transpose(1, 2)
 
 
+def _scan_common(u, B, C, A, D, z, delta_bias):
+    Bsz, E, L = u.shape
+    dt = u.dtype
+    u_tm = u.transpose(1, 2).contiguous()
+    z_tm = z.to(dt).transpose(1, 2).contiguous() if z is not None else None
+    # B_t | C_t rows in fp32 holding the values at the model dtype's precision (what the x_proj epilogue writes)
+    bc = torch.cat([B.to(dt).transpose(1, 2), C.to(dt).transpose(1, 2)], dim=-1).float().contiguous()   # [B, L, 32]
+    A32 = A.float().contiguous()
+    Dv = (D.float() if D is not None else torch.zeros(E, device=u.device)).contiguous()
+    db = (delta_bias.float() if delta_bias is not None else torch.zeros(E, device=u.device)).contiguous()
+    return u_tm, z_tm, bc, A32, Dv, db
+
+
 def selective_scan_fn(u, delta, A, B, C, D=None, z=None, delta_bias=None, delta_softplus=False,
                       return_last_state=False, reverse=False, accumulate_into=None):
     """u, delta, z: (B, E, L); A: (E, 16); B, C: (B, 16, L); D, delta_bias: (E).  Returns (B, E, L)."""
@@ -87,25 +100,38 @@ def selective_scan_fn(u, delta, A, B, C, D=None, z=None, delta_bias=None, delta_
         raise NotImplementedError("return_last_state is not on the Caduceus path")
     lib = load_library()
     Bsz, E, L = u.shape
-    dt = u.dtype
-    u_tm = u.transpose(1, 2).contiguous()
-    d_tm = delta.to(dt).transpose(1, 2).contiguous()
-    z_tm = z.to(dt).transpose(1, 2).contiguous() if z is not None else None
-    bc = torch.cat([B.to(dt).transpose(1, 2), C.to(dt).transpose(1, 2)], dim=-1).contiguous()   # [B, L, 32]
-    A32 = A.float().contiguous()
-    Dv = (D.float() if D is not None else torch.zeros(E, device=u.device)).contiguous()
-    db = (delta_bias.float() if delta_bias is not None else torch.zeros(E, device=u.device)).contiguous()
-    if accumulate_into is not None:
-        y = accumulate_into.transpose(1, 2).contiguous()
-    else:
-        y = torch.empty_like(u_tm)
-    esz = u_tm.element_size()
+    u_tm, z_tm, bc, A32, Dv, db = _scan_common(u, B, C, A, D, z, delta_bias)
+    d_tm = delta.to(u.dtype).transpose(1, 2).contiguous()
+    y = accumulate_into.transpose(1, 2).contiguous() if accumulate_into is not None else torch.empty_like(u_tm)
     with torch.cuda.device(u.device):
         _check(lib.pcad_selective_scan(u_tm.data_ptr(), d_tm.data_ptr(), z_tm.data_ptr() if z_tm is not None else None,
-                                       E, bc.data_ptr(), bc.data_ptr() + 16 * esz, 32, A32.data_ptr(), Dv.data_ptr(),
-                                       db.data_ptr(), y.data_ptr(), Bsz, L, E, int(bool(reverse)),
-                                       int(accumulate_into is not None), _dt(u_tm), _stream_ptr()),
-               "pcad_selective_scan")
+                                       E, bc.data_ptr(), A32.data_ptr(), Dv.data_ptr(), db.data_ptr(), y.data_ptr(),
+                                       Bsz, L, E, int(bool(reverse)), int(accumulate_into is not None), _dt(u_tm),
+                                       _stream_ptr()), "pcad_selective_scan")
+    return y.transpose(1, 2)
+
+
+def selective_scan_dtproj_fn(u, dt_low, dt_proj_weight, A, B, C, D=None, z=None, delta_bias=None, reverse=False,
+                             accumulate_into=None):
+    """mamba_inner_fn's tail: delta = dt_proj_weight @ dt_low (on MFMA inside the kernel), then selective_scan_fn.
+    u, z: (B, E, L); dt_low: (B, L, R); dt_proj_weight: (E, R)."""
+    _require_gpu(u, "u")
+    lib = load_library()
+    Bsz, E, L = u.shape
+    R = dt_low.shape[-1]
+    Rp = (R + 63) // 64 * 64
+    u_tm, z_tm, bc, A32, Dv, db = _scan_common(u, B, C, A, D, z, delta_bias)
+    dl = torch.zeros((Bsz, L, Rp), dtype=u.dtype, device=u.device)
+    dl[..., :R] = dt_low.to(u.dtype)
+    W = torch.zeros((E, Rp), dtype=u.dtype, device=u.device)
+    W[:, :R] = dt_proj_weight.to(u.dtype)
+    y = accumulate_into.transpose(1, 2).contiguous() if accumulate_into is not None else torch.empty_like(u_tm)
+    with torch.cuda.device(u.device):
+        _check(lib.pcad_selective_scan_dtproj(u_tm.data_ptr(), dl.data_ptr(), Rp, W.data_ptr(), Rp,
+                                              z_tm.data_ptr() if z_tm is not None else None, E, bc.data_ptr(),
+                                              A32.data_ptr(), Dv.data_ptr(), db.data_ptr(), y.data_ptr(), Bsz, L, E,
+                                              int(bool(reverse)), int(accumulate_into is not None), _dt(u_tm),
+                                              _stream_ptr()), "pcad_selective_scan_dtproj")
     return y.transpose(1, 2)
 
 

@@ -98,6 +98,33 @@ def test_selective_scan_fp32(ops, L):
     assert relerr(out2, ref + ref_rev) < 2e-5
 
 
+@pytest.mark.parametrize("L,R,dtype", [(512, 64, torch.float32), (70, 24, torch.float32), (33, 48, torch.float32),
+                                       (256, 64, torch.bfloat16), (45, 24, torch.bfloat16)])
+def test_selective_scan_fused_dtproj(ops, L, R, dtype):
+    """engine form: delta = dt_proj.weight @ dt_low on MFMA inside the scan (mamba_inner_fn tail), both directions."""
+    u, _, A, Bm, Cm, D, z, db = _scan_inputs(L + R, 2, 128, L)
+    g = torch.Generator().manual_seed(R)
+    dt_low = torch.randn(2, L, R, generator=g)
+    Wdt = torch.randn(128, R, generator=g) * R ** -0.5
+    db = db - 3.0
+    bf = dtype == torch.bfloat16
+    rnd = O.round_bf16 if bf else (lambda t: t)
+    c = (lambda t: t.bfloat16().float()) if bf else (lambda t: t)
+    delta = rnd(torch.einsum("blr,er->bel", c(dt_low), c(Wdt)))
+    ref = O.selective_scan_fn(c(u), delta, A, c(Bm), c(Cm), D, z=c(z), delta_bias=db, delta_softplus=True, rnd=rnd)
+    ref_rev = O.selective_scan_fn(c(u).flip(-1), delta.flip(-1), A, c(Bm).flip(-1), c(Cm).flip(-1), D, z=c(z).flip(-1),
+                                  delta_bias=db, delta_softplus=True, rnd=rnd).flip(-1)
+    to = lambda t: t.to(DEV).to(dtype) if t.is_floating_point() else t.to(DEV)
+    f = lambda t: t.to(DEV)
+    out = ops.selective_scan_dtproj_fn(to(u), to(dt_low), to(Wdt), f(A), to(Bm), to(Cm), f(D), z=to(z), delta_bias=f(db))
+    tol = 2 ** -7 if bf else 3e-5
+    assert out.dtype == dtype
+    assert relerr(out, ref) < tol
+    out2 = ops.selective_scan_dtproj_fn(to(u), to(dt_low), to(Wdt), f(A), to(Bm), to(Cm), f(D), z=to(z), delta_bias=f(db),
+                                        reverse=True, accumulate_into=out)
+    assert relerr(out2, rnd(ref + ref_rev)) < 2 * tol
+
+
 def test_selective_scan_softplus_threshold_and_small_dt(ops):
     """edge cases: softplus linear branch (>20) and tiny time-steps (log1p accuracy)."""
     u, delta, A, Bm, Cm, D, z, db = _scan_inputs(3, 1, 64, 32)

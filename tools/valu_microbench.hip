@@ -1,0 +1,77 @@
+// Micro-benchmark (developer tool, not part of the product): issue cost of v_exp_f32 vs v_fma_f32 vs
+// v_pk_fma_f32 on gfx950 and whether transcendental ops overlap with plain VALU work.  Informs the scan kernel.
+//   hipcc --offload-arch=gfx950 -O3 -o valu_microbench tools/valu_microbench.hip && ./valu_microbench
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+template <int MODE, int NFMA>
+__global__ __launch_bounds__(256) void k(float* out, long long* cyc, int iters, float seed) {
+    float e[8]; f2 p[8]; float f[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { e[i] = seed * (i + 1) * 1e-3f - 0.5f; f[i] = seed + i; p[i] = f2{seed + i, seed - i}; }
+    const f2 ca = {0.999f, 1.001f}, cb = {1e-3f, -1e-3f};
+    long long t0 = __builtin_readcyclecounter();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            if (MODE == 0 || MODE == 3 || MODE == 4) asm volatile("v_exp_f32 %0, %0" : "+v"(e[i]));
+            if (MODE == 1) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(f[i]) : "v"(ca[0]), "v"(cb[0]));
+            if (MODE == 2) asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(p[i]) : "v"(ca), "v"(cb));
+            if (MODE == 3) {
+#pragma unroll
+                for (int j = 0; j < NFMA; ++j) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(f[(i + j) & 7]) : "v"(ca[0]), "v"(cb[0]));
+            }
+            if (MODE == 4) {
+#pragma unroll
+                for (int j = 0; j < NFMA; ++j) asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(p[(i + j) & 7]) : "v"(ca), "v"(cb));
+            }
+        }
+    }
+    long long t1 = __builtin_readcyclecounter();
+    float s = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s += e[i] + f[i] + p[i][0] + p[i][1];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+    if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
+}
+
+template <int MODE, int NFMA>
+void run(const char* name, int waves_per_simd) {
+    const int blocks = 256 * waves_per_simd;   // 256-thread blocks = 4 waves = 1 per SIMD
+    float* out; long long* cyc;
+    hipMalloc(&out, sizeof(float) * blocks * 256); hipMalloc(&cyc, sizeof(long long) * blocks);
+    const int iters = 20000;
+    hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+    k<MODE, NFMA><<<blocks, 256>>>(out, cyc, 100, 1.0f);
+    hipEventRecord(a);
+    k<MODE, NFMA><<<blocks, 256>>>(out, cyc, iters, 1.0f);
+    hipEventRecord(b); hipEventSynchronize(b);
+    float ms; hipEventElapsedTime(&ms, a, b);
+    std::vector<long long> h(blocks); hipMemcpy(h.data(), cyc, sizeof(long long) * blocks, hipMemcpyDeviceToHost);
+    double avg = 0; for (auto v : h) avg += v; avg /= blocks;
+    const double groups = (double)iters * 8;                       // instruction groups per wave
+    // wall-clock based: SIMD-cycles (at 2.4 GHz) per group per wave, divided by waves sharing the SIMD
+    const double wall_cyc_per_group = ms * 1e-3 * 2.4e9 / groups / waves_per_simd;
+    printf("%-28s waves/SIMD=%d  wall %.3f ms  -> %.2f SIMD-cycles@2.4GHz per group (1 exp%s)   [in-kernel counter: %.1f ticks/group/wave]\n",
+           name, waves_per_simd, ms, wall_cyc_per_group, "", avg / groups);
+    hipFree(out); hipFree(cyc);
+}
+
+int main() {
+    for (int w : {1, 2, 4}) {
+        run<0, 0>("exp only", w);
+        run<1, 0>("fma only", w);
+        run<2, 0>("pk_fma only", w);
+        run<3, 1>("exp + 1 fma", w);
+        run<3, 2>("exp + 2 fma", w);
+        run<3, 3>("exp + 3 fma", w);
+        run<3, 4>("exp + 4 fma", w);
+        run<4, 1>("exp + 1 pk_fma", w);
+        run<4, 2>("exp + 2 pk_fma", w);
+        run<4, 3>("exp + 3 pk_fma", w);
+        printf("\n");
+    }
+    return 0;
+}
