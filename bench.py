@@ -43,18 +43,22 @@ def parse():
 
 
 def algorithmic_work(cfg, rows, esz):
-    """per-launch algorithmic flops / HBM bytes of each kernel class for `rows` token-rows (DESIGN.md §4)."""
+    """per-launch algorithmic flops / HBM bytes of each kernel class for `rows` token-rows (DESIGN.md §3/§4)."""
     D, E, N, R = cfg.d_model, cfg.d_inner, cfg.d_state, cfg.dt_rank
     X = R + 2 * N
+    Rp = (R + 63) // 64 * 64
     w = {}
     w["gemm_in_proj"] = dict(flops=2.0 * rows * D * 2 * E, bytes=esz * (rows * D + rows * 2 * E + 2 * E * D))
-    w["gemm_x_proj"] = dict(flops=2.0 * rows * E * X, bytes=esz * (rows * E + rows * X + X * E))
-    w["gemm_dt_proj"] = dict(flops=2.0 * rows * R * E, bytes=esz * (rows * R + rows * E + R * E))
+    w["gemm_x_proj"] = dict(flops=2.0 * rows * E * X, bytes=esz * (rows * E + rows * Rp + X * E) + 4 * rows * 2 * N)
     w["gemm_out_proj"] = dict(flops=2.0 * rows * E * D, bytes=esz * (rows * E + rows * D + E * D))
     w["add_rmsnorm"] = dict(flops=4.0 * rows * D, bytes=rows * D * (2 * esz + 8))
     w["conv1d_bidir"] = dict(flops=2.0 * 2 * 4 * rows * E, bytes=esz * rows * E * 3)
-    # per direction launch: read u, delta, z (+ y for the accumulating direction: averaged 0.5) + B,C; write y
-    w["selective_scan"] = dict(flops=rows * E * N * 6.0, bytes=esz * (rows * E * 4.5 + rows * 2 * N))
+    # per direction launch: read u, z (+ y for the accumulating direction: averaged 0.5), dt_low, B|C (fp32); write y.
+    # flops: dt_proj contraction on MFMA (2*R*E) + 6 per state update; valu_cycles: measured issue costs on gfx950
+    # (tools/valu_microbench.hip, 4 waves/SIMD, 2.4 GHz nominal): per (t, 64-channel wave) 16 states x (2 pk_mul +
+    # 2 pk_fma)/2 x 5.24 + 16 x 8.48 (v_exp_f32) + ~125 (softplus, SiLU gate, conversions, I/O) = ~430 cycles.
+    w["selective_scan"] = dict(flops=rows * E * (N * 6.0 + 2.0 * R), bytes=esz * (rows * E * 3.5 + rows * Rp) + 4 * rows * 2 * N,
+                               valu_cycles=rows * (E / 64.0) * 430.0)
     w["final_head"] = dict(flops=0.0, bytes=0.0)
     return w
 
@@ -163,6 +167,13 @@ def main():
                 a = work[dom]["bytes"] / avg_s / 1e9
                 res["roofline"] = {"kernel": dom, "bound": "hbm", "achieved": a, "peak": PEAK_HBM, "unit": "GB/s",
                                    "frac": a / PEAK_HBM, "traffic": None}
+                if "valu_cycles" in work[dom]:
+                    # the scan is VALU/transcendental-bound, which the contract's hbm|mfma choice cannot express:
+                    # fraction of the chip's VALU issue time (1024 SIMDs x 2.4 GHz nominal) the modelled work needs
+                    res["roofline"]["valu_frac"] = work[dom]["valu_cycles"] / (avg_s * 1024 * 2.4e9)
+                    res["roofline"]["note"] = ("dominant kernel is VALU/transcendental-bound (16 v_exp_f32 + 32 packed fp32 ops "
+                                               "per (t, channel)); valu_frac = modelled issue cycles / (launch time x 1024 SIMDs "
+                                               "x 2.4 GHz), DESIGN.md §3")
             res["roofline"]["share_of_gpu_time"] = kern[dom]["total_ms"] / sum(k["total_ms"] for k in kern.values())
             res["kernels"] = kern
         # ---- host-CPU baseline: the oracle port, same model / same kind of input, bounded sample ------

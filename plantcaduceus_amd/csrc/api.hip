@@ -62,7 +62,10 @@ struct pcad_engine {
     int esz;        // bytes per activation element
     int rdt;        // residual dtype
     int chunk;      // sequences per pass through the layer stack
+    int nstreams;   // 1: everything on the caller's stream; 2: chunks alternate between two library streams
     bool bound = false;
+    hipStream_t aux[2] = {nullptr, nullptr};
+    hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr}, ev_phase = nullptr;
     std::vector<LayerWeights> layers;
     void* emb = nullptr;        // [V, D] dtype
     float* emb_f32 = nullptr;   // [V, D] fp32 copy of the dtype-rounded table
@@ -205,6 +208,11 @@ int pcad_create(const pcad_config* cfg, pcad_handle* out) {
     const char* ck = getenv("PCAD_CHUNK_SEQS");
     e->chunk = ck ? atoi(ck) : 64;
     if (e->chunk < 1) e->chunk = 1;
+    const char* ns = getenv("PCAD_STREAMS");
+    // default 1: measured on MI355X (r01d) two lanes give 851 vs 852 seq/s -- co-running a VALU-bound scan and an
+    // MFMA-bound GEMM slows each by the other's share (shared issue/power budget), so nothing is gained.
+    e->nstreams = ns ? atoi(ns) : 1;
+    if (e->nstreams != 2) e->nstreams = 1;
     *out = e;
     return PCAD_OK;
 }
@@ -214,6 +222,12 @@ void pcad_destroy(pcad_handle h) {
     for (int c = 0; c < PCAD_NUM_KERNEL_CLASSES; ++c)
         for (auto& pr : h->prof_ev[c]) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     for (auto ev : h->prof_pool) (void)hipEventDestroy(ev);
+    for (int i = 0; i < 2; ++i) {
+        if (h->aux[i]) (void)hipStreamDestroy(h->aux[i]);
+        if (h->ev_join[i]) (void)hipEventDestroy(h->ev_join[i]);
+    }
+    if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+    if (h->ev_phase) (void)hipEventDestroy(h->ev_phase);
     delete h;
 }
 
@@ -309,7 +323,9 @@ int pcad_bind_weights(pcad_handle h, const pcad_tensor* tensors, int n, void* ar
 size_t pcad_workspace_bytes(pcad_handle h, int batch, int seqlen) {
     if (!h || batch <= 0 || seqlen <= 0) return 0;
     const int Bc = batch < h->chunk ? batch : h->chunk;
-    return carve_workspace(h, nullptr, Bc, seqlen).bytes;
+    const int nchunks = (batch + h->chunk - 1) / h->chunk;
+    const int lanes = (h->nstreams == 2 && nchunks >= 2) ? 2 : 1;     // one workspace slab per concurrent chunk
+    return carve_workspace(h, nullptr, Bc, seqlen).bytes * lanes;
 }
 
 static int forward_impl(pcad_handle h, const int32_t* ids, int B, int L, const int32_t* positions, int P,
@@ -335,63 +351,127 @@ static int forward_impl(pcad_handle h, const int32_t* ids, int B, int L, const i
     const size_t need = pcad_workspace_bytes(h, B, L);
     if (ws_bytes < need) return fail(PCAD_ERR_WORKSPACE, "workspace too small: %zu < %zu", ws_bytes, need);
 
-    hipStream_t s = (hipStream_t)stream;
+    hipStream_t cs = (hipStream_t)stream;
     const int D = e->D, E = e->E, N = e->N, Rp = e->Rp, XP = e->XP, dt = e->cfg.dtype, rdt = e->rdt;
     const size_t esz = e->esz;
     const float eps = e->cfg.eps;
     const int Q = P ? P : L;
+    const int nchunks = (B + e->chunk - 1) / e->chunk;
+    const int lanes = (e->nstreams == 2 && nchunks >= 2) ? 2 : 1;
+    const size_t slab = carve_workspace(e, nullptr, B < e->chunk ? B : e->chunk, L).bytes;
 
-    for (int b0 = 0; b0 < B; b0 += e->chunk) {
-        const int Bc = (B - b0) < e->chunk ? (B - b0) : e->chunk;
-        const int S = 2 * Bc;
+    // One chunk = up to `chunk` windows (2x strands) walking the whole layer stack.  With two lanes, chunks alternate
+    // between two library-owned streams forked from / joined to the caller's stream; the second lane starts half
+    // a layer late so that one chunk's VALU-bound scans run beside the other chunk's MFMA-bound GEMMs.
+    struct Lane { hipStream_t s; Workspace w; int b0, Bc; bool active; };
+    Lane ln[2];
+    if (lanes == 2) {
+        if (!e->aux[0]) {
+            for (int i = 0; i < 2; ++i) {
+                HIP_TRY(hipStreamCreateWithFlags(&e->aux[i], hipStreamNonBlocking));
+                HIP_TRY(hipEventCreateWithFlags(&e->ev_join[i], hipEventDisableTiming));
+            }
+            HIP_TRY(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&e->ev_phase, hipEventDisableTiming));
+        }
+        HIP_TRY(hipEventRecord(e->ev_fork, cs));
+        for (int i = 0; i < 2; ++i) HIP_TRY(hipStreamWaitEvent(e->aux[i], e->ev_fork, 0));
+    }
+
+    auto phase_G = [&](Lane& c, int li) -> int {        // residual add + norm, in_proj, conv (both directions)
+        hipStream_t s = c.s;
+        const LayerWeights& W = e->layers[li];
+        const int S = 2 * c.Bc;
         const int64_t rows = (int64_t)S * L;
-        Workspace w = carve_workspace(e, workspace, Bc, L);
-        const int32_t* ids_c = ids + (int64_t)b0 * L;
+        const int32_t* ids_c = ids + (int64_t)c.b0 * L;
+        if (li == 0) {
+            if (all_hidden) {   // hidden_states[0] = RCPSEmbedding output
+                HIP_TRY(launch_embed_only(ids_c, e->emb, e->comp, c.w.h, c.Bc, L, D, dt, s));
+                HIP_TRY(launch_assemble_hidden(c.w.h, (char*)all_hidden + ((size_t)c.b0 * L * 2 * D) * esz, c.Bc, L, D, dt, s));
+            }
+            ProfScope ps(e, PCAD_K_NORM, s);
+            HIP_TRY(launch_embed_rmsnorm(ids_c, e->emb, e->comp, W.norm_w, c.w.u, c.w.res, c.Bc, L, D, eps, dt, rdt, s));
+        } else {
+            ProfScope ps(e, PCAD_K_NORM, s);
+            HIP_TRY(launch_add_rmsnorm(c.w.h, c.w.res, W.norm_w, c.w.u, c.w.res, rows, D, eps, dt, rdt, s));
+        }
+        // in_proj (tied between directions: once per strand)
+        { ProfScope ps(e, PCAD_K_GEMM_IN, s);
+        HIP_TRY(launch_gemm_nt(c.w.u, D, W.W_in, D, c.w.xz, 2 * E, rows, 2 * E, D, dt, dt, false, s)); }
+        // conv1d + SiLU, causal and anti-causal from one read of x
+        { ProfScope ps(e, PCAD_K_CONV, s);
+        HIP_TRY(launch_conv_bidir(c.w.xz, 2 * E, W.dir[0].conv_w, W.dir[0].conv_b, W.dir[1].conv_w, W.dir[1].conv_b,
+                                  c.w.xc[0], c.w.xc[1], S, L, E, dt, s)); }
+        return PCAD_OK;
+    };
+    auto phase_V = [&](Lane& c, int li) -> int {        // x_proj + fused dt_proj/scan, both directions; out_proj
+        hipStream_t s = c.s;
+        const LayerWeights& W = e->layers[li];
+        const int S = 2 * c.Bc;
+        const int64_t rows = (int64_t)S * L;
+        for (int d = 0; d < 2; ++d) {
+            const DirWeights& dw = W.dir[d];
+            // x_proj -> dt_low [rows, Rp] (model dtype, zero padded) and B_t | C_t [rows, 32] (fp32 side output)
+            { ProfScope ps(e, PCAD_K_GEMM_X, s);
+            HIP_TRY(launch_gemm_nt_split(c.w.xc[d], E, dw.Wx, E, c.w.dtl[d], Rp, c.w.bc[d], 2 * N, Rp, rows, XP, E, dt, s)); }
+            // dt_proj (on MFMA inside the scan) + bias + softplus + recurrence + D skip + SiLU(z) gate
+            ProfScope ps(e, PCAD_K_SCAN, s);
+            HIP_TRY(launch_scan(c.w.xc[d], (const char*)c.w.xz + (size_t)E * esz, 2 * E, nullptr, c.w.dtl[d], Rp, dw.Wdt, Rp,
+                                c.w.bc[d], dw.A2, 1.0f, dw.Dskip, dw.dt_bias, c.w.y, S, L, E, d == 1, d == 1, dt, s));
+        }
+        // out_proj on (y_fwd + y_rev): the two tied out_proj calls folded by linearity
+        { ProfScope ps(e, PCAD_K_GEMM_OUT, s);
+        HIP_TRY(launch_gemm_nt(c.w.y, E, W.W_out, E, c.w.h, D, rows, D, E, dt, dt, false, s)); }
+        if (all_hidden && li + 1 < e->nl) {
+            char* dst = (char*)all_hidden + ((size_t)(li + 1) * B * L * 2 * D + (size_t)c.b0 * L * 2 * D) * esz;
+            HIP_TRY(launch_assemble_hidden(c.w.h, dst, c.Bc, L, D, dt, s));
+        }
+        return PCAD_OK;
+    };
+    auto phase_head = [&](Lane& c) -> int {
+        void* hout = hidden_out ? (char*)hidden_out + ((size_t)c.b0 * Q * 2 * D) * esz : nullptr;
+        float* lout = logits_out ? logits_out + (size_t)c.b0 * Q * e->V : nullptr;
+        if (hout || lout) {
+            ProfScope ps(e, PCAD_K_HEAD, c.s);
+            HIP_TRY(launch_final_head(c.w.h, c.w.res, e->normf_w, e->emb, e->emb_f32, e->comp, hout, lout, c.Bc, L, D, eps,
+                                      pos, dt, rdt, c.s));
+        }
+        return PCAD_OK;
+    };
 
-        if (all_hidden) {   // hidden_states[0] = RCPSEmbedding output
-            HIP_TRY(launch_embed_only(ids_c, e->emb, e->comp, w.h, Bc, L, D, dt, s));
-            HIP_TRY(launch_assemble_hidden(w.h, (char*)all_hidden + ((size_t)b0 * L * 2 * D) * esz, Bc, L, D, dt, s));
+    for (int g0 = 0; g0 < nchunks; g0 += lanes) {
+        for (int i = 0; i < lanes; ++i) {
+            const int ck = g0 + i;
+            ln[i].active = ck < nchunks;
+            if (!ln[i].active) continue;
+            ln[i].b0 = ck * e->chunk;
+            ln[i].Bc = (B - ln[i].b0) < e->chunk ? (B - ln[i].b0) : e->chunk;
+            ln[i].s = lanes == 2 ? e->aux[i] : cs;
+            ln[i].w = carve_workspace(e, (char*)workspace + (size_t)i * slab, ln[i].Bc, L);
         }
         for (int li = 0; li < e->nl; ++li) {
-            const LayerWeights& W = e->layers[li];
-            if (li == 0) {
-                ProfScope ps(e, PCAD_K_NORM, s);
-                HIP_TRY(launch_embed_rmsnorm(ids_c, e->emb, e->comp, W.norm_w, w.u, w.res, Bc, L, D, eps, dt, rdt, s));
-            } else {
-                ProfScope ps(e, PCAD_K_NORM, s);
-                HIP_TRY(launch_add_rmsnorm(w.h, w.res, W.norm_w, w.u, w.res, rows, D, eps, dt, rdt, s));
+            for (int i = 0; i < lanes; ++i) {
+                if (!ln[i].active) continue;
+                if (int rc = phase_G(ln[i], li)) return rc;
+                if (lanes == 2 && li == 0 && i == 0 && ln[1].active) {
+                    // stagger: lane 1 starts when lane 0 has finished its first GEMM phase
+                    HIP_TRY(hipEventRecord(e->ev_phase, ln[0].s));
+                    HIP_TRY(hipStreamWaitEvent(ln[1].s, e->ev_phase, 0));
+                }
             }
-            // in_proj (tied between directions: once per strand)
-            { ProfScope ps(e, PCAD_K_GEMM_IN, s);
-            HIP_TRY(launch_gemm_nt(w.u, D, W.W_in, D, w.xz, 2 * E, rows, 2 * E, D, dt, dt, false, s)); }
-            // conv1d + SiLU, causal and anti-causal from one read of x
-            { ProfScope ps(e, PCAD_K_CONV, s);
-            HIP_TRY(launch_conv_bidir(w.xz, 2 * E, W.dir[0].conv_w, W.dir[0].conv_b, W.dir[1].conv_w, W.dir[1].conv_b,
-                                      w.xc[0], w.xc[1], S, L, E, dt, s)); }
-            for (int d = 0; d < 2; ++d) {
-                const DirWeights& dw = W.dir[d];
-                // x_proj -> dt_low [rows, Rp] (model dtype, zero padded) and B_t | C_t [rows, 32] (fp32 side output)
-                { ProfScope ps(e, PCAD_K_GEMM_X, s);
-                HIP_TRY(launch_gemm_nt_split(w.xc[d], E, dw.Wx, E, w.dtl[d], Rp, w.bc[d], 2 * N, Rp, rows, XP, E, dt, s)); }
-                // dt_proj (on MFMA inside the scan) + bias + softplus + recurrence + D skip + SiLU(z) gate
-                ProfScope ps(e, PCAD_K_SCAN, s);
-                HIP_TRY(launch_scan(w.xc[d], (const char*)w.xz + (size_t)E * esz, 2 * E, nullptr, w.dtl[d], Rp, dw.Wdt, Rp,
-                                    w.bc[d], dw.A2, 1.0f, dw.Dskip, dw.dt_bias, w.y, S, L, E, d == 1, d == 1, dt, s));
-            }
-            // out_proj on (y_fwd + y_rev): the two tied out_proj calls folded by linearity
-            { ProfScope ps(e, PCAD_K_GEMM_OUT, s);
-            HIP_TRY(launch_gemm_nt(w.y, E, W.W_out, E, w.h, D, rows, D, E, dt, dt, false, s)); }
-            if (all_hidden && li + 1 < e->nl) {
-                char* dst = (char*)all_hidden + ((size_t)(li + 1) * B * L * 2 * D + (size_t)b0 * L * 2 * D) * esz;
-                HIP_TRY(launch_assemble_hidden(w.h, dst, Bc, L, D, dt, s));
+            for (int i = 0; i < lanes; ++i) {
+                if (!ln[i].active) continue;
+                if (int rc = phase_V(ln[i], li)) return rc;
             }
         }
-        void* hout = hidden_out ? (char*)hidden_out + ((size_t)b0 * Q * 2 * D) * esz : nullptr;
-        float* lout = logits_out ? logits_out + (size_t)b0 * Q * e->V : nullptr;
-        if (hout || lout) {
-            ProfScope ps(e, PCAD_K_HEAD, s);
-            HIP_TRY(launch_final_head(w.h, w.res, e->normf_w, e->emb, e->emb_f32, e->comp, hout, lout, Bc, L, D, eps, pos,
-                                      dt, rdt, s));
+        for (int i = 0; i < lanes; ++i)
+            if (ln[i].active)
+                if (int rc = phase_head(ln[i])) return rc;
+    }
+    if (lanes == 2) {
+        for (int i = 0; i < 2; ++i) {
+            HIP_TRY(hipEventRecord(e->ev_join[i], e->aux[i]));
+            HIP_TRY(hipStreamWaitEvent(cs, e->ev_join[i], 0));
         }
     }
     return PCAD_OK;

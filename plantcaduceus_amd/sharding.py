@@ -21,6 +21,25 @@ def world() -> Tuple[int, int]:
     return 0, 1
 
 
+def init_from_env(device: str) -> str:
+    """Under `torchrun` (WORLD_SIZE > 1): join the process group (RCCL for ROCm devices, gloo for cpu) and return
+    this rank's device (`cuda:LOCAL_RANK`); otherwise return `device` unchanged."""
+    import os
+    ws = int(os.environ.get("WORLD_SIZE", "1"))
+    if ws <= 1 or not dist.is_available():
+        return device
+    if str(device).startswith("cuda"):
+        device = "cuda:%d" % int(os.environ.get("LOCAL_RANK", "0"))
+        torch.cuda.set_device(torch.device(device))
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if str(device).startswith("cuda"):
+            dist.init_process_group(backend="nccl", device_id=torch.device(device))
+        else:
+            dist.init_process_group(backend="gloo")
+    return device
+
+
 def shard_bounds(n: int, rank: int, world_size: int) -> Tuple[int, int, int]:
     """-> (start, stop, per_rank): contiguous block of rank `rank`; per_rank = ceil(n / world_size)."""
     per = -(-n // world_size) if n > 0 else 0

@@ -243,6 +243,7 @@ def main(argv: Optional[Sequence[str]] = None):
     logging.basicConfig(level=logging.INFO, format="%(asctime)s - %(levelname)s - %(message)s",
                         datefmt="%Y-%m-%d %H:%M:%S")
     args = parse_args(argv)
+    args.device = sharding.init_from_env(args.device)
     if args.inputDF is not None:
         logging.info(f"Reading input data from {args.inputDF}")
         snpDF = pd.read_csv(args.inputDF, delimiter="\t")

@@ -98,6 +98,10 @@ def test_batch_chunking_and_empty_and_all_hidden(monkeypatch):
     monkeypatch.setenv("PCAD_CHUNK_SEQS", "3")   # 7 sequences -> chunks 3,3,1
     m = build(cfg, sd, torch.float32)
     lg = m(input_ids=ids.to(DEV)).logits.cpu()
+    monkeypatch.setenv("PCAD_STREAMS", "2")      # same chunks alternating between the two library streams
+    m1 = build(cfg, sd, torch.float32)
+    assert torch.equal(lg, m1(input_ids=ids.to(DEV)).logits.cpu())
+    monkeypatch.setenv("PCAD_STREAMS", "1")
     monkeypatch.setenv("PCAD_CHUNK_SEQS", "64")
     m2 = build(cfg, sd, torch.float32)
     assert torch.equal(lg, m2(input_ids=ids.to(DEV)).logits.cpu())
