@@ -174,6 +174,18 @@ def main():
                     res["roofline"]["note"] = ("dominant kernel is VALU/transcendental-bound (16 v_exp_f32 + 32 packed fp32 ops "
                                                "per (t, channel)); valu_frac = modelled issue cycles / (launch time x 1024 SIMDs "
                                                "x 2.4 GHz), DESIGN.md §3")
+            # HBM bytes per launch from the PMC counters (separate rocprofv3 --pmc passes, summary committed under profiles/)
+            try:
+                import glob
+                pm = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))
+                if pm and args.model == "l32" and args.dtype == "bf16" and rows == 65536:
+                    pj = json.load(open(pm[-1]))
+                    key = dom if dom in pj["classes"] else ("gemm_in_out_proj" if dom in ("gemm_in_proj", "gemm_out_proj") else None)
+                    if key:
+                        res["roofline"]["traffic"] = pj["classes"][key]["traffic_bytes_per_launch"]
+                        res["roofline"]["traffic_source"] = os.path.basename(pm[-1])
+            except Exception:
+                pass
             res["roofline"]["share_of_gpu_time"] = kern[dom]["total_ms"] / sum(k["total_ms"] for k in kern.values())
             res["kernels"] = kern
         # ---- host-CPU baseline: the oracle port, same model / same kind of input, bounded sample ------
