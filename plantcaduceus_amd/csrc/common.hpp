@@ -15,15 +15,14 @@ __device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(
 __device__ __forceinline__ float bf16lo_to_f32(uint32_t v) { return __uint_as_float(v << 16); }
 __device__ __forceinline__ float bf16hi_to_f32(uint32_t v) { return __uint_as_float(v & 0xffff0000u); }
 
-// round-to-nearest-even fp32 -> bf16 (finite inputs; NaN payloads are not preserved)
-__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
-    uint32_t u = __float_as_uint(f);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (bf16_t)(u >> 16);
-}
+// round-to-nearest-even fp32 -> bf16: the compiler lowers the __bf16 conversion to v_cvt_pk_bf16_f32 on gfx950
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
-    return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+    const bf16x2_t r = __builtin_convertvector(f32x2_t{lo, hi}, bf16x2_t);
+    return __builtin_bit_cast(uint32_t, r);
 }
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) { return (bf16_t)(pack_bf16x2(f, 0.f) & 0xffffu); }
 __device__ __forceinline__ float round_to_bf16(float f) { return bf16_to_f32(f32_to_bf16(f)); }
 
 // storage-type traits: T is `float` or `bf16_t`

@@ -5,18 +5,25 @@
 // K-contiguous (token-major activations x nn.Linear weights), which is the natural MFMA layout.
 //
 // Design (wave64, CDNA4):
-//   * 128x128 block tile, 4 waves as 2(M) x 2(N), each wave 64x64 = 4x4 MFMA 16x16 tiles.
+//   * 256x128 block tile, 8 waves as 4(M) x 2(N), each wave 64x64 = 4x4 MFMA 16x16 tiles; ONE persistent block per
+//     CU walking its share of the output tiles.
 //   * K tile = 128 BYTES per row for every dtype (64 bf16 / 32 fp32) so the LDS image, the staging code and
 //     the ds_read_b128 fragment reads are byte-identical; only the MFMA differs:
 //       bf16: v_mfma_f32_16x16x32_bf16 (one per 16-byte fragment pair),
 //       fp32: 4 x v_mfma_f32_16x16x4_f32 on the 4 floats of the same fragments (exact fp32, k permuted
 //             identically on both operands).
-//   * global -> LDS by direct LDS-DMA (global_load_lds_dwordx4), double buffered, one barrier per K tile.
-//     The LDS image is lane-linear (DMA constraint), so the bank-conflict swizzle (16-byte chunk index XOR a
-//     row key) is applied to the per-lane SOURCE address and again on the fragment read.
+//   * global -> LDS by direct LDS-DMA (global_load_lds_dwordx4) into a 3-stage ring (3 x 48 KiB): the loads of
+//     K-tile g+3 are issued in the middle of K-tile g and waited for with a COUNTED s_waitcnt vmcnt(6), so 2.5
+//     K-tiles (~2500 cycles of MFMA work per SIMD) cover the HBM/L2 latency; one raw s_barrier per K-tile.
+//   * MFMA operand fragments are double-buffered in registers (ds_read_b128 of the next k-half under the 16 MFMAs
+//     of the current one), so LDS latency is never exposed.  (Measured: with a 2-stage ring and loads one K-tile ahead the loop was latency-bound
+//     at ~950 TF whatever the tile prologue/epilogue did.)  The ring runs continuously across the block's output
+//     tiles, so a tile's first K-tiles load under the previous tile's last MFMAs and its stores.
+//   * The LDS image is lane-linear (DMA constraint), so the bank-conflict swizzle (16-byte chunk index XOR a
+//     row key) is applied to the per-lane SOURCE address and again on the fragment read (0 conflicts measured).
 //   * operands swapped (W is the MFMA "A" operand) with W rows permuted inside the wave tile so that each
 //     lane ends up holding 16 CONSECUTIVE output columns of one output row: 32/64-byte vector stores.
-//   * blockIdx -> tile map is XCD-aware: each XCD walks a contiguous range of tiles, m-fastest inside
+//   * tile -> (m, n) map is XCD-aware: each XCD walks a contiguous range of tiles, m-fastest inside
 //     groups of 8 m-panels, so the A panels and the current W rows stay in that XCD's 4 MiB L2.
 #include "common.hpp"
 #include "kernels.hpp"
@@ -25,9 +32,12 @@ namespace pcad {
 
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 
-constexpr int BM = 128, BN = 128, ROWB = 128;          // ROWB: bytes of K per tile row
-constexpr int TILE_BYTES = BM * ROWB;                  // 16 KiB per operand tile
-constexpr int GEMM_LDS = 2 * 2 * TILE_BYTES;           // 64 KiB: 2 buffers x (A, W)
+constexpr int BM = 256, BN = 128, ROWB = 128;          // ROWB: bytes of K per tile row
+constexpr int A_BYTES = BM * ROWB, W_BYTES = BN * ROWB; // 32 KiB + 16 KiB per stage
+constexpr int STAGE_BYTES = A_BYTES + W_BYTES;
+constexpr int NSTAGE = 3;
+constexpr int GEMM_LDS = NSTAGE * STAGE_BYTES;         // 144 KiB
+constexpr int GEMM_THREADS = 512;
 constexpr int GROUP_M = 8;
 
 __device__ __forceinline__ int key_a(int r) { return (r >> 1) & 7; }
@@ -55,55 +65,84 @@ __device__ __forceinline__ void glds16(const char* gsrc, char* lds_wave_base) {
 }
 
 template <typename T, typename OutT, bool ROUND, bool VEC, bool SPLIT>
-__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const T* __restrict__ A, int64_t lda,
-                                                         const T* __restrict__ W, int64_t ldw,
-                                                         OutT* __restrict__ C, int64_t ldc, int64_t M, int N, int K,
-                                                         int tiles_m, int tiles_n, float* __restrict__ C2,
-                                                         int64_t ldc2, int nsplit) {
+__global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_kernel(const T* __restrict__ A, int64_t lda,
+                                                                  const T* __restrict__ W, int64_t ldw,
+                                                                  OutT* __restrict__ C, int64_t ldc, int64_t M, int N,
+                                                                  int K, int tiles_m, int tiles_n,
+                                                                  float* __restrict__ C2, int64_t ldc2, int nsplit) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-
-    // ---- XCD-aware tile map -------------------------------------------------------------------
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);    // 0..7
     const int nblk = tiles_m * tiles_n;
-    const int bid = blockIdx.x;
-    const int xcd = bid & 7, idx = bid >> 3;
-    const int q = nblk >> 3, r = nblk & 7;
-    const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    const int gsz = GROUP_M * tiles_n;
-    const int g = logical / gsz;
-    const int first_m = g * GROUP_M;
-    const int gm = min(GROUP_M, tiles_m - first_m);
-    const int in_g = logical - g * gsz;
-    const int tm = first_m + in_g % gm;
-    const int tn = in_g / gm;
-    const int64_t m0 = (int64_t)tm * BM;
-    const int n0 = tn * BN;
-
-    // ---- staging addresses: wave stages rows [wave*32 + i*8, +8) of both tiles --------------------
-    const char* pa[4];
-    const char* pw[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int row = wave * 32 + i * 8 + (lane >> 3);
-        const int ca = (lane & 7) ^ key_a(row);
-        const int cw = (lane & 7) ^ key_w(row);
-        int64_t ga = m0 + row; if (ga > M - 1) ga = M - 1;
-        int gw = n0 + row; if (gw > N - 1) gw = N - 1;
-        pa[i] = reinterpret_cast<const char*>(A + ga * lda) + ca * 16;
-        pw[i] = reinterpret_cast<const char*>(W + (int64_t)gw * ldw) + cw * 16;
-    }
     const int nkt = (K * (int)sizeof(T)) / ROWB;
 
-    auto stage = [&](int kt, int buf) {
-        char* as = smem + buf * (2 * TILE_BYTES) + (wave * 32) * ROWB;
-        char* ws = as + TILE_BYTES;
+    // ---- XCD-aware tile map: block b runs on XCD b & 7 (observed dispatch order; speed only) and walks the
+    // contiguous logical range of that XCD, m-fastest inside groups of GROUP_M m-panels -------------------------
+    auto tile_coords = [&](int tile, int64_t& m0, int& n0) {
+        const int xcd = tile & 7, idx = tile >> 3;
+        const int q = nblk >> 3, r = nblk & 7;
+        const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+        const int gsz = GROUP_M * tiles_n;
+        const int g = logical / gsz;
+        const int first_m = g * GROUP_M;
+        const int gm = min(GROUP_M, tiles_m - first_m);
+        const int in_g = logical - g * gsz;
+        m0 = (int64_t)(first_m + in_g % gm) * BM;
+        n0 = (in_g / gm) * BN;
+    };
+
+    // ---- staging cursor (runs two K-tiles ahead of the MFMAs): wave stages A rows [wave*32, +32) and W rows
+    // [wave*16, +16) of the cursor's tile: 4 + 2 LDS-DMA instructions of 1 KiB ------------------------------------
+    const char* pa[4];
+    const char* pw[2];
+    auto set_ptrs = [&](int64_t m0, int n0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = wave * 32 + i * 8 + (lane >> 3);
+            int64_t ga = m0 + row; if (ga > M - 1) ga = M - 1;
+            pa[i] = reinterpret_cast<const char*>(A + ga * lda) + (((lane & 7) ^ key_a(row)) << 4);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row = wave * 16 + i * 8 + (lane >> 3);
+            int gw = n0 + row; if (gw > N - 1) gw = N - 1;
+            pw[i] = reinterpret_cast<const char*>(W + (int64_t)gw * ldw) + (((lane & 7) ^ key_w(row)) << 4);
+        }
+    };
+    auto stage = [&](int kt, int st) {
+        char* as = smem + st * STAGE_BYTES + (wave * 32) * ROWB;
+        char* ws = smem + st * STAGE_BYTES + A_BYTES + (wave * 16) * ROWB;
         const int64_t ko = (int64_t)kt * ROWB;
 #pragma unroll
         for (int i = 0; i < 4; ++i) glds16(pa[i] + ko, as + i * 8 * ROWB);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) glds16(pw[i] + ko, ws + i * 8 * ROWB);
+        for (int i = 0; i < 2; ++i) glds16(pw[i] + ko, ws + i * 8 * ROWB);
+    };
+    int stile = blockIdx.x, skt = 0;        // what the next stage() call loads
+    bool s_valid = stile < nblk;
+    auto stage_next = [&](int st) -> bool {     // returns whether 6 DMAs were issued
+        const bool issued = s_valid;
+        if (s_valid) {
+            stage(skt, st);
+            if (++skt == nkt) {
+                skt = 0;
+                stile += (int)gridDim.x;
+                s_valid = stile < nblk;
+                if (s_valid) {
+                    int64_t sm0; int sn0;
+                    tile_coords(stile, sm0, sn0);
+                    set_ptrs(sm0, sn0);
+                }
+            }
+        }
+        return issued;
+    };
+    // wait until the DMAs of the K-tile about to be read have landed: if `younger` DMAs (6 per wave, issued after
+    // them; loads retire in order) are in flight they may stay in flight, otherwise drain everything
+    auto wait_landed = [&](bool younger) {
+        if (younger) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     };
 
     const int wm = wave >> 1, wn = wave & 1;
@@ -115,85 +154,144 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const T* __restrict__ A
         const int ra = wm * 64 + i * 16 + li;
         a_off[i] = ra * ROWB; a_key[i] = key_a(ra);
         const int rw = wn * 64 + (li >> 2) * 16 + i * 4 + (li & 3);
-        w_off[i] = rw * ROWB; w_key[i] = key_w(rw);
+        w_off[i] = A_BYTES + rw * ROWB; w_key[i] = key_w(rw);
     }
 
     f32x4 acc[4][4];
+    auto zero_acc = [&]() {
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    stage(0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-
-    for (int kt = 0; kt < nkt; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < nkt) stage(kt + 1, buf ^ 1);
-        const char* as = smem + buf * (2 * TILE_BYTES);
-        const char* ws = as + TILE_BYTES;
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            const int chunk = kk * 4 + lg;
-            u32x4 af[4], wf[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                af[i] = *reinterpret_cast<const u32x4*>(as + a_off[i] + ((chunk ^ a_key[i]) << 4));
-                wf[i] = *reinterpret_cast<const u32x4*>(ws + w_off[i] + ((chunk ^ w_key[i]) << 4));
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = Mma<T>::run(wf[j], af[i], acc[i][j]);
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-    }
+            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    };
 
     // ---- epilogue: lane holds, per mi, 16 consecutive columns n = nb .. nb+15 of row m ------------
-    const int nb = n0 + wn * 64 + lg * 16;
+    auto epilogue = [&](int64_t m0, int n0) {
+        const int nb = n0 + wn * 64 + lg * 16;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int64_t m = m0 + wm * 64 + i * 16 + li;
-        if (m >= M) continue;
-        float o[16];
+        for (int i = 0; i < 4; ++i) {
+            const int64_t m = m0 + wm * 64 + i * 16 + li;
+            if (m >= M) continue;
+            float o[16];
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+            for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int rr = 0; rr < 4; ++rr) {
-                float v = acc[i][j][rr];
-                if constexpr (ROUND) v = round_to_bf16(v);
-                o[j * 4 + rr] = v;
-            }
-        if constexpr (SPLIT) {
-            if (nb >= nsplit) {   // fp32 side output (x_proj: B_t | C_t rows for the scan's scalar loads)
-                if (nb + 16 <= N) {
-                    float* d2 = C2 + m * ldc2 + (nb - nsplit);
-#pragma unroll
-                    for (int e = 0; e < 16; e += 4) {
-                        f32x4 v = {Elem<T>::round(o[e]), Elem<T>::round(o[e + 1]), Elem<T>::round(o[e + 2]),
-                                   Elem<T>::round(o[e + 3])};
-                        *reinterpret_cast<f32x4*>(d2 + e) = v;
-                    }
+                for (int rr = 0; rr < 4; ++rr) {
+                    float v = acc[i][j][rr];
+                    if constexpr (ROUND) v = round_to_bf16(v);
+                    o[j * 4 + rr] = v;
                 }
-                continue;
+            if constexpr (SPLIT) {
+                if (nb >= nsplit) {   // fp32 side output (x_proj: B_t | C_t rows for the scan's scalar loads)
+                    if (nb + 16 <= N) {
+                        float* d2 = C2 + m * ldc2 + (nb - nsplit);
+#pragma unroll
+                        for (int e = 0; e < 16; e += 4) {
+                            f32x4 v = {Elem<T>::round(o[e]), Elem<T>::round(o[e + 1]), Elem<T>::round(o[e + 2]),
+                                       Elem<T>::round(o[e + 3])};
+                            *reinterpret_cast<f32x4*>(d2 + e) = v;
+                        }
+                    }
+                    continue;
+                }
+            }
+            OutT* dst = C + m * ldc + nb;
+            const int Nmain = SPLIT ? nsplit : N;
+            if (VEC && nb + 16 <= Nmain) {
+                float lo[8], hi[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { lo[e] = o[e]; hi[e] = o[8 + e]; }
+                store8<OutT>(dst, lo);
+                store8<OutT>(dst + 8, hi);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 16; ++e)
+                    if (nb + e < Nmain) Elem<OutT>::store(dst + e, o[e]);
             }
         }
-        OutT* dst = C + m * ldc + nb;
-        const int Nmain = SPLIT ? nsplit : N;
-        if (VEC && nb + 16 <= Nmain) {
-            float lo[8], hi[8];
+    };
+
+    // ---- persistent loop: one continuous K-tile ring across this block's output tiles --------------------------
+    // Fragment reads are software-pipelined in registers: the k-half-1 fragments of K-tile g are read before its
+    // k-half-0 MFMAs, and the k-half-0 fragments of K-tile g+1 before the k-half-1 MFMAs of g, so ds_read latency
+    // is always under 16 MFMAs.  That puts the "g+1 has landed" barrier in the MIDDLE of iteration g.
+    auto load_frags = [&](int st, int kk, u32x4 (&af)[4], u32x4 (&wf)[4]) {
+        const char* base = smem + st * STAGE_BYTES;
+        const int chunk = kk * 4 + lg;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { lo[e] = o[e]; hi[e] = o[8 + e]; }
-            store8<OutT>(dst, lo);
-            store8<OutT>(dst + 8, hi);
+        for (int i = 0; i < 4; ++i) {
+            af[i] = *reinterpret_cast<const u32x4*>(base + a_off[i] + ((chunk ^ a_key[i]) << 4));
+            wf[i] = *reinterpret_cast<const u32x4*>(base + w_off[i] + ((chunk ^ w_key[i]) << 4));
+        }
+    };
+    auto mma16 = [&](const u32x4 (&af)[4], const u32x4 (&wf)[4]) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = Mma<T>::run(wf[j], af[i], acc[i][j]);
+    };
+
+    int tile = blockIdx.x;
+    if (tile >= nblk) return;
+    int64_t m0; int n0;
+    tile_coords(tile, m0, n0);
+    set_ptrs(m0, n0);
+    stage_next(0);                                   // K-tile g = 0
+    wait_landed(stage_next(1));                      // g = 1 (possibly of the next output tile, or nothing) stays in flight
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    u32x4 af0[4], wf0[4], af1[4], wf1[4];
+    load_frags(0, 0, af0, wf0);
+    bool younger = stage_next(2);                    // g = 2
+    zero_acc();
+    int st = 0, kt = 0;
+    bool pending = false;
+    int64_t pm0 = 0; int pn0 = 0;
+    while (true) {
+        const int stn = st == 2 ? 0 : st + 1;
+        load_frags(st, 1, af1, wf1);
+        if (pending) {                    // previous tile's result (its MFMAs were issued before the last barrier)
+            epilogue(pm0, pn0);
+            zero_acc();
+            pending = false;
+        }
+        mma16(af0, wf0);
+        // K-tile g+1 must have landed before anyone reads it; the 6 DMAs of g+2 may stay in flight.  (The epilogue's
+        // stores also count in vmcnt on CDNA4; they are younger than g+1's DMAs, and loads retire in order among
+        // themselves, so "<= 6 outstanding" still implies g+1 has landed.)  lgkmcnt(0): this wave's reads of stage
+        // `st` are complete, so after the barrier the stage may be overwritten by the DMAs of g+3.
+        wait_landed(younger);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        load_frags(stn, 0, af0, wf0);     // K-tile g+1, k-half 0 (garbage after the last K-tile: never multiplied)
+        younger = stage_next(st);         // K-tile g+3 -> the stage whose last reads completed above
+        mma16(af1, wf1);
+        st = stn;
+        if (kt + 1 < nkt) {
+            ++kt;
         } else {
-#pragma unroll
-            for (int e = 0; e < 16; ++e)
-                if (nb + e < Nmain) Elem<OutT>::store(dst + e, o[e]);
+            pending = true; pm0 = m0; pn0 = n0;
+            tile += (int)gridDim.x;
+            if (tile >= nblk) break;
+            tile_coords(tile, m0, n0);
+            kt = 0;
         }
     }
+    epilogue(pm0, pn0);
+}
+
+// persistent launch: 1 resident block of 8 waves per CU (LDS-limited), a multiple of 8 so block b stays on XCD b & 7
+static int persistent_grid(int nblk) {
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+        if (cus <= 0) cus = 256;
+    }
+    const int cap = cus / 8 * 8;
+    return nblk < cap ? nblk : cap;
 }
 
 template <typename T, typename OutT, bool ROUND>
@@ -201,7 +299,7 @@ static hipError_t launch_gemm_t(const void* A, int64_t lda, const void* W, int64
                                 int64_t M, int N, int K, hipStream_t s) {
     const int tiles_m = (int)((M + BM - 1) / BM), tiles_n = (N + BN - 1) / BN;
     const bool vec = ((ldc * (int64_t)sizeof(OutT)) % 16 == 0) && (((uintptr_t)C) % 16 == 0);
-    dim3 grid((unsigned)(tiles_m * tiles_n)), block(256);
+    dim3 grid((unsigned)persistent_grid(tiles_m * tiles_n)), block(GEMM_THREADS);
     static bool attr_done_v = false, attr_done_s = false;
     if (vec) {
         auto kfn = gemm_nt_kernel<T, OutT, ROUND, true, false>;
@@ -227,7 +325,7 @@ template <typename T>
 static hipError_t launch_gemm_split_t(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc,
                                       float* C2, int64_t ldc2, int nsplit, int64_t M, int N, int K, hipStream_t s) {
     const int tiles_m = (int)((M + BM - 1) / BM), tiles_n = (N + BN - 1) / BN;
-    dim3 grid((unsigned)(tiles_m * tiles_n)), block(256);
+    dim3 grid((unsigned)persistent_grid(tiles_m * tiles_n)), block(GEMM_THREADS);
     auto kfn = gemm_nt_kernel<T, T, false, true, true>;
     static bool attr_done = false;
     if (!attr_done) {
