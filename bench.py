@@ -146,8 +146,10 @@ def main():
                                    % (args.model, cfg.d_model, cfg.n_layer, args.dtype, B, L, p),
                        "batch_per_gpu": B, "seq_len": L, "parallelism": "dp%d (batch-sharded, all_gather of [B,4])" % world},
         }
-        chunk = int(os.environ.get("PCAD_CHUNK_SEQS", "64"))
-        rows = 2 * min(B, chunk) * L
+        chunk_max = int(os.environ.get("PCAD_CHUNK_SEQS", "64"))
+        nchunks = -(-B // chunk_max)
+        chunk = -(-B // nchunks)                                  # even split, as pcad_forward does
+        rows = 2 * chunk * L
         work = algorithmic_work(cfg, rows, esz)
         kern = {}
         for name, (n, ms) in stats.items():
@@ -178,11 +180,12 @@ def main():
             try:
                 import glob
                 pm = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))
-                if pm and args.model == "l32" and args.dtype == "bf16" and rows == 65536:
+                if pm and args.model == "l32" and args.dtype == "bf16":
                     pj = json.load(open(pm[-1]))
                     key = dom if dom in pj["classes"] else ("gemm_in_out_proj" if dom in ("gemm_in_proj", "gemm_out_proj") else None)
                     if key:
-                        res["roofline"]["traffic"] = pj["classes"][key]["traffic_bytes_per_launch"]
+                        # measured at 65536 token-rows per launch; scaled to this run's rows per launch
+                        res["roofline"]["traffic"] = int(pj["classes"][key]["traffic_bytes_per_launch"] * rows / 65536.0)
                         res["roofline"]["traffic_source"] = os.path.basename(pm[-1])
             except Exception:
                 pass

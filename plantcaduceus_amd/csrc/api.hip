@@ -206,6 +206,7 @@ int pcad_create(const pcad_config* cfg, pcad_handle* out) {
     e->esz = cfg->dtype == PCAD_BF16 ? 2 : 4;
     e->rdt = (cfg->residual_in_fp32 || cfg->dtype == PCAD_F32) ? F32 : BF16;
     const char* ck = getenv("PCAD_CHUNK_SEQS");
+    // 64 windows = 128 strands x E/64 waves = 4096 waves at E = 2048: exactly 4 waves per SIMD, the scan's occupancy
     e->chunk = ck ? atoi(ck) : 64;
     if (e->chunk < 1) e->chunk = 1;
     const char* ns = getenv("PCAD_STREAMS");
@@ -320,10 +321,16 @@ int pcad_bind_weights(pcad_handle h, const pcad_tensor* tensors, int n, void* ar
     return PCAD_OK;
 }
 
+// windows per chunk for a batch of B: the fewest chunks of at most `chunk` windows, evenly sized (no small tail chunk)
+static int chunk_for(const pcad_engine* e, int B) {
+    const int n = (B + e->chunk - 1) / e->chunk;
+    return (B + n - 1) / n;
+}
+
 size_t pcad_workspace_bytes(pcad_handle h, int batch, int seqlen) {
     if (!h || batch <= 0 || seqlen <= 0) return 0;
-    const int Bc = batch < h->chunk ? batch : h->chunk;
-    const int nchunks = (batch + h->chunk - 1) / h->chunk;
+    const int Bc = chunk_for(h, batch);
+    const int nchunks = (batch + Bc - 1) / Bc;
     const int lanes = (h->nstreams == 2 && nchunks >= 2) ? 2 : 1;     // one workspace slab per concurrent chunk
     return carve_workspace(h, nullptr, Bc, seqlen).bytes * lanes;
 }
@@ -356,9 +363,10 @@ static int forward_impl(pcad_handle h, const int32_t* ids, int B, int L, const i
     const size_t esz = e->esz;
     const float eps = e->cfg.eps;
     const int Q = P ? P : L;
-    const int nchunks = (B + e->chunk - 1) / e->chunk;
+    const int chunk = chunk_for(e, B);
+    const int nchunks = (B + chunk - 1) / chunk;
     const int lanes = (e->nstreams == 2 && nchunks >= 2) ? 2 : 1;
-    const size_t slab = carve_workspace(e, nullptr, B < e->chunk ? B : e->chunk, L).bytes;
+    const size_t slab = carve_workspace(e, nullptr, chunk, L).bytes;
 
     // One chunk = up to `chunk` windows (2x strands) walking the whole layer stack.  With two lanes, chunks alternate
     // between two library-owned streams forked from / joined to the caller's stream; the second lane starts half
@@ -444,8 +452,8 @@ static int forward_impl(pcad_handle h, const int32_t* ids, int B, int L, const i
             const int ck = g0 + i;
             ln[i].active = ck < nchunks;
             if (!ln[i].active) continue;
-            ln[i].b0 = ck * e->chunk;
-            ln[i].Bc = (B - ln[i].b0) < e->chunk ? (B - ln[i].b0) : e->chunk;
+            ln[i].b0 = ck * chunk;
+            ln[i].Bc = (B - ln[i].b0) < chunk ? (B - ln[i].b0) : chunk;
             ln[i].s = lanes == 2 ? e->aux[i] : cs;
             ln[i].w = carve_workspace(e, (char*)workspace + (size_t)i * slab, ln[i].Bc, L);
         }

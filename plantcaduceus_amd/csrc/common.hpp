@@ -82,13 +82,21 @@ constexpr float kLn2 = 0.6931471805599453f;
 // silu(v) = v / (1 + exp(-v))
 __device__ __forceinline__ float silu(float v) { return v * fast_rcp(1.0f + fast_exp2(-v * kLog2e)); }
 
-// softplus with torch's threshold (20); log1p evaluated with Kahan's correction so that small
-// time-steps (softplus(-7) ~ 1e-3) keep full fp32 relative accuracy.
+// softplus with torch's threshold (20): log1p(e), e = exp(x).  For e < 2^-4 a 6-term alternating series
+// (truncation e^6/7 < 1e-8 relative) keeps full fp32 relative accuracy for small time-steps (softplus(-7) ~ 1e-3)
+// where log(1 + e) would lose it to the rounding of 1 + e; above, log2(1 + e) is accurate to < 1e-6 relative.
+// 2 transcendentals (v_exp_f32, v_log_f32) + 8 plain ops.
 __device__ __forceinline__ float softplus(float x) {
     const float e = fast_exp2(x * kLog2e);
-    const float w = 1.0f + e;
-    const float d = w - 1.0f;
-    const float l = (d == 0.0f) ? e : fast_log2(w) * kLn2 * (e * fast_rcp(d));
+    const float big = fast_log2(1.0f + e) * kLn2;
+    float p = -1.0f / 6.0f;
+    p = p * e + 0.2f;
+    p = p * e - 0.25f;
+    p = p * e + (1.0f / 3.0f);
+    p = p * e - 0.5f;
+    p = p * e + 1.0f;
+    const float small = p * e;
+    const float l = e < 0.0625f ? small : big;
     return x > 20.0f ? x : l;
 }
 

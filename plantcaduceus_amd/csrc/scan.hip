@@ -22,6 +22,8 @@
 //     direction's output (BiMambaWrapper strategy "add", tied out_proj folded by linearity).
 // VALU/transcendental bound (measured on gfx950: v_exp_f32 8.5, v_fma_f32 3.7, v_pk_fma_f32 5.2 cycles per
 // wave-instruction at 4 waves/SIMD, not overlapping): ~19 cycles per (t, channel, state).
+#include <cstdlib>
+
 #include "common.hpp"
 #include "kernels.hpp"
 
@@ -64,6 +66,33 @@ template <> struct DeltaTile<bf16_t> {
     }
 };
 
+// Rp == 64 (every PlantCaduceus size: dt_rank <= 64): the dt_low operand of the NEXT block (4 x 16 bytes per lane) is
+// loaded one block ahead and held in registers through the walk, so its HBM/L2 latency is never exposed.
+struct DeltaPre { u32x4 a[4]; };
+__device__ __forceinline__ DeltaPre delta_prefetch(const bf16_t* __restrict__ dtl, int64_t lddt, int64_t row_base,
+                                                   int t0, int L, int lane) {
+    const int tr = max(0, min(t0 + (lane & 31), L - 1));
+    const bf16_t* arow = dtl + (row_base + tr) * lddt + (lane >> 5) * 8;
+    DeltaPre p;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) p.a[k] = *reinterpret_cast<const u32x4*>(arow + k * 16);
+    return p;
+}
+__device__ __forceinline__ void delta_run_pre(const DeltaPre& p, const bf16_t* __restrict__ Wdt, int c0, int lane,
+                                              f32x16& acc0, f32x16& acc1) {
+    const bf16_t* b0 = Wdt + (int64_t)(c0 + (lane & 31)) * 64 + (lane >> 5) * 8;
+    const bf16_t* b1 = b0 + (int64_t)32 * 64;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const u32x4 w0 = *reinterpret_cast<const u32x4*>(b0 + k * 16);
+        const u32x4 w1 = *reinterpret_cast<const u32x4*>(b1 + k * 16);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, p.a[k]),
+                                                       __builtin_bit_cast(bf16x8_t, w0), acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, p.a[k]),
+                                                       __builtin_bit_cast(bf16x8_t, w1), acc1, 0, 0, 0);
+    }
+}
+
 template <> struct DeltaTile<float> {
     // exact fp32 on v_mfma_f32_32x32x2_f32; lane half kh = l>>5 owns k in [kh*Rp/2, (kh+1)*Rp/2) (same
     // permutation of k on both operands, so the contraction is unchanged).
@@ -89,7 +118,8 @@ template <> struct DeltaTile<float> {
 };
 
 // FUSED: delta comes from dt_low . Wdt^T (above);  !FUSED: delta is read from memory like u (operator entry).
-template <typename T, bool REV, bool ACC, bool HASZ, bool FUSED>
+// PRE (bf16, FUSED, Rp == 64): dt_low operand prefetched one block ahead.
+template <typename T, bool REV, bool ACC, bool HASZ, bool FUSED, bool PRE>
 __global__ __launch_bounds__(64, 4) void scan_kernel(const T* __restrict__ u, const T* __restrict__ z, int64_t ldz,
                                                   const T* __restrict__ dsrc, int64_t ldd,
                                                   const T* __restrict__ Wdt, int Rp,
@@ -154,24 +184,33 @@ __global__ __launch_bounds__(64, 4) void scan_kernel(const T* __restrict__ u, co
     load_bc(0, bcc);
 
     // one recurrence step on raw inputs (uraw, zraw, yraw, draw) at walk step s
+    float dv_cur = 0.f;    // FUSED: delta of the step about to run, read from LDS one step ahead
     auto step = [&](int s, int tb0, T uraw, T zraw, T yraw, T draw) {
         f2 bcn[NSTATE];
         load_bc(s + 1, bcn);
         const uint32_t t = (uint32_t)tclamp(s);
-        float dv;
-        if constexpr (FUSED) dv = dvs[(int)t - tb0][lane];
-        else dv = softplus(Elem<T>::to_f32(draw) + db);
+        float dv, dv_next = 0.f;
+        if constexpr (FUSED) {
+            dv = dv_cur;
+            const int idx = (int)t - tb0 + (REV ? -1 : 1);          // next step's row of the slab (same block)
+            dv_next = dvs[max(0, min(TB - 1, idx))][lane];
+        } else {
+            dv = softplus(Elem<T>::to_f32(draw) + db);
+        }
         const float uv = Elem<T>::to_f32(uraw);
         const float du = dv * uv;
         const f2 dv2 = {dv, dv}, du2 = {du, du};
-        f2 yacc = {dsk * uv, 0.f};
+        f2 yacc0 = {dsk * uv, 0.f}, yacc1 = {0.f, 0.f};      // two independent accumulation chains
 #pragma unroll
-        for (int p = 0; p < NSTATE / 2; ++p) {
-            const f2 e = dv2 * a2p[p];
-            const f2 a = {exp2_hw(e[0]), exp2_hw(e[1])};
-            hp[p] = a * hp[p] + du2 * bcc[p];
-            yacc = hp[p] * bcc[NSTATE / 2 + p] + yacc;
+        for (int p = 0; p < NSTATE / 2; p += 2) {
+            const f2 e0 = dv2 * a2p[p], e1 = dv2 * a2p[p + 1];
+            const f2 a0 = {exp2_hw(e0[0]), exp2_hw(e0[1])}, a1 = {exp2_hw(e1[0]), exp2_hw(e1[1])};
+            hp[p] = a0 * hp[p] + du2 * bcc[p];
+            hp[p + 1] = a1 * hp[p + 1] + du2 * bcc[p + 1];
+            yacc0 = hp[p] * bcc[NSTATE / 2 + p] + yacc0;
+            yacc1 = hp[p + 1] * bcc[NSTATE / 2 + p + 1] + yacc1;
         }
+        const f2 yacc = yacc0 + yacc1;
         float yv = yacc[0] + yacc[1];
         if constexpr (HASZ) yv *= silu(Elem<T>::to_f32(zraw));
         yv = Elem<T>::round(yv);
@@ -179,7 +218,11 @@ __global__ __launch_bounds__(64, 4) void scan_kernel(const T* __restrict__ u, co
         Elem<T>::store(y_s + t * (uint32_t)E + lane, yv);
 #pragma unroll
         for (int p = 0; p < NSTATE; ++p) bcc[p] = bcn[p];
+        dv_cur = dv_next;
     };
+
+    DeltaPre pre;
+    if constexpr (PRE) pre = delta_prefetch((const bf16_t*)dsrc, ldd, row0, REV ? (L - TB) : 0, L, lane);
 
     for (int b = 0; b < nblk; ++b) {
         const int tb0 = REV ? (L - (b + 1) * TB) : b * TB;
@@ -187,7 +230,13 @@ __global__ __launch_bounds__(64, 4) void scan_kernel(const T* __restrict__ u, co
             f32x16 acc0, acc1;
 #pragma unroll
             for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
-            DeltaTile<T>::run(dsrc, ldd, row0, tb0, L, Wdt, c0, Rp, lane, acc0, acc1);
+            if constexpr (PRE) {
+                delta_run_pre(pre, (const bf16_t*)Wdt, c0, lane, acc0, acc1);
+                // next block's operand: in flight during this block's 32-step walk (rows clamp at the sequence ends)
+                pre = delta_prefetch((const bf16_t*)dsrc, ldd, row0, REV ? (L - (b + 2) * TB) : (b + 1) * TB, L, lane);
+            } else {
+                DeltaTile<T>::run(dsrc, ldd, row0, tb0, L, Wdt, c0, Rp, lane, acc0, acc1);
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 // lanes 32..63 of acc0[r] <-> lanes 0..31 of acc1[r]
@@ -201,6 +250,7 @@ __global__ __launch_bounds__(64, 4) void scan_kernel(const T* __restrict__ u, co
         }
         const int s_begin = b * TB;                                      // first walk step of the block
         const int s_end = min(L, s_begin + TB);                          // one past the last
+        if constexpr (FUSED) dv_cur = dvs[tclamp(s_begin) - tb0][lane];
         int s0 = s_begin;
         for (; s0 + CH <= s_end; s0 += CH) {                             // full chunks: straight-line body
             T un[CH], zn[CH], yn[CH], dn[CH];
@@ -218,14 +268,14 @@ __global__ __launch_bounds__(64, 4) void scan_kernel(const T* __restrict__ u, co
     }
 }
 
-template <typename T, bool FUSED>
+template <typename T, bool FUSED, bool PRE = false>
 static hipError_t launch_scan_t(const void* u, const void* z, int64_t ldz, const void* dsrc, int64_t ldd,
                                 const void* Wdt, int Rp, const float* bc, const float* A2, float a_scale,
                                 const float* Dskip, const float* dbias, void* y, int S, int L, int E, bool reverse,
                                 bool accumulate, hipStream_t s) {
     dim3 grid((unsigned)(E / 64), (unsigned)S), block(64);
 #define PCAD_SCAN(REV, ACC, HZ)                                                                                    \
-    hipLaunchKernelGGL((scan_kernel<T, REV, ACC, HZ, FUSED>), grid, block, 0, s, (const T*)u, (const T*)z, ldz,       \
+    hipLaunchKernelGGL((scan_kernel<T, REV, ACC, HZ, FUSED, PRE>), grid, block, 0, s, (const T*)u, (const T*)z, ldz,       \
                        (const T*)dsrc, ldd, (const T*)Wdt, Rp, bc, A2, a_scale, Dskip, dbias, (const T*)y, (T*)y, L, E)
     const bool hz = z != nullptr;
     if (!reverse && !accumulate) { if (hz) PCAD_SCAN(false, false, true); else PCAD_SCAN(false, false, false); }
@@ -245,6 +295,8 @@ hipError_t launch_scan(const void* u, const void* z, int64_t ldz, const void* de
     const bool fused = delta == nullptr;
     if (fused && (!dt_low || !Wdt || Rp <= 0 || Rp % 64)) return hipErrorInvalidValue;
     if (dt == BF16) {
+        if (fused && Rp == 64 && lddt % 8 == 0)
+            return launch_scan_t<bf16_t, true, true>(u, z, ldz, dt_low, lddt, Wdt, Rp, bc, A2, a_scale, Dskip, dbias, y, S, L, E, reverse, accumulate, s);
         if (fused) return launch_scan_t<bf16_t, true>(u, z, ldz, dt_low, lddt, Wdt, Rp, bc, A2, a_scale, Dskip, dbias, y, S, L, E, reverse, accumulate, s);
         return launch_scan_t<bf16_t, false>(u, z, ldz, delta, E, nullptr, 0, bc, A2, a_scale, Dskip, dbias, y, S, L, E, reverse, accumulate, s);
     }
