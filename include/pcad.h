@@ -105,6 +105,13 @@ int    pcad_forward(pcad_handle h, const int32_t* ids, int B, int L,
                     void* hidden_out, float* logits_out,
                     void* workspace, size_t workspace_bytes, pcad_stream stream);
 
+/* In-silico-mutagenesis form (reference pipelines/in-silico-mutagenesis -> src/zero_shot_score.py -input-vcf, one
+ * masked forward per variant position): window b is evaluated at its own position pos_per_seq[b] (device int32 [B],
+ * clamped to [0, L)).  hidden_out [B, 1, 2*D] / logits_out [B, 1, vocab], either may be NULL. */
+int    pcad_forward_at(pcad_handle h, const int32_t* ids, int B, int L, const int32_t* pos_per_seq,
+                       void* hidden_out, float* logits_out,
+                       void* workspace, size_t workspace_bytes, pcad_stream stream);
+
 /* Per-layer mixer outputs for the last pcad_forward are not kept; this variant additionally writes
  * hidden_states[0..n_layer-1] (the inputs of every block) to `all_hidden` ([n_layer, B, L, 2*D],
  * cfg.dtype) — the `output_hidden_states=True` tuple of the reference minus its last entry. */

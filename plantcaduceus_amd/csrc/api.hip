@@ -336,7 +336,7 @@ size_t pcad_workspace_bytes(pcad_handle h, int batch, int seqlen) {
 }
 
 static int forward_impl(pcad_handle h, const int32_t* ids, int B, int L, const int32_t* positions, int P,
-                        void* all_hidden, void* hidden_out, float* logits_out, void* workspace, size_t ws_bytes,
+                        const int32_t* pos_per_seq, void* all_hidden, void* hidden_out, float* logits_out, void* workspace, size_t ws_bytes,
                         pcad_stream stream) {
     if (!h) return fail(PCAD_ERR_INVALID, "pcad_forward: null handle");
     pcad_engine* e = h;
@@ -362,7 +362,7 @@ static int forward_impl(pcad_handle h, const int32_t* ids, int B, int L, const i
     const int D = e->D, E = e->E, N = e->N, Rp = e->Rp, XP = e->XP, dt = e->cfg.dtype, rdt = e->rdt;
     const size_t esz = e->esz;
     const float eps = e->cfg.eps;
-    const int Q = P ? P : L;
+    const int Q = pos_per_seq ? 1 : (P ? P : L);
     const int chunk = chunk_for(e, B);
     const int nchunks = (B + chunk - 1) / chunk;
     const int lanes = (e->nstreams == 2 && nchunks >= 2) ? 2 : 1;
@@ -442,7 +442,7 @@ static int forward_impl(pcad_handle h, const int32_t* ids, int B, int L, const i
         if (hout || lout) {
             ProfScope ps(e, PCAD_K_HEAD, c.s);
             HIP_TRY(launch_final_head(c.w.h, c.w.res, e->normf_w, e->emb, e->emb_f32, e->comp, hout, lout, c.Bc, L, D, eps,
-                                      pos, dt, rdt, c.s));
+                                      pos, pos_per_seq ? pos_per_seq + c.b0 : nullptr, dt, rdt, c.s));
         }
         return PCAD_OK;
     };
@@ -487,13 +487,21 @@ static int forward_impl(pcad_handle h, const int32_t* ids, int B, int L, const i
 
 int pcad_forward(pcad_handle h, const int32_t* ids, int B, int L, const int32_t* positions, int P, void* hidden_out,
                  float* logits_out, void* workspace, size_t workspace_bytes, pcad_stream stream) {
-    return forward_impl(h, ids, B, L, positions, P, nullptr, hidden_out, logits_out, workspace, workspace_bytes, stream);
+    return forward_impl(h, ids, B, L, positions, P, nullptr, nullptr, hidden_out, logits_out, workspace, workspace_bytes,
+                        stream);
+}
+
+int pcad_forward_at(pcad_handle h, const int32_t* ids, int B, int L, const int32_t* pos_per_seq, void* hidden_out,
+                    float* logits_out, void* workspace, size_t workspace_bytes, pcad_stream stream) {
+    if (!pos_per_seq) return fail(PCAD_ERR_INVALID, "pcad_forward_at: null pos_per_seq");
+    return forward_impl(h, ids, B, L, nullptr, 0, pos_per_seq, nullptr, hidden_out, logits_out, workspace, workspace_bytes,
+                        stream);
 }
 
 int pcad_forward_all_hidden(pcad_handle h, const int32_t* ids, int B, int L, void* all_hidden, void* hidden_out,
                             float* logits_out, void* workspace, size_t workspace_bytes, pcad_stream stream) {
     if (!all_hidden) return fail(PCAD_ERR_INVALID, "pcad_forward_all_hidden: null all_hidden");
-    return forward_impl(h, ids, B, L, nullptr, 0, all_hidden, hidden_out, logits_out, workspace, workspace_bytes,
+    return forward_impl(h, ids, B, L, nullptr, 0, nullptr, all_hidden, hidden_out, logits_out, workspace, workspace_bytes,
                         stream);
 }
 

@@ -20,10 +20,12 @@ hipError_t launch_add_rmsnorm(const void* x, const void* res_in, const float* w,
 hipError_t launch_embed_rmsnorm(const int32_t* ids, const void* emb, const int32_t* comp8, const float* w,
                                 void* y, void* res_out, int B, int L, int D, float eps, int dt, int rdt,
                                 hipStream_t s);
-// final add + norm_f + RC re-assembly + tied RCPS LM head, only at the requested positions.
+// final add + norm_f + RC re-assembly + tied RCPS LM head, only at the requested positions (a shared list `pos`,
+// or one position per window from the device array `pos_per_seq` [B]).
 hipError_t launch_final_head(const void* h, const void* res, const float* w, const void* emb,
                              const float* emb_f32, const int32_t* comp8, void* hidden_out, float* logits_out,
-                             int B, int L, int D, float eps, Positions pos, int dt, int rdt, hipStream_t s);
+                             int B, int L, int D, float eps, Positions pos, const int32_t* pos_per_seq, int dt, int rdt,
+                             hipStream_t s);
 // hidden_states[i] (block input = previous mixer output / embedding) assembled in RCPS layout.
 hipError_t launch_assemble_hidden(const void* h, void* out, int B, int L, int D, int dt, hipStream_t s);
 hipError_t launch_embed_only(const int32_t* ids, const void* emb, const int32_t* comp8, void* h, int B, int L,

@@ -119,14 +119,16 @@ __global__ __launch_bounds__(128) void final_head_kernel(const T* __restrict__ h
                                                          const float* __restrict__ w, const float* __restrict__ emb,
                                                          const int32_t* __restrict__ comp8, T* __restrict__ hidden_out,
                                                          float* __restrict__ logits_out, int B, int L, int D, float eps,
-                                                         Positions pos) {
+                                                         Positions pos, const int32_t* __restrict__ pos_per_seq) {
     __shared__ float part[8];
     const int lane = threadIdx.x & 63;
     const int wv = threadIdx.x >> 6;   // 0: forward strand, 1: rc strand
-    const int Q = pos.n ? pos.n : L;
+    const int Q = pos_per_seq ? 1 : (pos.n ? pos.n : L);
     const int b = blockIdx.x / Q, q = blockIdx.x - b * Q;
     int p = q;
-    if (pos.n) {
+    if (pos_per_seq) {
+        p = min(max(pos_per_seq[b], 0), L - 1);      // one evaluated position per window (in-silico mutagenesis sweeps)
+    } else if (pos.n) {
         // uniform select from the by-value array (avoids runtime-indexed kernarg scratch)
 #pragma unroll
         for (int i = 0; i < 16; ++i)
@@ -205,13 +207,13 @@ __global__ __launch_bounds__(128) void final_head_kernel(const T* __restrict__ h
 template <typename T, typename RT>
 static hipError_t launch_final_t(const void* h, const void* res, const float* w, const float* emb_f32,
                                  const int32_t* comp8, void* hidden_out, float* logits_out, int B, int L, int D,
-                                 float eps, Positions pos, hipStream_t s) {
-    const int Q = pos.n ? pos.n : L;
+                                 float eps, Positions pos, const int32_t* pos_per_seq, hipStream_t s) {
+    const int Q = pos_per_seq ? 1 : (pos.n ? pos.n : L);
     dim3 grid((unsigned)(B * Q)), block(128);
     if (B * Q == 0) return hipSuccess;
 #define PCAD_FH(MC)                                                                                          \
     hipLaunchKernelGGL((final_head_kernel<T, RT, MC>), grid, block, 0, s, (const T*)h, (const RT*)res, w, emb_f32, \
-                       comp8, (T*)hidden_out, logits_out, B, L, D, eps, pos)
+                       comp8, (T*)hidden_out, logits_out, B, L, D, eps, pos, pos_per_seq)
     if (D <= 512) PCAD_FH(1);
     else if (D <= 1024) PCAD_FH(2);
     else PCAD_FH(4);
@@ -221,14 +223,15 @@ static hipError_t launch_final_t(const void* h, const void* res, const float* w,
 
 hipError_t launch_final_head(const void* h, const void* res, const float* w, const void* /*emb*/,
                              const float* emb_f32, const int32_t* comp8, void* hidden_out, float* logits_out, int B,
-                             int L, int D, float eps, Positions pos, int dt, int rdt, hipStream_t s) {
+                             int L, int D, float eps, Positions pos, const int32_t* pos_per_seq, int dt, int rdt,
+                             hipStream_t s) {
     if (D % 8 || D > 2048) return hipErrorInvalidValue;
     if (dt == BF16 && rdt == F32)
-        return launch_final_t<bf16_t, float>(h, res, w, emb_f32, comp8, hidden_out, logits_out, B, L, D, eps, pos, s);
+        return launch_final_t<bf16_t, float>(h, res, w, emb_f32, comp8, hidden_out, logits_out, B, L, D, eps, pos, pos_per_seq, s);
     if (dt == BF16 && rdt == BF16)
-        return launch_final_t<bf16_t, bf16_t>(h, res, w, emb_f32, comp8, hidden_out, logits_out, B, L, D, eps, pos, s);
+        return launch_final_t<bf16_t, bf16_t>(h, res, w, emb_f32, comp8, hidden_out, logits_out, B, L, D, eps, pos, pos_per_seq, s);
     if (dt == F32 && rdt == F32)
-        return launch_final_t<float, float>(h, res, w, emb_f32, comp8, hidden_out, logits_out, B, L, D, eps, pos, s);
+        return launch_final_t<float, float>(h, res, w, emb_f32, comp8, hidden_out, logits_out, B, L, D, eps, pos, pos_per_seq, s);
     return hipErrorInvalidValue;
 }
 

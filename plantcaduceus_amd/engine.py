@@ -48,6 +48,8 @@ SIGNATURES = {
     "pcad_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int, C.c_int]),
     "pcad_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int32), C.c_int,
                                C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "pcad_forward_at": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                  C.c_void_p, C.c_size_t, C.c_void_p]),
     "pcad_forward_all_hidden": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                           C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "pcad_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
@@ -173,9 +175,11 @@ class Engine:
         base = self._aligned(self._ws)
         return base, self._ws.numel() - (base - self._ws.data_ptr())
 
-    def forward(self, input_ids: torch.Tensor, positions: Optional[Sequence[int]] = None,
+    def forward(self, input_ids: torch.Tensor, positions=None,
                 want_hidden: bool = False, want_logits: bool = True, all_hidden: bool = False):
-        """ids [B, L] (any int dtype, on this device) -> (logits fp32 [B,Q,8] | None, hidden [B,Q,2D] | None[, all])."""
+        """ids [B, L] (any int dtype, on this device) -> (logits fp32 [B,Q,8] | None, hidden [B,Q,2D] | None[, all]).
+        positions: None (all L), a short list shared by every window, or an integer tensor [B] on this device
+        (one position per window, Q = 1)."""
         _require_gpu(input_ids, "input_ids")
         if input_ids.dim() != 2:
             raise ValueError(f"input_ids must be [B, L], got {tuple(input_ids.shape)}")
@@ -184,8 +188,14 @@ class Engine:
         ids = input_ids.to(torch.int32).contiguous()
         B, L = ids.shape
         D = self.config.d_model
+        per_seq = None
+        if torch.is_tensor(positions):
+            if positions.dim() != 1 or positions.shape[0] != B or positions.device != self.device:
+                raise ValueError("per-window positions must be an integer tensor [B] on the engine's device")
+            per_seq = positions.to(torch.int32).contiguous()
+            positions = None
         P = 0 if positions is None else len(positions)
-        Q = P if P else L
+        Q = 1 if per_seq is not None else (P if P else L)
         with torch.cuda.device(self.device):
             logits = torch.empty((B, Q, 8), dtype=torch.float32, device=self.device) if want_logits else None
             hidden = torch.empty((B, Q, 2 * D), dtype=self.dtype, device=self.device) if want_hidden else None
@@ -195,12 +205,16 @@ class Engine:
             lp = logits.data_ptr() if logits is not None else None
             hp = hidden.data_ptr() if hidden is not None else None
             if all_hidden:
-                if positions is not None:
+                if positions is not None or per_seq is not None:
                     raise ValueError("all_hidden requires positions=None")
                 allh = torch.empty((self.config.n_layer, B, L, 2 * D), dtype=self.dtype, device=self.device)
                 _check(self.lib.pcad_forward_all_hidden(self._h, ids.data_ptr(), B, L, allh.data_ptr(), hp, lp, ws,
                                                         ws_bytes, _stream_ptr()), "pcad_forward_all_hidden")
                 return logits, hidden, allh
+            if per_seq is not None:
+                _check(self.lib.pcad_forward_at(self._h, ids.data_ptr(), B, L, per_seq.data_ptr(), hp, lp, ws, ws_bytes,
+                                                _stream_ptr()), "pcad_forward_at")
+                return logits, hidden
             pos_arr = (C.c_int32 * P)(*[int(p) for p in positions]) if P else None
             _check(self.lib.pcad_forward(self._h, ids.data_ptr(), B, L, pos_arr, P, hp, lp, ws, ws_bytes,
                                          _stream_ptr()), "pcad_forward")

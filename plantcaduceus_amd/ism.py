@@ -1,0 +1,94 @@
+"""In-silico mutagenesis sweeps — the workload of reference `pipelines/in-silico-mutagenesis/` run through
+`src/zero_shot_score.py -input-vcf` (pipelines/in-silico-mutagenesis/README.md:56-64).
+
+The reference pipeline writes one VCF row per (position, alt != ref) (`1_simulation.R:85-100`) and
+`seq_from_vcf` turns every ROW into its own masked window and forward (`src/zero_shot_score.py:189-201`), although
+the three alt rows of a position share an identical masked input.  Here one masked forward per POSITION yields all
+four nucleotide probabilities, so the three scores log(p_alt / p_ref) come from one forward (3x fewer forwards for
+the same output), and the position to read is passed per window (`pcad_forward_at`).
+
+  sweep_window(model, seq, tokenizer, device)          every position of ONE window masked in turn -> probs [L, 4]
+  sweep_region(model, chrom_seq, start, stop, ...)     reference semantics: a window centred (tokenIdx 255) on every
+                                                      position of [start, stop) -> probs [n, 4]
+  ism_scores(probs, ref_bases)                         -> [n, 4] log(p_alt / p_ref), 0 for alt == ref, NaN where the
+                                                      reference base is not A/C/G/T
+"""
+from __future__ import annotations
+
+import logging
+from typing import Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import sharding
+from .zero_shot import NUCLEOTIDES, extract_logits, tokenize_masked, window_for
+
+
+def _acgt_cols(tokenizer):
+    v = tokenizer.get_vocab()
+    return [v[c] for c in "acgt"]
+
+
+def sweep_window(model, seq: str, tokenizer, device, positions: Optional[Sequence[int]] = None,
+                 batch_size: int = 256) -> np.ndarray:
+    """Mask every position (or `positions`) of one window in turn: fp32 [n_pos, 4] = softmax over a,c,g,t of the
+    logits AT the masked position.  n_pos forwards of the same window with different masks (the network is
+    bi-directional, so nothing is shared between them)."""
+    ids = torch.from_numpy(tokenize_masked([seq], tokenizer, None)[0].astype(np.int64))
+    L = ids.shape[0]
+    pos_all = torch.arange(L) if positions is None else torch.as_tensor(list(positions), dtype=torch.long)
+    n_total = pos_all.shape[0]
+    cols = _acgt_cols(tokenizer)
+    rank, ws = sharding.world()
+    start, stop, per = sharding.shard_bounds(n_total, rank, ws)
+    pos_local = sharding.pad_rows(pos_all[start:stop], per) if ws > 1 else pos_all
+    per_seq = bool(getattr(model, "supports_positions", False))
+    outs = []
+    with torch.inference_mode():
+        for b0 in range(0, pos_local.shape[0], batch_size):
+            p = pos_local[b0:b0 + batch_size]
+            cur = ids.unsqueeze(0).repeat(p.shape[0], 1)
+            cur[torch.arange(p.shape[0]), p] = tokenizer.mask_token_id
+            cur = cur.to(device)
+            if per_seq:
+                lg = model(input_ids=cur, positions=p.to(device)).logits[:, 0, :]
+            else:
+                lg = model(input_ids=cur).logits[torch.arange(p.shape[0]), p.to(device) if str(device) != "cpu" else p, :]
+            outs.append(torch.softmax(lg[:, cols].float(), dim=1))
+        probs = torch.cat(outs, dim=0) if outs else torch.empty((0, 4), dtype=torch.float32, device=device)
+        probs = sharding.all_gather_rows(probs, n_total)
+    return probs.cpu().numpy()
+
+
+def sweep_region(model, chrom_seq: str, start: int, stop: int, tokenizer, device, tokenIdx: int = 255,
+                 batch_size: int = 128) -> np.ndarray:
+    """Reference semantics (one record per position, window [pos - tokenIdx, pos + 512 - tokenIdx), N padded at the
+    chromosome ends): fp32 [stop - start, 4] probabilities of the masked centre base."""
+    logging.info(f"ISM sweep over {stop - start} positions")
+    seqs = [window_for(chrom_seq, p, tokenIdx) for p in range(start, stop)]
+    return extract_logits(model, seqs, device, tokenIdx, tokenizer, batch_size)
+
+
+def ism_scores(probs: np.ndarray, ref_bases: Sequence[str]) -> np.ndarray:
+    """[n, 4] log(p_alt / p_ref) in A,C,G,T order (reference score, src/zero_shot_score.py:124-134)."""
+    probs = np.asarray(probs, dtype=np.float64)
+    out = np.full(probs.shape, np.nan)
+    for i, r in enumerate(ref_bases):
+        r = r.upper()
+        if r in NUCLEOTIDES:
+            out[i] = np.log(probs[i] / probs[i, NUCLEOTIDES.index(r)])
+    return out
+
+
+def write_ism_vcf(path: str, chrom: str, start: int, ref_bases: Sequence[str], scores: np.ndarray):
+    """One row per (position, alt != ref) like `1_simulation.R:110-127` emits, with the score in INFO."""
+    with open(path, "w") as f:
+        f.write("##fileformat=VCFv4.2\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\n")
+        for i, r in enumerate(ref_bases):
+            r = r.upper()
+            if r not in NUCLEOTIDES:
+                continue
+            for k, a in enumerate(NUCLEOTIDES):
+                if a != r:
+                    f.write(f"{chrom}\t{start + i + 1}\t.\t{r}\t{a}\t.\t.\tplantCAD_zero_shot={scores[i, k]}\n")
