@@ -148,17 +148,18 @@ static void linear_micro(const float* A, int lda, const float* W, int K, float* 
 }
 
 static void linear_nt(const float* A, int lda, const float* W, int K, float* C, int ldc, int M, int N) {
-    enum { MB = 32, NB = 32 };
+    /* one work item = MB rows x NB weight rows: the item's A block (MB*K floats) and weight panel (NB*K floats)
+     * both stay in a core's L2 while its 4x4 micro-tiles are walked, so each is fetched once per item */
+    enum { MB = 64, NB = 64 };
     const int nib = (M + MB - 1) / MB, njb = (N + NB - 1) / NB;
-    /* static schedule over (weight panel, row block): a thread's consecutive items share the weight panel */
-#pragma omp parallel for collapse(2) schedule(static)
-    for (int jbi = 0; jbi < njb; ++jbi) {
-        for (int ibi = 0; ibi < nib; ++ibi) {
+#pragma omp parallel for collapse(2) schedule(dynamic, 1)
+    for (int ibi = 0; ibi < nib; ++ibi) {
+        for (int jbi = 0; jbi < njb; ++jbi) {
             const int jb = jbi * NB, ib = ibi * MB;
             const int je = jb + NB < N ? jb + NB : N;
             const int ie = ib + MB < M ? ib + MB : M;
-            for (int i0 = ib; i0 < ie; i0 += 4)
-                for (int j0 = jb; j0 < je; j0 += 4)
+            for (int j0 = jb; j0 < je; j0 += 4)
+                for (int i0 = ib; i0 < ie; i0 += 4)
                     linear_micro(A + (size_t)i0 * lda, lda, W + (size_t)j0 * K, K, C + (size_t)i0 * ldc + j0, ldc,
                                  ie - i0 < 4 ? ie - i0 : 4, je - j0 < 4 ? je - j0 : 4);
         }
@@ -283,6 +284,7 @@ int oracle_forward(const oracle_model* m, const int32_t* ids, int B, int L, floa
             conv_silu(xz, ly->conv_w[d], ly->conv_b[d], xc, S, L, E, d);
             linear_nt(xc, E, ly->x_proj[d], E, dbl, XP, (int)rows, XP);
             linear_nt(dbl, XP, ly->dt_w[d], R, delta, E, (int)rows, E);
+#pragma omp parallel for schedule(static)
             for (int i = 0; i < E * NST; ++i) A[i] = -expf(ly->A_log[d][i]);
             scan_dir(xc, delta, dbl, xz, A, ly->dt_b[d], ly->Dskip[d], y, S, L, E, R, d);
         }
