@@ -39,6 +39,8 @@ def parse():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--cpu-seqs", type=int, default=-1, help="sample size for the CPU baseline (0 = skip)")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--profile-stride", type=int, default=8,
+                    help="HIP events around every N-th launch of each kernel class during the timed region")
     return ap.parse_args()
 
 
@@ -118,7 +120,7 @@ def main():
     for _ in range(args.warmup):
         out = step()
     if not args.no_profile:
-        eng.profile(True)
+        eng.profile(max(1, args.profile_stride))
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -155,11 +157,15 @@ def main():
         for name, (n, ms) in stats.items():
             if n:
                 avg = ms / n
-                kern[name] = {"launches": n, "total_ms": round(ms, 3), "avg_ms": round(avg, 5),
+                kern[name] = {"timed_launches": n, "timed_ms": round(ms, 3), "avg_ms": round(avg, 5),
                               "TFLOP/s": round(work[name]["flops"] / (avg * 1e-3) / 1e12, 2),
                               "GB/s": round(work[name]["bytes"] / (avg * 1e-3) / 1e9, 1)}
         if kern:
-            dom = max(kern, key=lambda k: kern[k]["total_ms"])
+            per_step = {"add_rmsnorm": 1, "gemm_in_proj": 1, "conv1d_bidir": 1, "gemm_x_proj": 2, "selective_scan": 2,
+                        "gemm_out_proj": 1, "final_head": 0}     # launches per layer and chunk
+            for name in kern:
+                kern[name]["est_ms_per_step"] = round(kern[name]["avg_ms"] * per_step.get(name, 0) * cfg.n_layer * nchunks, 2)
+            dom = max(kern, key=lambda k: kern[k]["est_ms_per_step"])
             avg_s = kern[dom]["avg_ms"] * 1e-3
             if dom.startswith("gemm"):
                 a = work[dom]["flops"] / avg_s / 1e12
@@ -189,7 +195,9 @@ def main():
                         res["roofline"]["traffic_source"] = os.path.basename(pm[-1])
             except Exception:
                 pass
-            res["roofline"]["share_of_gpu_time"] = kern[dom]["total_ms"] / sum(k["total_ms"] for k in kern.values())
+            res["roofline"]["share_of_gpu_time"] = kern[dom]["est_ms_per_step"] / max(1e-9, sum(k["est_ms_per_step"] for k in kern.values()))
+            res["roofline"]["timing"] = ("HIP events on the launch stream around every %d-th launch of the class during the "
+                                         "timed region" % max(1, args.profile_stride))
             res["kernels"] = kern
         # ---- host-CPU baseline: the oracle port, same model / same kind of input, bounded sample ------
         ncpu = args.cpu_seqs
@@ -199,7 +207,7 @@ def main():
                 co = COracle(sd, cfg)
                 threads = co.threads
                 if ncpu < 0:
-                    ncpu = max(2, threads // 8)                   # bounded sample: ~10-30 s of all-core CPU work
+                    ncpu = max(2, threads // 16)                  # bounded sample: ~10-30 s of all-core CPU work
                 sample = ids_np[:ncpu]
                 t1 = time.perf_counter()
                 lg, _ = co.forward(sample)

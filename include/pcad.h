@@ -129,7 +129,8 @@ typedef struct pcad_kernel_stat {
     int64_t launches;
     double  total_ms;           /* sum of (stop - start) event times of this class's launches */
 } pcad_kernel_stat;
-/* When on, every launch of pcad_forward is bracketed by a pair of hipEvents recorded on `stream`. */
+/* on = 0: off; on = 1: every launch of pcad_forward is bracketed by a pair of hipEvents recorded on its stream;
+ * on = N > 1: every N-th launch of each kernel class is (a sample over the same region at 1/N of the event overhead). */
 int pcad_profile_enable(pcad_handle h, int on);
 /* Waits for the recorded events, writes one entry per kernel class (<= max_out), resets the counters.
  * Returns the number of entries written (>= 0) or a negative status. */

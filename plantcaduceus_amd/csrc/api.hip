@@ -73,6 +73,8 @@ struct pcad_engine {
     int32_t* comp = nullptr;    // [8] device
     // optional per-kernel-class timing with HIP events recorded on the caller's stream
     bool prof = false;
+    int prof_stride = 1;                                  // bracket every prof_stride-th launch of a class
+    int64_t prof_seen[PCAD_NUM_KERNEL_CLASSES] = {0};
     std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_ev[PCAD_NUM_KERNEL_CLASSES];
     std::vector<hipEvent_t> prof_pool;
     double prof_ms[PCAD_NUM_KERNEL_CLASSES] = {0};
@@ -160,7 +162,10 @@ hipEvent_t prof_event(pcad_engine* e) {
 struct ProfScope {   // records start/stop events around one launch when profiling is on
     pcad_engine* e; int cls; hipStream_t s; hipEvent_t a = nullptr, b = nullptr;
     ProfScope(pcad_engine* e_, int cls_, hipStream_t s_) : e(e_), cls(cls_), s(s_) {
-        if (e->prof) { a = prof_event(e); b = prof_event(e); if (a) (void)hipEventRecord(a, s); }
+        if (e->prof && (e->prof_seen[cls]++ % e->prof_stride) == 0) {
+            a = prof_event(e); b = prof_event(e);
+            if (a) (void)hipEventRecord(a, s);
+        }
     }
     ~ProfScope() {
         if (a && b) { (void)hipEventRecord(b, s); e->prof_ev[cls].push_back({a, b}); }
@@ -508,6 +513,8 @@ int pcad_forward_all_hidden(pcad_handle h, const int32_t* ids, int B, int L, voi
 int pcad_profile_enable(pcad_handle h, int on) {
     if (!h) return fail(PCAD_ERR_INVALID, "pcad_profile_enable: null handle");
     h->prof = on != 0;
+    h->prof_stride = on > 1 ? on : 1;
+    for (int c = 0; c < PCAD_NUM_KERNEL_CLASSES; ++c) h->prof_seen[c] = 0;
     return PCAD_OK;
 }
 

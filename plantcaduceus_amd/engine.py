@@ -220,7 +220,8 @@ class Engine:
                                          _stream_ptr()), "pcad_forward")
         return logits, hidden
 
-    def profile(self, on: bool):
+    def profile(self, on):
+        """False/0: off; True/1: HIP events around every launch; N > 1: around every N-th launch of each kernel class."""
         _check(self.lib.pcad_profile_enable(self._h, int(on)), "pcad_profile_enable")
 
     def profile_read(self):

@@ -1,13 +1,17 @@
-"""developer tool: time pcad_gemm_nt on the in_proj / out_proj shapes (optionally under PCAD_GEMM_ABLATE)."""
+"""developer tool: time pcad_gemm_nt on the in_proj / out_proj shapes and check it against torch."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from plantcaduceus_amd import ops
 for (M, N, K) in [(65536, 4096, 1024), (65536, 1024, 2048)]:
     x = torch.randn(M, K, device="cuda").bfloat16(); w = (torch.randn(N, K, device="cuda") / K ** 0.5).bfloat16()
-    for _ in range(3): ops.linear(x, w)
+    out = ops.linear(x, w)
+    ref = (x[:4096].float() @ w.float().t())
+    err = ((out[:4096].float() - ref).abs().max() / ref.abs().max()).item()
+    ref2 = (x[-512:].float() @ w.float().t())
+    err2 = ((out[-512:].float() - ref2).abs().max() / ref2.abs().max()).item()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize(); a.record()
     for _ in range(20): ops.linear(x, w)
     b.record(); torch.cuda.synchronize()
     ms = a.elapsed_time(b) / 20
-    print(f"abl={os.environ.get('PCAD_GEMM_ABLATE','0')} M={M} N={N} K={K}: {ms:.4f} ms  {2.0*M*N*K/ms/1e9:.0f} TF")
+    print(f"no256={os.environ.get('PCAD_GEMM_NO256','')} M={M} N={N} K={K}: {ms:.4f} ms  {2.0*M*N*K/ms/1e9:.0f} TF  relerr {err:.2e} {err2:.2e}")
