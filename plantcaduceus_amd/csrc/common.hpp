@@ -30,12 +30,14 @@ template <typename T> struct Elem;
 template <> struct Elem<float> {
     static __device__ __forceinline__ float load(const float* p) { return *p; }
     static __device__ __forceinline__ float to_f32(float v) { return v; }
+    static __device__ __forceinline__ float from_f32(float v) { return v; }
     static __device__ __forceinline__ void store(float* p, float v) { *p = v; }
     static __device__ __forceinline__ float round(float v) { return v; }
 };
 template <> struct Elem<bf16_t> {
     static __device__ __forceinline__ float load(const bf16_t* p) { return bf16_to_f32(*p); }
     static __device__ __forceinline__ float to_f32(bf16_t v) { return bf16_to_f32(v); }
+    static __device__ __forceinline__ bf16_t from_f32(float v) { return f32_to_bf16(v); }
     static __device__ __forceinline__ void store(bf16_t* p, float v) { *p = f32_to_bf16(v); }
     static __device__ __forceinline__ float round(float v) { return round_to_bf16(v); }
 };
@@ -82,21 +84,18 @@ constexpr float kLn2 = 0.6931471805599453f;
 // silu(v) = v / (1 + exp(-v))
 __device__ __forceinline__ float silu(float v) { return v * fast_rcp(1.0f + fast_exp2(-v * kLog2e)); }
 
-// softplus with torch's threshold (20): log1p(e), e = exp(x).  For e < 2^-4 a 6-term alternating series
-// (truncation e^6/7 < 1e-8 relative) keeps full fp32 relative accuracy for small time-steps (softplus(-7) ~ 1e-3)
-// where log(1 + e) would lose it to the rounding of 1 + e; above, log2(1 + e) is accurate to < 1e-6 relative.
-// 2 transcendentals (v_exp_f32, v_log_f32) + 8 plain ops.
+// softplus with torch's threshold (20): log1p(e), e = exp(x).  For e < 2^-6 the series e - e^2/2 + e^3/3
+// (truncation e^3/4 < 1e-6 relative) keeps full relative accuracy for small time-steps (softplus(-7) ~ 1e-3) where
+// log(1 + e) would lose it to the rounding of 1 + e; above, log2(1 + e) is accurate to < 4e-6 relative.
+// 2 transcendentals (v_exp_f32, v_log_f32) + 6 plain ops.
 __device__ __forceinline__ float softplus(float x) {
     const float e = fast_exp2(x * kLog2e);
     const float big = fast_log2(1.0f + e) * kLn2;
-    float p = -1.0f / 6.0f;
-    p = p * e + 0.2f;
-    p = p * e - 0.25f;
-    p = p * e + (1.0f / 3.0f);
+    float p = 1.0f / 3.0f;
     p = p * e - 0.5f;
     p = p * e + 1.0f;
     const float small = p * e;
-    const float l = e < 0.0625f ? small : big;
+    const float l = e < 0.015625f ? small : big;
     return x > 20.0f ? x : l;
 }
 

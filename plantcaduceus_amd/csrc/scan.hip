@@ -39,6 +39,30 @@ constexpr int CH = 4;     // timesteps per prefetch chunk
 
 __device__ __forceinline__ float exp2_hw(float x) { return __builtin_amdgcn_exp2f(x); }
 
+// Row accesses through a wave-uniform buffer descriptor: SGPR row offset + constant per-lane byte offset, so a load
+// or store costs no VALU address arithmetic (buffer_load_ushort v, v_lane, s[rsrc], s_row offen).
+typedef __attribute__((address_space(8))) void* rsrc_t;
+__device__ __forceinline__ auto make_rsrc(const void* base, uint32_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
+}
+template <typename T> struct BufIO;
+template <> struct BufIO<bf16_t> {
+    template <typename R> static __device__ __forceinline__ bf16_t load(R r, int voff, uint32_t soff) {
+        return (bf16_t)__builtin_amdgcn_raw_buffer_load_b16(r, voff, (int)soff, 0);
+    }
+    template <typename R> static __device__ __forceinline__ void store(bf16_t v, R r, int voff, uint32_t soff) {
+        __builtin_amdgcn_raw_buffer_store_b16(v, r, voff, (int)soff, 0);
+    }
+};
+template <> struct BufIO<float> {
+    template <typename R> static __device__ __forceinline__ float load(R r, int voff, uint32_t soff) {
+        return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, voff, (int)soff, 0));
+    }
+    template <typename R> static __device__ __forceinline__ void store(float v, R r, int voff, uint32_t soff) {
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, voff, (int)soff, 0);
+    }
+};
+
 // ---- delta tile: acc[half][r] <- sum_k dtl[t0 + tt][k] * Wdt[c][k],  tt = (r&3) + 8*(r>>2) + 4*half ------
 // After the MFMAs lane l holds column (l & 31) of channel tile q (channels 32q..32q+31) for the rows
 // 4*(l>>5) + {0..3, 8..11, 16..19, 24..27}; swapping the upper half of tile 0 with the lower half of tile 1
@@ -152,13 +176,14 @@ __global__ __launch_bounds__(64, 4) void scan_kernel(const T* __restrict__ u, co
     // Steps past the end of the sequence (last chunk when L % CH != 0) run on clamped rows and only their store
     // is suppressed, which keeps the chunk body branch-free.
     // Wave-uniform per-strand bases + 32-bit in-strand offsets (L * ld < 2^31): SGPR base, lane offset in a VGPR.
-    const T* __restrict__ u_s = u + row0 * E + c0;
-    const T* __restrict__ z_s = HASZ ? z + row0 * ldz + c0 : nullptr;
-    const T* __restrict__ d_s = FUSED ? nullptr : dsrc + row0 * ldd + c0;
-    const T* yin_s = ACC ? yin + row0 * E + c0 : nullptr;
-    T* y_s = y + row0 * E + c0;
+    const uint32_t esz = (uint32_t)sizeof(T);
+    const auto u_r = make_rsrc(u + row0 * E + c0, (uint32_t)L * (uint32_t)E * esz);
+    const auto z_r = make_rsrc(HASZ ? z + row0 * ldz + c0 : u, (uint32_t)L * (uint32_t)ldz * esz);
+    const auto d_r = make_rsrc(FUSED ? u : dsrc + row0 * ldd + c0, (uint32_t)L * (uint32_t)ldd * esz);
+    const auto y_r = make_rsrc(y + row0 * E + c0, (uint32_t)L * (uint32_t)E * esz);     // also the ACC input
     const float* __restrict__ bc_s = bc + row0 * (2 * NSTATE);
-    const uint32_t ldz32 = (uint32_t)ldz, ldd32 = (uint32_t)ldd;
+    const uint32_t rowE = (uint32_t)E * esz, rowZ = (uint32_t)ldz * esz, rowD = (uint32_t)ldd * esz;
+    const int voff = lane * (int)esz;
 
     T ub[CH], zb[CH], yb[CH], dr[CH];      // RAW prefetched values: converted at use, so no early vmcnt wait
     auto tclamp = [&](int s) { const int sc = min(s, L - 1); return REV ? (L - 1 - sc) : sc; };
@@ -166,10 +191,10 @@ __global__ __launch_bounds__(64, 4) void scan_kernel(const T* __restrict__ u, co
 #pragma unroll
         for (int i = 0; i < CH; ++i) {
             const uint32_t t = (uint32_t)tclamp(s0 + i);
-            uu[i] = (u_s + t * (uint32_t)E)[lane];
-            if constexpr (HASZ) zz[i] = (z_s + t * ldz32)[lane];
-            if constexpr (ACC) yy[i] = (yin_s + t * (uint32_t)E)[lane];
-            if constexpr (!FUSED) dd[i] = (d_s + t * ldd32)[lane];
+            uu[i] = BufIO<T>::load(u_r, voff, t * rowE);
+            if constexpr (HASZ) zz[i] = BufIO<T>::load(z_r, voff, t * rowZ);
+            if constexpr (ACC) yy[i] = BufIO<T>::load(y_r, voff, t * rowE);
+            if constexpr (!FUSED) dd[i] = BufIO<T>::load(d_r, voff, t * rowD);
         }
     };
     load_chunk(0, ub, zb, yb, dr);
@@ -192,8 +217,8 @@ __global__ __launch_bounds__(64, 4) void scan_kernel(const T* __restrict__ u, co
         float dv, dv_next = 0.f;
         if constexpr (FUSED) {
             dv = dv_cur;
-            const int idx = (int)t - tb0 + (REV ? -1 : 1);          // next step's row of the slab (same block)
-            dv_next = dvs[max(0, min(TB - 1, idx))][lane];
+            // next step's row of the slab; wraps at the end of the block, where the value is never used
+            dv_next = dvs[((int)t - tb0 + (REV ? -1 : 1)) & (TB - 1)][lane];
         } else {
             dv = softplus(Elem<T>::to_f32(draw) + db);
         }
@@ -213,9 +238,8 @@ __global__ __launch_bounds__(64, 4) void scan_kernel(const T* __restrict__ u, co
         const f2 yacc = yacc0 + yacc1;
         float yv = yacc[0] + yacc[1];
         if constexpr (HASZ) yv *= silu(Elem<T>::to_f32(zraw));
-        yv = Elem<T>::round(yv);
-        if constexpr (ACC) yv += Elem<T>::to_f32(yraw);
-        Elem<T>::store(y_s + t * (uint32_t)E + lane, yv);
+        if constexpr (ACC) yv = Elem<T>::round(yv) + Elem<T>::to_f32(yraw);    // each direction is rounded, then summed
+        BufIO<T>::store(Elem<T>::from_f32(yv), y_r, voff, t * rowE);
 #pragma unroll
         for (int p = 0; p < NSTATE; ++p) bcc[p] = bcn[p];
         dv_cur = dv_next;
@@ -292,6 +316,7 @@ hipError_t launch_scan(const void* u, const void* z, int64_t ldz, const void* de
                        hipStream_t s) {
     if (S <= 0 || L <= 0) return hipSuccess;
     if (E % 64) return hipErrorInvalidValue;
+    if ((int64_t)L * (ldz > E ? ldz : E) * 4 >= ((int64_t)1 << 31)) return hipErrorInvalidValue;   // 32-bit in-strand offsets
     const bool fused = delta == nullptr;
     if (fused && (!dt_low || !Wdt || Rp <= 0 || Rp % 64)) return hipErrorInvalidValue;
     if (dt == BF16) {

@@ -13,7 +13,7 @@ from typing import Dict, Optional, Sequence
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpcad.so")
+LIB_PATH = os.environ.get("PCAD_LIB") or os.path.join(_HERE, "libpcad.so")   # PCAD_LIB: developer A/B of two builds
 CSRC = os.path.join(_HERE, "csrc")
 
 PCAD_F32, PCAD_BF16 = 0, 1
