@@ -148,7 +148,7 @@ def main():
                                    % (args.model, cfg.d_model, cfg.n_layer, args.dtype, B, L, p),
                        "batch_per_gpu": B, "seq_len": L, "parallelism": "dp%d (batch-sharded, all_gather of [B,4])" % world},
         }
-        chunk_max = int(os.environ.get("PCAD_CHUNK_SEQS", "64"))
+        chunk_max = int(os.environ.get("PCAD_CHUNK_SEQS", str(-(-131072 // cfg.d_inner))))
         nchunks = -(-B // chunk_max)
         chunk = -(-B // nchunks)                                  # even split, as pcad_forward does
         rows = 2 * chunk * L

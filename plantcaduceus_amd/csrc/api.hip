@@ -211,8 +211,9 @@ int pcad_create(const pcad_config* cfg, pcad_handle* out) {
     e->esz = cfg->dtype == PCAD_BF16 ? 2 : 4;
     e->rdt = (cfg->residual_in_fp32 || cfg->dtype == PCAD_F32) ? F32 : BF16;
     const char* ck = getenv("PCAD_CHUNK_SEQS");
-    // 64 windows = 128 strands x E/64 waves = 4096 waves at E = 2048: exactly 4 waves per SIMD, the scan's occupancy
-    e->chunk = ck ? atoi(ck) : 64;
+    // windows per chunk such that the scan launch (2 strands x E/64 waves per window) is 4096 waves = 4 per SIMD, its
+    // occupancy: 64 at l32 (E = 2048), 85 at l28, 128 at l24, 170 at l20
+    e->chunk = ck ? atoi(ck) : (131072 + e->E - 1) / e->E;
     if (e->chunk < 1) e->chunk = 1;
     const char* ns = getenv("PCAD_STREAMS");
     // default 1: measured on MI355X (r01d) two lanes give 851 vs 852 seq/s -- co-running a VALU-bound scan and an

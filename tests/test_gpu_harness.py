@@ -87,3 +87,33 @@ def test_config3_l32_bf16_example_snps(golden_dir):
     top2 = np.sort(ref, 1)[:, -2:]
     conf = (top2[:, 1] - top2[:, 0]) > 6e-2
     assert (probs[:n].argmax(1)[conf] == ref.argmax(1)[conf]).all()
+
+
+def test_config2_l20_bf16_batch1024():
+    """BASELINE config 2: PlantCaduceus_l20 bf16, 1024 synthetic 512-bp windows (numpy default_rng(0)), mask at 255.
+    All rows: finite, normalised, reverse-complement equivariant.  A bounded sample against the CPU oracle port:
+    fp32 weights rounded to bf16, fp32 arithmetic (the bf16 path's noise is the tolerance)."""
+    from oracle.c_oracle import COracle
+    cfg = make_config("l20")
+    sd = synthetic_state_dict(cfg, seed=1234, stress=False)
+    m = hip_model(cfg, sd, torch.bfloat16)
+    tok = CaduceusTokenizer()
+    rng = np.random.default_rng(0)
+    ids = rng.integers(3, 7, size=(1024, 512)).astype(np.int32)
+    ids[:, 255] = tok.mask_token_id
+    probs = zero_shot.extract_logits(m, ids, DEV, 255, tok, batch_size=1024)
+    assert probs.shape == (1024, 4) and np.isfinite(probs).all()
+    np.testing.assert_allclose(probs.sum(1), 1.0, rtol=1e-5)
+    comp = np.array(cfg.complement_list(), dtype=np.int32)
+    rc = comp[ids[:, ::-1]]
+    probs_rc = zero_shot.extract_logits(m, np.ascontiguousarray(rc), DEV, 511 - 255, tok, batch_size=1024)[:, ::-1]
+    assert np.abs(probs_rc - probs).max() < 2e-2
+    n = 8
+    lg, _ = COracle(sd, cfg, dtype=torch.bfloat16).forward(ids[:n])
+    z = lg[:, 255, 3:7]
+    ref = np.exp(z - z.max(1, keepdims=True))
+    ref /= ref.sum(1, keepdims=True)
+    assert np.abs(probs[:n] - ref).max() < 3e-2
+    top2 = np.sort(ref, 1)[:, -2:]
+    conf = (top2[:, 1] - top2[:, 0]) > 6e-2
+    assert (probs[:n].argmax(1)[conf] == ref.argmax(1)[conf]).all()
