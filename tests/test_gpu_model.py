@@ -1,4 +1,5 @@
 """-m gpu: model-level parity of the HIP forward (through the C ABI + HF surface) vs the CPU oracle."""
+import numpy as np
 import pytest
 import torch
 
@@ -125,3 +126,23 @@ def test_no_cpu_fallback():
     m.load_state_dict(sd, strict=False)
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         m(input_ids=rand_ids(1, 16, 0))
+
+
+def test_long_window_8192():
+    """PlantCAD2-sized context (reference docs/zero-shot-eval.md:31,42: 8 192-bp windows, token_idx 4095): the
+    kernels are length-generic (time-sequential scan, sliding-window conv).  fp32, one l20-wide layer pair, against
+    the C oracle port."""
+    from oracle.c_oracle import COracle
+    cfg = make_config("x", d_model=384, n_layer=2)
+    sd = synthetic_state_dict(cfg, seed=17)
+    L = 8192
+    ids = rand_ids(2, L, 3, mask=4095)
+    m = build(cfg, sd, torch.float32)
+    out = m(input_ids=ids.to(DEV), output_hidden_states=True, positions=[4095, 0, L - 1])
+    lg_ref, hid_ref = COracle(sd, cfg).forward(ids.numpy(), want_hidden=True)
+    sel = [4095, 0, L - 1]
+    lg = out.logits.cpu().numpy()
+    assert np.abs(lg - lg_ref[:, sel]).max() / np.abs(lg_ref).max() < 1e-4
+    hid = out.hidden_states[-1].cpu().numpy()
+    assert np.abs(hid - hid_ref[:, sel]).max() / np.abs(hid_ref).max() < 1e-4
+    assert (lg[:, 0, 3:7].argmax(-1) == lg_ref[:, 4095, 3:7].argmax(-1)).all()
