@@ -63,6 +63,7 @@ struct pcad_engine {
     int rdt;        // residual dtype
     int chunk;      // sequences per pass through the layer stack
     int nstreams;   // 1: everything on the caller's stream; 2: chunks alternate between two library streams
+    bool blocked;   // xc and y in the blocked layout (common.hpp::blocked_off); PCAD_PLAIN_LAYOUT=1 turns it off (A/B knob)
     bool bound = false;
     hipStream_t aux[2] = {nullptr, nullptr};
     hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr}, ev_phase = nullptr;
@@ -134,13 +135,14 @@ Workspace carve_workspace(const pcad_engine* e, void* base, int Bc, int L) {
     w.u = c.take(rows * D * esz);
     w.h = c.take(rows * D * esz);
     w.xz = c.take(rows * 2 * E * esz);
-    w.xc[0] = c.take(rows * E * esz);
-    w.xc[1] = c.take(rows * E * esz);
+    const size_t rows8 = (rows + 7) / 8 * 8;   // xc and y use the blocked layout: whole 8-row blocks
+    w.xc[0] = c.take(rows8 * E * esz);
+    w.xc[1] = c.take(rows8 * E * esz);
     w.dtl[0] = c.take(rows * e->Rp * esz);     // dt_low (x_proj columns [0, Rp), zero padded past R)
     w.dtl[1] = c.take(rows * e->Rp * esz);
     w.bc[0] = (float*)c.take(rows * 2 * e->N * 4);   // B_t | C_t rows, fp32 (values rounded to the model dtype)
     w.bc[1] = (float*)c.take(rows * 2 * e->N * 4);
-    w.y = c.take(rows * E * esz);
+    w.y = c.take(rows8 * E * esz);
     w.bytes = c.off;
     return w;
 }
@@ -215,6 +217,7 @@ int pcad_create(const pcad_config* cfg, pcad_handle* out) {
     // occupancy: 64 at l32 (E = 2048), 85 at l28, 128 at l24, 170 at l20
     e->chunk = ck ? atoi(ck) : (131072 + e->E - 1) / e->E;
     if (e->chunk < 1) e->chunk = 1;
+    e->blocked = getenv("PCAD_PLAIN_LAYOUT") == nullptr && (e->E * e->esz) % 128 == 0;
     const char* ns = getenv("PCAD_STREAMS");
     // default 1: measured on MI355X (r01d) two lanes give 851 vs 852 seq/s -- co-running a VALU-bound scan and an
     // MFMA-bound GEMM slows each by the other's share (shared issue/power budget), so nothing is gained.
@@ -415,7 +418,7 @@ static int forward_impl(pcad_handle h, const int32_t* ids, int B, int L, const i
         // conv1d + SiLU, causal and anti-causal from one read of x
         { ProfScope ps(e, PCAD_K_CONV, s);
         HIP_TRY(launch_conv_bidir(c.w.xz, 2 * E, W.dir[0].conv_w, W.dir[0].conv_b, W.dir[1].conv_w, W.dir[1].conv_b,
-                                  c.w.xc[0], c.w.xc[1], S, L, E, dt, s)); }
+                                  c.w.xc[0], c.w.xc[1], S, L, E, dt, e->blocked, s)); }
         return PCAD_OK;
     };
     auto phase_V = [&](Lane& c, int li) -> int {        // x_proj + fused dt_proj/scan, both directions; out_proj
@@ -427,15 +430,16 @@ static int forward_impl(pcad_handle h, const int32_t* ids, int B, int L, const i
             const DirWeights& dw = W.dir[d];
             // x_proj -> dt_low [rows, Rp] (model dtype, zero padded) and B_t | C_t [rows, 32] (fp32 side output)
             { ProfScope ps(e, PCAD_K_GEMM_X, s);
-            HIP_TRY(launch_gemm_nt_split(c.w.xc[d], E, dw.Wx, E, c.w.dtl[d], Rp, c.w.bc[d], 2 * N, Rp, rows, XP, E, dt, s)); }
+            HIP_TRY(launch_gemm_nt_split(c.w.xc[d], E, dw.Wx, E, c.w.dtl[d], Rp, c.w.bc[d], 2 * N, Rp, rows, XP, E, dt, s,
+                                         e->blocked)); }
             // dt_proj (on MFMA inside the scan) + bias + softplus + recurrence + D skip + SiLU(z) gate
             ProfScope ps(e, PCAD_K_SCAN, s);
             HIP_TRY(launch_scan(c.w.xc[d], (const char*)c.w.xz + (size_t)E * esz, 2 * E, nullptr, c.w.dtl[d], Rp, dw.Wdt, Rp,
-                                c.w.bc[d], dw.A2, 1.0f, dw.Dskip, dw.dt_bias, c.w.y, S, L, E, d == 1, d == 1, dt, s));
+                                c.w.bc[d], dw.A2, 1.0f, dw.Dskip, dw.dt_bias, c.w.y, S, L, E, d == 1, d == 1, dt, s, e->blocked));
         }
         // out_proj on (y_fwd + y_rev): the two tied out_proj calls folded by linearity
         { ProfScope ps(e, PCAD_K_GEMM_OUT, s);
-        HIP_TRY(launch_gemm_nt(c.w.y, E, W.W_out, E, c.w.h, D, rows, D, E, dt, dt, false, s)); }
+        HIP_TRY(launch_gemm_nt(c.w.y, E, W.W_out, E, c.w.h, D, rows, D, E, dt, dt, false, s, e->blocked)); }
         if (all_hidden && li + 1 < e->nl) {
             char* dst = (char*)all_hidden + ((size_t)(li + 1) * B * L * 2 * D + (size_t)c.b0 * L * 2 * D) * esz;
             HIP_TRY(launch_assemble_hidden(c.w.h, dst, c.Bc, L, D, dt, s));
@@ -560,7 +564,7 @@ int pcad_causal_conv1d_silu(const void* x, int64_t ldx, const float* w_fwd, cons
     if (!x || !w_fwd || !b_fwd || !w_rev || !b_rev) return fail(PCAD_ERR_INVALID, "pcad_causal_conv1d_silu: null argument");
     if (S < 0 || L < 0 || E <= 0 || E % 8 || ldx < E || ldx % 8)
         return fail(PCAD_ERR_INVALID, "pcad_causal_conv1d_silu: bad shape (E and ldx must be multiples of 8)");
-    HIP_TRY(launch_conv_bidir(x, ldx, w_fwd, b_fwd, w_rev, b_rev, y_fwd, y_rev, S, L, E, dtype, (hipStream_t)stream));
+    HIP_TRY(launch_conv_bidir(x, ldx, w_fwd, b_fwd, w_rev, b_rev, y_fwd, y_rev, S, L, E, dtype, false, (hipStream_t)stream));
     return PCAD_OK;
 }
 

@@ -78,6 +78,14 @@ __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_ex
 __device__ __forceinline__ float fast_log2(float x) { return __builtin_amdgcn_logf(x); }    // v_log_f32
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }     // v_rcp_f32
 
+// "Blocked" activation layout used for the tensors that an MFMA GEMM streams as its A operand (xc, y):
+// [row / 8][k-piece][row % 8][128 bytes], k-piece = (byte offset in the row) / 128.  One 1 KiB LDS-DMA instruction of
+// the GEMM (8 rows x 128 B) then reads ONE contiguous 1 KiB block instead of 8 pieces from 8 DRAM rows.
+// byte offset of (row r, byte cb of the row) for rows of `pieces` x 128 bytes:
+__host__ __device__ __forceinline__ int64_t blocked_off(int64_t r, int64_t cb, int64_t pieces) {
+    return (((r >> 3) * pieces + (cb >> 7)) << 10) + ((r & 7) << 7) + (cb & 127);
+}
+
 constexpr float kLog2e = 1.4426950408889634f;
 constexpr float kLn2 = 0.6931471805599453f;
 

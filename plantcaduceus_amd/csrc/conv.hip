@@ -51,7 +51,8 @@ template <typename T>
 __global__ __launch_bounds__(256) void conv_bidir_kernel(const T* __restrict__ x, int64_t ldx,
                                                          const float* __restrict__ wf, const float* __restrict__ bfw,
                                                          const float* __restrict__ wr, const float* __restrict__ brw,
-                                                         T* __restrict__ yf, T* __restrict__ yr, int S, int L, int E) {
+                                                         T* __restrict__ yf, T* __restrict__ yr, int S, int L, int E,
+                                                         int out_blocked) {
     typedef typename Raw8<T>::type raw_t;
     const int nchunk = E >> 3;
     const int nseg = (L + CONV_SEG - 1) / CONV_SEG;
@@ -108,7 +109,9 @@ __global__ __launch_bounds__(256) void conv_bidir_kernel(const T* __restrict__ x
                     of[e] = silu(af);
                     orv[e] = silu(ar);
                 }
-                const int64_t o = ((int64_t)s * L + t + k) * E + c;
+                const int64_t orow = (int64_t)s * L + t + k;
+                const int64_t o = out_blocked ? blocked_off(orow, (int64_t)c * sizeof(T), ((int64_t)E * sizeof(T)) >> 7) / (int64_t)sizeof(T)
+                                              : orow * E + c;
                 if (yf != nullptr) store8<T>(yf + o, of);
                 if (yr != nullptr) store8<T>(yr + o, orv);
             }
@@ -121,18 +124,20 @@ __global__ __launch_bounds__(256) void conv_bidir_kernel(const T* __restrict__ x
 }
 
 hipError_t launch_conv_bidir(const void* x, int64_t ldx, const float* wf, const float* bf, const float* wr,
-                             const float* br, void* yf, void* yr, int S, int L, int E, int dt, hipStream_t s) {
+                             const float* br, void* yf, void* yr, int S, int L, int E, int dt, bool out_blocked,
+                             hipStream_t s) {
     if (S <= 0 || L <= 0) return hipSuccess;
     if (E % 8) return hipErrorInvalidValue;
+    if (out_blocked && (E * (dt == BF16 ? 2 : 4)) % 128) return hipErrorInvalidValue;
     const int64_t total = (int64_t)S * ((L + CONV_SEG - 1) / CONV_SEG) * (E >> 3);
     const int64_t nb = (total + 255) / 256;
     if (nb > 0x7fffffff) return hipErrorInvalidValue;
     if (dt == BF16)
         hipLaunchKernelGGL(conv_bidir_kernel<bf16_t>, dim3((unsigned)nb), dim3(256), 0, s, (const bf16_t*)x, ldx, wf,
-                           bf, wr, br, (bf16_t*)yf, (bf16_t*)yr, S, L, E);
+                           bf, wr, br, (bf16_t*)yf, (bf16_t*)yr, S, L, E, (int)out_blocked);
     else
         hipLaunchKernelGGL(conv_bidir_kernel<float>, dim3((unsigned)nb), dim3(256), 0, s, (const float*)x, ldx, wf, bf,
-                           wr, br, (float*)yf, (float*)yr, S, L, E);
+                           wr, br, (float*)yf, (float*)yr, S, L, E, (int)out_blocked);
     return hipGetLastError();
 }
 

@@ -71,7 +71,8 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_kernel(const T* __res
                                                                   const T* __restrict__ W, int64_t ldw,
                                                                   OutT* __restrict__ C, int64_t ldc, int64_t M, int N,
                                                                   int K, int tiles_m, int tiles_n,
-                                                                  float* __restrict__ C2, int64_t ldc2, int nsplit) {
+                                                                  float* __restrict__ C2, int64_t ldc2, int nsplit,
+                                                                  int a_blocked) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -103,7 +104,8 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_kernel(const T* __res
         for (int i = 0; i < 4; ++i) {
             const int row = wave * 32 + i * 8 + (lane >> 3);
             int64_t ga = m0 + row; if (ga > M - 1) ga = M - 1;
-            pa[i] = reinterpret_cast<const char*>(A + ga * lda) + (((lane & 7) ^ key_a(row)) << 4);
+            const int64_t abyte = a_blocked ? blocked_off(ga, 0, (lda * (int64_t)sizeof(T)) >> 7) : ga * lda * (int64_t)sizeof(T);
+            pa[i] = reinterpret_cast<const char*>(A) + abyte + (((lane & 7) ^ key_a(row)) << 4);
         }
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -116,8 +118,9 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_kernel(const T* __res
         char* as = smem + st * STAGE_BYTES + (wave * 32) * ROWB;
         char* ws = smem + st * STAGE_BYTES + A_BYTES + (wave * 16) * ROWB;
         const int64_t ko = (int64_t)kt * ROWB;
+        const int64_t koa = a_blocked ? (int64_t)kt * 1024 : ko;     // blocked A: consecutive k-pieces are 1 KiB apart
 #pragma unroll
-        for (int i = 0; i < 4; ++i) glds16(pa[i] + ko, as + i * 8 * ROWB);
+        for (int i = 0; i < 4; ++i) glds16(pa[i] + koa, as + i * 8 * ROWB);
 #pragma unroll
         for (int i = 0; i < 2; ++i) glds16(pw[i] + ko, ws + i * 8 * ROWB);
     };
@@ -300,7 +303,7 @@ template <typename T, typename OutT>
 __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm256_kernel(const T* __restrict__ A, int64_t lda,
                                                                   const T* __restrict__ W, int64_t ldw,
                                                                   OutT* __restrict__ C, int64_t ldc, int64_t M, int N,
-                                                                  int K, int tiles_m, int tiles_n) {
+                                                                  int K, int tiles_m, int tiles_n, int a_blocked) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -331,7 +334,8 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm256_kernel(const T* __res
             const int row = wave * 32 + i * 8 + (lane >> 3);
             int64_t ga = m0 + row; if (ga > M - 1) ga = M - 1;
             int gw = n0 + row; if (gw > N - 1) gw = N - 1;
-            pa[i] = reinterpret_cast<const char*>(A + ga * lda) + (((lane & 7) ^ key_a(row)) << 4);
+            const int64_t abyte = a_blocked ? blocked_off(ga, 0, (lda * (int64_t)sizeof(T)) >> 7) : ga * lda * (int64_t)sizeof(T);
+            pa[i] = reinterpret_cast<const char*>(A) + abyte + (((lane & 7) ^ key_a(row)) << 4);
             pw[i] = reinterpret_cast<const char*>(W + (int64_t)gw * ldw) + (((lane & 7) ^ key_w(row)) << 4);
         }
     };
@@ -343,8 +347,9 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm256_kernel(const T* __res
             char* as = smem + st * STAGE2_BYTES + (wave * 32) * ROWB;
             char* ws = as + A2_BYTES;
             const int64_t ko = (int64_t)skt * ROWB;
+            const int64_t koa = a_blocked ? (int64_t)skt * 1024 : ko;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) glds16(pa[i] + ko, as + i * 8 * ROWB);
+            for (int i = 0; i < 4; ++i) glds16(pa[i] + koa, as + i * 8 * ROWB);
 #pragma unroll
             for (int i = 0; i < 4; ++i) glds16(pw[i] + ko, ws + i * 8 * ROWB);
             if (++skt == nkt) {
@@ -495,7 +500,7 @@ static int persistent_grid(int nblk) {
 
 template <typename T, typename OutT, bool ROUND>
 static hipError_t launch_gemm_t(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc,
-                                int64_t M, int N, int K, hipStream_t s) {
+                                int64_t M, int N, int K, hipStream_t s, bool a_blocked) {
     const int tiles_m = (int)((M + BM - 1) / BM), tiles_n = (N + BN - 1) / BN;
     const bool vec = ((ldc * (int64_t)sizeof(OutT)) % 16 == 0) && (((uintptr_t)C) % 16 == 0);
     dim3 grid((unsigned)persistent_grid(tiles_m * tiles_n)), block(GEMM_THREADS);
@@ -507,7 +512,7 @@ static hipError_t launch_gemm_t(const void* A, int64_t lda, const void* W, int64
             attr_done_v = true;
         }
         hipLaunchKernelGGL(kfn, grid, block, GEMM_LDS, s, (const T*)A, lda, (const T*)W, ldw, (OutT*)C, ldc, M, N, K,
-                           tiles_m, tiles_n, (float*)nullptr, (int64_t)0, 0);
+                           tiles_m, tiles_n, (float*)nullptr, (int64_t)0, 0, (int)a_blocked);
     } else {
         auto kfn = gemm_nt_kernel<T, OutT, ROUND, false, false>;
         if (!attr_done_s) {
@@ -515,14 +520,15 @@ static hipError_t launch_gemm_t(const void* A, int64_t lda, const void* W, int64
             attr_done_s = true;
         }
         hipLaunchKernelGGL(kfn, grid, block, GEMM_LDS, s, (const T*)A, lda, (const T*)W, ldw, (OutT*)C, ldc, M, N, K,
-                           tiles_m, tiles_n, (float*)nullptr, (int64_t)0, 0);
+                           tiles_m, tiles_n, (float*)nullptr, (int64_t)0, 0, (int)a_blocked);
     }
     return hipGetLastError();
 }
 
 template <typename T>
 static hipError_t launch_gemm_split_t(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc,
-                                      float* C2, int64_t ldc2, int nsplit, int64_t M, int N, int K, hipStream_t s) {
+                                      float* C2, int64_t ldc2, int nsplit, int64_t M, int N, int K, hipStream_t s,
+                                      bool a_blocked) {
     const int tiles_m = (int)((M + BM - 1) / BM), tiles_n = (N + BN - 1) / BN;
     dim3 grid((unsigned)persistent_grid(tiles_m * tiles_n)), block(GEMM_THREADS);
     auto kfn = gemm_nt_kernel<T, T, false, true, true>;
@@ -532,24 +538,25 @@ static hipError_t launch_gemm_split_t(const void* A, int64_t lda, const void* W,
         attr_done = true;
     }
     hipLaunchKernelGGL(kfn, grid, block, GEMM_LDS, s, (const T*)A, lda, (const T*)W, ldw, (T*)C, ldc, M, N, K, tiles_m,
-                       tiles_n, C2, ldc2, nsplit);
+                       tiles_n, C2, ldc2, nsplit, (int)a_blocked);
     return hipGetLastError();
 }
 
 hipError_t launch_gemm_nt_split(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc, float* C2,
-                                int64_t ldc2, int nsplit, int64_t M, int N, int K, int dt, hipStream_t s) {
+                                int64_t ldc2, int nsplit, int64_t M, int N, int K, int dt, hipStream_t s, bool a_blocked) {
     if (M <= 0 || N <= 0) return hipSuccess;
     const int esz = dt == BF16 ? 2 : 4;
     if (K <= 0 || (K * esz) % ROWB || nsplit % 16 || (N - nsplit) % 16) return hipErrorInvalidValue;
     if ((lda * esz) % 16 || (ldw * esz) % 16 || ((uintptr_t)A) % 16 || ((uintptr_t)W) % 16) return hipErrorInvalidValue;
     if ((ldc * esz) % 16 || ((uintptr_t)C) % 16 || (ldc2 * 4) % 16 || ((uintptr_t)C2) % 16) return hipErrorInvalidValue;
-    if (dt == BF16) return launch_gemm_split_t<bf16_t>(A, lda, W, ldw, C, ldc, C2, ldc2, nsplit, M, N, K, s);
-    return launch_gemm_split_t<float>(A, lda, W, ldw, C, ldc, C2, ldc2, nsplit, M, N, K, s);
+    if (a_blocked && (lda * esz) % 128) return hipErrorInvalidValue;
+    if (dt == BF16) return launch_gemm_split_t<bf16_t>(A, lda, W, ldw, C, ldc, C2, ldc2, nsplit, M, N, K, s, a_blocked);
+    return launch_gemm_split_t<float>(A, lda, W, ldw, C, ldc, C2, ldc2, nsplit, M, N, K, s, a_blocked);
 }
 
 template <typename T>
 static hipError_t launch_gemm256_t(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc, int64_t M,
-                                   int N, int K, hipStream_t s) {
+                                   int N, int K, hipStream_t s, bool a_blocked) {
     const int tiles_m = (int)((M + BM2 - 1) / BM2), tiles_n = (N + BN2 - 1) / BN2;
     dim3 grid((unsigned)persistent_grid(tiles_m * tiles_n)), block(GEMM_THREADS);
     auto kfn = gemm256_kernel<T, T>;
@@ -559,31 +566,32 @@ static hipError_t launch_gemm256_t(const void* A, int64_t lda, const void* W, in
         attr_done = true;
     }
     hipLaunchKernelGGL(kfn, grid, block, GEMM2_LDS, s, (const T*)A, lda, (const T*)W, ldw, (T*)C, ldc, M, N, K, tiles_m,
-                       tiles_n);
+                       tiles_n, (int)a_blocked);
     return hipGetLastError();
 }
 
 hipError_t launch_gemm_nt(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc, int64_t M,
-                          int N, int K, int dt, int out_dt, bool round_bf16, hipStream_t s) {
+                          int N, int K, int dt, int out_dt, bool round_bf16, hipStream_t s, bool a_blocked) {
     if (M <= 0 || N <= 0) return hipSuccess;
     const int esz = dt == BF16 ? 2 : 4;
     if (K <= 0 || (K * esz) % ROWB) return hipErrorInvalidValue;
     if ((lda * esz) % 16 || (ldw * esz) % 16 || ((uintptr_t)A) % 16 || ((uintptr_t)W) % 16)
         return hipErrorInvalidValue;
+    if (a_blocked && (lda * esz) % 128) return hipErrorInvalidValue;
     static const bool no256 = getenv("PCAD_GEMM_NO256") != nullptr;      // developer knob: force the 256x128 kernel
     const bool big = !no256 && M >= 2048 && N >= 512 && N % 16 == 0 && out_dt == dt &&
                      (ldc * esz) % 16 == 0 && ((uintptr_t)C) % 16 == 0;
     if (big) {
-        if (dt == BF16) return launch_gemm256_t<bf16_t>(A, lda, W, ldw, C, ldc, M, N, K, s);
-        return launch_gemm256_t<float>(A, lda, W, ldw, C, ldc, M, N, K, s);
+        if (dt == BF16) return launch_gemm256_t<bf16_t>(A, lda, W, ldw, C, ldc, M, N, K, s, a_blocked);
+        return launch_gemm256_t<float>(A, lda, W, ldw, C, ldc, M, N, K, s, a_blocked);
     }
     if (dt == BF16 && out_dt == BF16)
-        return launch_gemm_t<bf16_t, bf16_t, false>(A, lda, W, ldw, C, ldc, M, N, K, s);
+        return launch_gemm_t<bf16_t, bf16_t, false>(A, lda, W, ldw, C, ldc, M, N, K, s, a_blocked);
     if (dt == BF16 && out_dt == F32)
-        return round_bf16 ? launch_gemm_t<bf16_t, float, true>(A, lda, W, ldw, C, ldc, M, N, K, s)
-                          : launch_gemm_t<bf16_t, float, false>(A, lda, W, ldw, C, ldc, M, N, K, s);
+        return round_bf16 ? launch_gemm_t<bf16_t, float, true>(A, lda, W, ldw, C, ldc, M, N, K, s, a_blocked)
+                          : launch_gemm_t<bf16_t, float, false>(A, lda, W, ldw, C, ldc, M, N, K, s, a_blocked);
     if (dt == F32 && out_dt == F32)
-        return launch_gemm_t<float, float, false>(A, lda, W, ldw, C, ldc, M, N, K, s);
+        return launch_gemm_t<float, float, false>(A, lda, W, ldw, C, ldc, M, N, K, s, a_blocked);
     return hipErrorInvalidValue;
 }
 

@@ -34,26 +34,32 @@ hipError_t launch_embed_only(const int32_t* ids, const void* emb, const int32_t*
 // gemm.hip --------------------------------------------------------------------------------------
 // C[M,N] = A[M,K] W[N,K]^T.  K multiple of 128 bytes; lda/ldw multiples of 16 bytes.
 // out_dt: F32 or == dt.  round_bf16: round the fp32 result to bf16 precision before an F32 store.
+// a_blocked: A is in the blocked layout with rows of lda elements.
 hipError_t launch_gemm_nt(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc,
-                          int64_t M, int N, int K, int dt, int out_dt, bool round_bf16, hipStream_t s);
+                          int64_t M, int N, int K, int dt, int out_dt, bool round_bf16, hipStream_t s,
+                          bool a_blocked = false);
 // x_proj form: columns [0, nsplit) -> C (dtype dt, ld ldc); columns [nsplit, N) -> C2 (fp32, rounded to dt's
 // precision, ld ldc2).  nsplit % 16 == 0.
 hipError_t launch_gemm_nt_split(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc,
-                                float* C2, int64_t ldc2, int nsplit, int64_t M, int N, int K, int dt, hipStream_t s);
+                                float* C2, int64_t ldc2, int nsplit, int64_t M, int N, int K, int dt, hipStream_t s,
+                                bool a_blocked = false);
 
 // conv.hip --------------------------------------------------------------------------------------
+// out_blocked: yf / yr in the blocked layout (common.hpp::blocked_off), buffers padded to a multiple of 8 rows.
 hipError_t launch_conv_bidir(const void* x, int64_t ldx, const float* wf, const float* bf, const float* wr,
-                             const float* br, void* yf, void* yr, int S, int L, int E, int dt, hipStream_t s);
+                             const float* br, void* yf, void* yr, int S, int L, int E, int dt, bool out_blocked,
+                             hipStream_t s);
 
 // scan.hip --------------------------------------------------------------------------------------
 // Selective scan of one direction.  delta == nullptr: fused dt_proj (delta tile = dt_low[rows, Rp] . Wdt[E, Rp]^T on
 // MFMA inside the kernel, Rp % 64 == 0, zero-padded K);  delta != nullptr: delta [rows, E] read from memory.
 // bc: fp32 [rows, 32] = B_t | C_t.  The recurrence uses A2 * a_scale as the base-2 decay rate: pass
 // (A * log2(e), 1) or (A, log2(e)).
+// uy_blocked: u and y are in the blocked layout (whole-tensor row index s*L + t, buffers padded to 8 rows).
 hipError_t launch_scan(const void* u, const void* z, int64_t ldz, const void* delta, const void* dt_low, int64_t lddt,
                        const void* Wdt, int Rp, const float* bc, const float* A2, float a_scale, const float* Dskip,
                        const float* dbias, void* y, int S, int L, int E, bool reverse, bool accumulate, int dt,
-                       hipStream_t s);
+                       hipStream_t s, bool uy_blocked = false);
 
 // pack.hip --------------------------------------------------------------------------------------
 // generic 2-D copy/convert with zero padding: dst[r, c] (dst_dt, ld = dst_ld) = src[r, c] for r < rows, c < cols else 0

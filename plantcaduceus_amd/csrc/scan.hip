@@ -143,14 +143,16 @@ template <> struct DeltaTile<float> {
 
 // FUSED: delta comes from dt_low . Wdt^T (above);  !FUSED: delta is read from memory like u (operator entry).
 // PRE (bf16, FUSED, Rp == 64): dt_low operand prefetched one block ahead.
-template <typename T, bool REV, bool ACC, bool HASZ, bool FUSED, bool PRE>
+// BLK8: u / y in the blocked layout AND L % 8 == 0 (the engine's case): one scalar block offset per 4-step chunk, the
+// per-step +-128 bytes ride in the buffer instruction's immediate offset.
+template <typename T, bool REV, bool ACC, bool HASZ, bool FUSED, bool PRE, bool BLK8>
 __global__ __launch_bounds__(64, 4) void scan_kernel(const T* __restrict__ u, const T* __restrict__ z, int64_t ldz,
                                                   const T* __restrict__ dsrc, int64_t ldd,
                                                   const T* __restrict__ Wdt, int Rp,
                                                   const float* __restrict__ bc,
                                                   const float* __restrict__ A2, float a_scale,
                                                   const float* __restrict__ Dskip, const float* __restrict__ dbias,
-                                                  const T* yin, T* y, int L, int E) {
+                                                  const T* yin, T* y, int L, int E, int uyb) {
     __shared__ float dvs[TB][64];
     const int lane = threadIdx.x;
     const int c0 = blockIdx.x * 64;
@@ -177,13 +179,41 @@ __global__ __launch_bounds__(64, 4) void scan_kernel(const T* __restrict__ u, co
     // is suppressed, which keeps the chunk body branch-free.
     // Wave-uniform per-strand bases + 32-bit in-strand offsets (L * ld < 2^31): SGPR base, lane offset in a VGPR.
     const uint32_t esz = (uint32_t)sizeof(T);
-    const auto u_r = make_rsrc(u + row0 * E + c0, (uint32_t)L * (uint32_t)E * esz);
-    const auto z_r = make_rsrc(HASZ ? z + row0 * ldz + c0 : u, (uint32_t)L * (uint32_t)ldz * esz);
-    const auto d_r = make_rsrc(FUSED ? u : dsrc + row0 * ldd + c0, (uint32_t)L * (uint32_t)ldd * esz);
-    const auto y_r = make_rsrc(y + row0 * E + c0, (uint32_t)L * (uint32_t)E * esz);     // also the ACC input
-    const float* __restrict__ bc_s = bc + row0 * (2 * NSTATE);
     const uint32_t rowE = (uint32_t)E * esz, rowZ = (uint32_t)ldz * esz, rowD = (uint32_t)ldd * esz;
+    // u and y: plain rows (descriptor based at the strand, offset t * rowE) or the blocked layout the GEMMs stream
+    // (descriptor based at the tensor, offset = blocked_off of the whole-tensor row; the wave's 64 channels are one or two
+    // 128-byte pieces, so the per-lane part is a constant)
+    const uint32_t pieces = rowE >> 7;
+    const uint32_t tot_rows = ((uint32_t)gridDim.y * (uint32_t)L + 7u) & ~7u;
+    const bool blk = BLK8 || uyb;       // BLK8 instantiations: known at compile time
+    const auto u_r = blk ? make_rsrc(u, tot_rows * rowE) : make_rsrc(u + row0 * E + c0, (uint32_t)L * rowE);
+    const auto y_r = blk ? make_rsrc(y, tot_rows * rowE) : make_rsrc(y + row0 * E + c0, (uint32_t)L * rowE);   // also the ACC input
+    const auto z_r = make_rsrc(HASZ ? z + row0 * ldz + c0 : u, (uint32_t)L * rowZ);
+    const auto d_r = make_rsrc(FUSED ? u : dsrc + row0 * ldd + c0, (uint32_t)L * rowD);
+    const float* __restrict__ bc_s = bc + row0 * (2 * NSTATE);
     const int voff = lane * (int)esz;
+    const int voff_uy = blk ? (int)((((uint32_t)voff >> 7) << 10) + ((uint32_t)voff & 127u)) : voff;
+    const uint32_t c0b = (uint32_t)c0 * esz;
+    auto off_uy = [&](uint32_t t) -> uint32_t {
+        if (blk) {
+            const uint32_t r = (uint32_t)row0 + t;
+            return (((r >> 3) * pieces + (c0b >> 7)) << 10) + ((r & 7u) << 7);
+        }
+        return t * rowE;
+    };
+    // scalar offset / per-lane offset of walk step s0 + i (s0 a multiple of CH).  BLK8: a CH-step chunk (CH = 4, aligned
+    // in walk space, rows s*L + t with L % 8 == 0) never crosses an 8-row block: scalar = offset of the chunk's lowest row,
+    // and the step's +128*k goes into the per-lane offset as a compile-time constant (folded into the immediate).
+    auto uy_soff = [&](int s0, int i) -> uint32_t {
+        if constexpr (BLK8) {
+            const int slo = min(REV ? s0 + CH - 1 : s0, L - 1);
+            return off_uy((uint32_t)(REV ? (L - 1 - slo) : slo));
+        } else {
+            const int sc = min(s0 + i, L - 1);
+            return off_uy((uint32_t)(REV ? (L - 1 - sc) : sc));
+        }
+    };
+    auto uy_voff = [&](int i) -> int { return BLK8 ? voff_uy + 128 * (REV ? CH - 1 - i : i) : voff_uy; };
 
     T ub[CH], zb[CH], yb[CH], dr[CH];      // RAW prefetched values: converted at use, so no early vmcnt wait
     auto tclamp = [&](int s) { const int sc = min(s, L - 1); return REV ? (L - 1 - sc) : sc; };
@@ -191,9 +221,9 @@ __global__ __launch_bounds__(64, 4) void scan_kernel(const T* __restrict__ u, co
 #pragma unroll
         for (int i = 0; i < CH; ++i) {
             const uint32_t t = (uint32_t)tclamp(s0 + i);
-            uu[i] = BufIO<T>::load(u_r, voff, t * rowE);
+            uu[i] = BufIO<T>::load(u_r, uy_voff(i), uy_soff(s0, i));
             if constexpr (HASZ) zz[i] = BufIO<T>::load(z_r, voff, t * rowZ);
-            if constexpr (ACC) yy[i] = BufIO<T>::load(y_r, voff, t * rowE);
+            if constexpr (ACC) yy[i] = BufIO<T>::load(y_r, uy_voff(i), uy_soff(s0, i));
             if constexpr (!FUSED) dd[i] = BufIO<T>::load(d_r, voff, t * rowD);
         }
     };
@@ -210,7 +240,7 @@ __global__ __launch_bounds__(64, 4) void scan_kernel(const T* __restrict__ u, co
 
     // one recurrence step on raw inputs (uraw, zraw, yraw, draw) at walk step s
     float dv_cur = 0.f;    // FUSED: delta of the step about to run, read from LDS one step ahead
-    auto step = [&](int s, int tb0, T uraw, T zraw, T yraw, T draw) {
+    auto step = [&](int s, int tb0, uint32_t oy, int vy, T uraw, T zraw, T yraw, T draw) {
         f2 bcn[NSTATE];
         load_bc(s + 1, bcn);
         const uint32_t t = (uint32_t)tclamp(s);
@@ -239,7 +269,7 @@ __global__ __launch_bounds__(64, 4) void scan_kernel(const T* __restrict__ u, co
         float yv = yacc[0] + yacc[1];
         if constexpr (HASZ) yv *= silu(Elem<T>::to_f32(zraw));
         if constexpr (ACC) yv = Elem<T>::round(yv) + Elem<T>::to_f32(yraw);    // each direction is rounded, then summed
-        BufIO<T>::store(Elem<T>::from_f32(yv), y_r, voff, t * rowE);
+        BufIO<T>::store(Elem<T>::from_f32(yv), y_r, vy, oy);
 #pragma unroll
         for (int p = 0; p < NSTATE; ++p) bcc[p] = bcn[p];
         dv_cur = dv_next;
@@ -280,27 +310,27 @@ __global__ __launch_bounds__(64, 4) void scan_kernel(const T* __restrict__ u, co
             T un[CH], zn[CH], yn[CH], dn[CH];
             load_chunk(s0 + CH, un, zn, yn, dn);
 #pragma unroll
-            for (int i = 0; i < CH; ++i) step(s0 + i, tb0, ub[i], zb[i], yb[i], dr[i]);
+            for (int i = 0; i < CH; ++i) step(s0 + i, tb0, uy_soff(s0, i), uy_voff(i), ub[i], zb[i], yb[i], dr[i]);
 #pragma unroll
             for (int i = 0; i < CH; ++i) { ub[i] = un[i]; zb[i] = zn[i]; yb[i] = yn[i]; dr[i] = dn[i]; }
         }
         if (s0 < s_end) {                                                // tail (< CH steps, end of the sequence)
 #pragma unroll
             for (int i = 0; i < CH - 1; ++i)
-                if (s0 + i < s_end) step(s0 + i, tb0, ub[i], zb[i], yb[i], dr[i]);
+                if (s0 + i < s_end) step(s0 + i, tb0, uy_soff(s0, i), uy_voff(i), ub[i], zb[i], yb[i], dr[i]);
         }
     }
 }
 
-template <typename T, bool FUSED, bool PRE = false>
+template <typename T, bool FUSED, bool PRE = false, bool BLK8 = false>
 static hipError_t launch_scan_t(const void* u, const void* z, int64_t ldz, const void* dsrc, int64_t ldd,
                                 const void* Wdt, int Rp, const float* bc, const float* A2, float a_scale,
                                 const float* Dskip, const float* dbias, void* y, int S, int L, int E, bool reverse,
-                                bool accumulate, hipStream_t s) {
+                                bool accumulate, hipStream_t s, bool uyb) {
     dim3 grid((unsigned)(E / 64), (unsigned)S), block(64);
 #define PCAD_SCAN(REV, ACC, HZ)                                                                                    \
-    hipLaunchKernelGGL((scan_kernel<T, REV, ACC, HZ, FUSED, PRE>), grid, block, 0, s, (const T*)u, (const T*)z, ldz,       \
-                       (const T*)dsrc, ldd, (const T*)Wdt, Rp, bc, A2, a_scale, Dskip, dbias, (const T*)y, (T*)y, L, E)
+    hipLaunchKernelGGL((scan_kernel<T, REV, ACC, HZ, FUSED, PRE, BLK8>), grid, block, 0, s, (const T*)u, (const T*)z, ldz,       \
+                       (const T*)dsrc, ldd, (const T*)Wdt, Rp, bc, A2, a_scale, Dskip, dbias, (const T*)y, (T*)y, L, E, (int)uyb)
     const bool hz = z != nullptr;
     if (!reverse && !accumulate) { if (hz) PCAD_SCAN(false, false, true); else PCAD_SCAN(false, false, false); }
     else if (!reverse && accumulate) { if (hz) PCAD_SCAN(false, true, true); else PCAD_SCAN(false, true, false); }
@@ -313,20 +343,24 @@ static hipError_t launch_scan_t(const void* u, const void* z, int64_t ldz, const
 hipError_t launch_scan(const void* u, const void* z, int64_t ldz, const void* delta, const void* dt_low, int64_t lddt,
                        const void* Wdt, int Rp, const float* bc, const float* A2, float a_scale, const float* Dskip,
                        const float* dbias, void* y, int S, int L, int E, bool reverse, bool accumulate, int dt,
-                       hipStream_t s) {
+                       hipStream_t s, bool uyb) {
     if (S <= 0 || L <= 0) return hipSuccess;
     if (E % 64) return hipErrorInvalidValue;
     if ((int64_t)L * (ldz > E ? ldz : E) * 4 >= ((int64_t)1 << 31)) return hipErrorInvalidValue;   // 32-bit in-strand offsets
+    if (uyb && (((int64_t)S * L + 7) / 8 * 8 * E * 4 >= ((int64_t)1 << 32) || (E * (dt == BF16 ? 2 : 4)) % 128))
+        return hipErrorInvalidValue;     // blocked layout: 32-bit whole-tensor offsets
     const bool fused = delta == nullptr;
     if (fused && (!dt_low || !Wdt || Rp <= 0 || Rp % 64)) return hipErrorInvalidValue;
     if (dt == BF16) {
+        if (fused && Rp == 64 && lddt % 8 == 0 && uyb && L % 8 == 0)
+            return launch_scan_t<bf16_t, true, true, true>(u, z, ldz, dt_low, lddt, Wdt, Rp, bc, A2, a_scale, Dskip, dbias, y, S, L, E, reverse, accumulate, s, uyb);
         if (fused && Rp == 64 && lddt % 8 == 0)
-            return launch_scan_t<bf16_t, true, true>(u, z, ldz, dt_low, lddt, Wdt, Rp, bc, A2, a_scale, Dskip, dbias, y, S, L, E, reverse, accumulate, s);
-        if (fused) return launch_scan_t<bf16_t, true>(u, z, ldz, dt_low, lddt, Wdt, Rp, bc, A2, a_scale, Dskip, dbias, y, S, L, E, reverse, accumulate, s);
-        return launch_scan_t<bf16_t, false>(u, z, ldz, delta, E, nullptr, 0, bc, A2, a_scale, Dskip, dbias, y, S, L, E, reverse, accumulate, s);
+            return launch_scan_t<bf16_t, true, true>(u, z, ldz, dt_low, lddt, Wdt, Rp, bc, A2, a_scale, Dskip, dbias, y, S, L, E, reverse, accumulate, s, uyb);
+        if (fused) return launch_scan_t<bf16_t, true>(u, z, ldz, dt_low, lddt, Wdt, Rp, bc, A2, a_scale, Dskip, dbias, y, S, L, E, reverse, accumulate, s, uyb);
+        return launch_scan_t<bf16_t, false>(u, z, ldz, delta, E, nullptr, 0, bc, A2, a_scale, Dskip, dbias, y, S, L, E, reverse, accumulate, s, uyb);
     }
-    if (fused) return launch_scan_t<float, true>(u, z, ldz, dt_low, lddt, Wdt, Rp, bc, A2, a_scale, Dskip, dbias, y, S, L, E, reverse, accumulate, s);
-    return launch_scan_t<float, false>(u, z, ldz, delta, E, nullptr, 0, bc, A2, a_scale, Dskip, dbias, y, S, L, E, reverse, accumulate, s);
+    if (fused) return launch_scan_t<float, true>(u, z, ldz, dt_low, lddt, Wdt, Rp, bc, A2, a_scale, Dskip, dbias, y, S, L, E, reverse, accumulate, s, uyb);
+    return launch_scan_t<float, false>(u, z, ldz, delta, E, nullptr, 0, bc, A2, a_scale, Dskip, dbias, y, S, L, E, reverse, accumulate, s, uyb);
 }
 
 }  // namespace pcad
