@@ -1,0 +1,64 @@
+#!/usr/bin/env python3
+"""rocprofv3 --pmc CSVs (FETCH_SIZE/, WRITE_SIZE/, SQ/ sub-directories of one run) -> profiles/<round>_pmc_traffic.json
+
+    python profiles/pmc_summary.py gpurun_out/<run> profiles/<round>_pmc_traffic.json
+"""
+import json
+import re
+import sys
+
+import pandas as pd
+
+NOTE_SRC = ("rocprofv3 --kernel-trace --pmc {FETCH_SIZE | WRITE_SIZE | SQ_*} (three separate passes) -- python3 bench.py --steps 1 "
+            "--warmup 1 --cpu-seqs 0 --no-profile --batch 128  (l32 bf16, 65536 token-rows per launch)")
+NOTE_CORR = ("per MI355X_MICROARCH.md §HBM: FETCH_SIZE on gfx950 reports 1/2 of a wide coalesced read (checked: conv and add_rmsnorm raw "
+             "values are 0.52x / 0.49x their algorithmic read bytes); WRITE_SIZE is 1:1 (scan = rows*E*2 exactly). traffic_bytes = "
+             "2*FETCH_SIZE + WRITE_SIZE. The scan's 2-byte-per-lane loads are outside the calibrated width, so its read side is an "
+             "upper estimate.")
+
+
+def short(n):
+    return re.sub(r"\(.*", "", n).replace("void ", "").replace("unsigned short", "bf16")
+
+
+def main():
+    base, out = sys.argv[1].rstrip("/") + "/", sys.argv[2]
+    res = {}
+    for c in ("FETCH_SIZE", "WRITE_SIZE"):
+        df = pd.read_csv(base + f"{c}/p_counter_collection.csv")
+        df = df[df.Counter_Name == c]
+        df["k"] = df.Kernel_Name.map(short)
+        for k, v in df.groupby("k").Counter_Value.mean().items():
+            if k.startswith("pcad::") and "pack" not in k:
+                res.setdefault(k, {})[c + "_KB"] = round(float(v), 1)
+    df = pd.read_csv(base + "SQ/p_counter_collection.csv")
+    df["k"] = df.Kernel_Name.map(short)
+    p = df.pivot_table(index="k", columns="Counter_Name", values="Counter_Value", aggfunc="mean")
+    for k, row in p.iterrows():
+        if k in res:
+            res[k].update({c: float(row[c]) for c in p.columns})
+            gui = row["GRBM_GUI_ACTIVE"] / 8.0          # summed over the 8 XCDs
+            res[k]["valu_busy_frac"] = round(row["SQ_ACTIVE_INST_VALU"] * 4 / 1024 / gui, 3)   # quad-cycles
+            res[k]["mfma_busy_frac"] = round(row["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024 / gui, 3)
+    cls = {"selective_scan": [k for k in res if "scan_kernel" in k],
+           "gemm_in_out_proj": [k for k in res if "gemm256_kernel" in k] or [k for k in res if "gemm_nt_kernel" in k and k.endswith("false>")],
+           "gemm_x_proj": [k for k in res if "gemm_nt_kernel" in k and k.endswith("true>")],
+           "conv1d_bidir": [k for k in res if "conv" in k],
+           "add_rmsnorm": [k for k in res if "add_rmsnorm" in k and k.endswith("false>")]}
+    o = {"source": NOTE_SRC, "correction": NOTE_CORR, "kernels": res, "classes": {}}
+    for c, ks in cls.items():
+        ks = [k for k in ks if "FETCH_SIZE_KB" in res[k] and "WRITE_SIZE_KB" in res[k]]
+        if not ks:
+            continue
+        f = sum(res[k]["FETCH_SIZE_KB"] for k in ks) / len(ks)
+        w = sum(res[k]["WRITE_SIZE_KB"] for k in ks) / len(ks)
+        o["classes"][c] = {"traffic_bytes_per_launch": round((2 * f + w) * 1024), "fetch_raw_bytes": round(f * 1024),
+                           "write_bytes": round(w * 1024),
+                           "valu_busy_frac": round(sum(res[k].get("valu_busy_frac", 0) for k in ks) / len(ks), 3),
+                           "mfma_busy_frac": round(sum(res[k].get("mfma_busy_frac", 0) for k in ks) / len(ks), 3)}
+    json.dump(o, open(out, "w"), indent=1)
+    print(json.dumps(o["classes"], indent=1))
+
+
+if __name__ == "__main__":
+    main()
