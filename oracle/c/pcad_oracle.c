@@ -45,11 +45,26 @@ typedef struct {
 typedef struct {
     int32_t d_model, n_layer, d_inner, dt_rank;
     float eps;
+    int32_t emulate_bf16;   /* round to bf16 at the reference's tensor boundaries (model run with torch_dtype=bfloat16) */
     int32_t complement[8];
     const float* emb;     /* [8, D] (tied LM head) */
     const float* norm_f;  /* [D] */
     const oracle_layer* layers;
 } oracle_model;
+
+/* round-to-nearest-even fp32 -> bf16 -> fp32 */
+static inline float rbf(float f) {
+    union { float f; uint32_t u; } v;
+    v.f = f;
+    v.u += 0x7fffu + ((v.u >> 16) & 1u);
+    v.u &= 0xffff0000u;
+    return v.f;
+}
+static void round_rows(float* x, size_t n, int on) {
+    if (!on) return;
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < (int64_t)n; ++i) x[i] = rbf(x[i]);
+}
 
 int oracle_num_threads(void) {
 #ifdef _OPENMP
@@ -168,7 +183,7 @@ static void linear_nt(const float* A, int lda, const float* W, int K, float* C, 
 
 /* rms_norm_fn(prenorm=True) over `rows` token rows: res = x (+ res); y = res * rsqrt(mean(res^2)+eps) * w */
 static void add_rmsnorm(const float* x, float* res, int has_res, const float* w, float* y, int64_t rows, int D,
-                        float eps) {
+                        float eps, int rb) {
 #pragma omp parallel for schedule(static)
     for (int64_t t = 0; t < rows; ++t) {
         float ss = 0.f;
@@ -180,12 +195,12 @@ static void add_rmsnorm(const float* x, float* res, int has_res, const float* w,
             ss += v * v;
         }
         const float rstd = 1.0f / sqrtf(ss / (float)D + eps);
-        for (int c = 0; c < D; ++c) y[(size_t)t * D + c] = r[c] * rstd * w[c];
+        for (int c = 0; c < D; ++c) { const float v = r[c] * rstd * w[c]; y[(size_t)t * D + c] = rb ? rbf(v) : v; }
     }
 }
 
 /* conv1d (width 4) + SiLU on x = xz[..., :E]; d = 1 is the anti-causal conv (reverse Mamba on unflipped rows) */
-static void conv_silu(const float* xz, const float* cw, const float* cb, float* xc, int S, int L, int E, int d) {
+static void conv_silu(const float* xz, const float* cw, const float* cb, float* xc, int S, int L, int E, int d, int rb) {
 #pragma omp parallel for collapse(2) schedule(static)
     for (int s = 0; s < S; ++s)
         for (int t = 0; t < L; ++t) {
@@ -197,7 +212,7 @@ static void conv_silu(const float* xz, const float* cw, const float* cb, float* 
                     const int tt = d == 0 ? t - 3 + k : t + 3 - k;
                     if (tt >= 0 && tt < L) a += cw[c * 4 + k] * base[(size_t)tt * 2 * E + c];
                 }
-                o[c] = silu_f(a);
+                o[c] = rb ? rbf(silu_f(a)) : silu_f(a);
             }
         }
 }
@@ -205,7 +220,7 @@ static void conv_silu(const float* xz, const float* cw, const float* cb, float* 
 /* selective scan of one direction, accumulated into y (gated by silu(z)); channel blocks of VL lanes,
  * sequential in t; parallel over (strand, channel block) */
 static void scan_dir(const float* xc, const float* delta, const float* dbl, const float* xz, const float* A,
-                     const float* dt_b, const float* Dskip, float* y, int S, int L, int E, int R, int d) {
+                     const float* dt_b, const float* Dskip, float* y, int S, int L, int E, int R, int d, int rb) {
     const int XP = R + 2 * NST;
 #pragma omp parallel for collapse(2) schedule(static)
     for (int s = 0; s < S; ++s)
@@ -237,7 +252,8 @@ static void scan_dir(const float* xc, const float* delta, const float* dbl, cons
                 }
                 for (int l = 0; l < VL; ++l) {
                     const int c = c0 + l;
-                    y[t * E + c] += yv[l] * silu_f(xz[t * 2 * E + E + c]);
+                    const float g = yv[l] * silu_f(xz[t * 2 * E + E + c]);      /* each direction rounded, then summed */
+                    y[t * E + c] = rb ? rbf(y[t * E + c] + rbf(g)) : y[t * E + c] + g;
                 }
             }
         }
@@ -275,23 +291,29 @@ int oracle_forward(const oracle_model* m, const int32_t* ids, int B, int L, floa
     for (int64_t r = 0; r < (int64_t)rows; ++r)
         memcpy(h + (size_t)r * D, m->emb + (size_t)(tok[r] & 7) * D, sizeof(float) * D);
 
+    const int rb = m->emulate_bf16;
+    round_rows(h, rows * D, rb);
     for (int li = 0; li < m->n_layer; ++li) {
         const oracle_layer* ly = &m->layers[li];
-        add_rmsnorm(h, res, li > 0, ly->norm_w, u, (int64_t)rows, D, m->eps);
+        add_rmsnorm(h, res, li > 0, ly->norm_w, u, (int64_t)rows, D, m->eps, rb);
         linear_nt(u, D, ly->in_proj, D, xz, 2 * E, (int)rows, 2 * E);
+        round_rows(xz, rows * 2 * E, rb);
         memset(y, 0, sizeof(float) * rows * E);
         for (int d = 0; d < 2; ++d) {
-            conv_silu(xz, ly->conv_w[d], ly->conv_b[d], xc, S, L, E, d);
+            conv_silu(xz, ly->conv_w[d], ly->conv_b[d], xc, S, L, E, d, rb);
             linear_nt(xc, E, ly->x_proj[d], E, dbl, XP, (int)rows, XP);
+            round_rows(dbl, rows * XP, rb);
             linear_nt(dbl, XP, ly->dt_w[d], R, delta, E, (int)rows, E);
+            round_rows(delta, rows * E, rb);
 #pragma omp parallel for schedule(static)
             for (int i = 0; i < E * NST; ++i) A[i] = -expf(ly->A_log[d][i]);
-            scan_dir(xc, delta, dbl, xz, A, ly->dt_b[d], ly->Dskip[d], y, S, L, E, R, d);
+            scan_dir(xc, delta, dbl, xz, A, ly->dt_b[d], ly->Dskip[d], y, S, L, E, R, d, rb);
         }
-        linear_nt(y, E, ly->out_proj, E, h, D, (int)rows, D);
+        linear_nt(y, E, ly->out_proj, E, h, D, (int)rows, D);        /* tied out_proj folded, as the engine does */
+        round_rows(h, rows * D, rb);
     }
     float* Hall = u;   /* final normalised hidden [S, L, D] */
-    add_rmsnorm(h, res, 1, m->norm_f, Hall, (int64_t)rows, D, m->eps);
+    add_rmsnorm(h, res, 1, m->norm_f, Hall, (int64_t)rows, D, m->eps, rb);
 
 #pragma omp parallel for collapse(2) schedule(static)
     for (int b = 0; b < B; ++b)
@@ -308,7 +330,7 @@ int oracle_forward(const oracle_model* m, const int32_t* ids, int B, int L, floa
                     const float* e1 = m->emb + (size_t)m->complement[v] * D;
                     float a = 0.f, bsum = 0.f;
                     for (int c = 0; c < D; ++c) { a += hf[c] * e0[c]; bsum += hr[c] * e1[c]; }
-                    logits[((size_t)b * L + l) * 8 + v] = a + bsum;
+                    logits[((size_t)b * L + l) * 8 + v] = rb ? rbf(rbf(a) + rbf(bsum)) : a + bsum;
                 }
             }
         }

@@ -40,7 +40,7 @@ class OracleLayer(C.Structure):
 
 class OracleModel(C.Structure):
     _fields_ = [("d_model", C.c_int32), ("n_layer", C.c_int32), ("d_inner", C.c_int32), ("dt_rank", C.c_int32),
-                ("eps", C.c_float), ("complement", C.c_int32 * 8), ("emb", FP), ("norm_f", FP),
+                ("eps", C.c_float), ("emulate_bf16", C.c_int32), ("complement", C.c_int32 * 8), ("emb", FP), ("norm_f", FP),
                 ("layers", C.POINTER(OracleLayer))]
 
 
@@ -62,9 +62,12 @@ def _lib():
 
 class COracle:
     """fp32 C/OpenMP forward from a reference-named state dict (values rounded through `dtype` first,
-    emulating from_pretrained(torch_dtype=...); arithmetic is always fp32)."""
+    emulating from_pretrained(torch_dtype=...); arithmetic is always fp32).  emulate_bf16=True additionally rounds
+    to bf16 at the tensor boundaries where the reference's bf16 model stores a bf16 tensor (u, xz, conv out, x_dbl,
+    delta, each direction's gated scan output and their sum, out_proj out, hidden, logits) — the engine's order,
+    i.e. caduceus_oracle.forward_strands(rnd=round_bf16, tie_fold=True)."""
 
-    def __init__(self, state_dict, config, dtype=None):
+    def __init__(self, state_dict, config, dtype=None, emulate_bf16=False):
         import torch
         self.lib = _lib()
         self.config = config
@@ -97,7 +100,7 @@ class COracle:
                 ly.Dskip[d] = arr(mp + "D")
         self.model = OracleModel(
             d_model=config.d_model, n_layer=config.n_layer, d_inner=config.d_inner, dt_rank=config.dt_rank,
-            eps=config.norm_epsilon, complement=(C.c_int32 * 8)(*config.complement_list()[:8]),
+            eps=config.norm_epsilon, emulate_bf16=int(bool(emulate_bf16)), complement=(C.c_int32 * 8)(*config.complement_list()[:8]),
             emb=arr(pre + "embeddings.word_embeddings.embedding.weight"), norm_f=arr(pre + "norm_f.weight"),
             layers=self.layers)
 

@@ -75,15 +75,18 @@ def test_config3_l32_bf16_example_snps(golden_dir):
     rc = [s.translate(comp)[::-1] for s in seqs]
     probs_rc = zero_shot.extract_logits(m, rc, DEV, 511 - 255, tok, batch_size=128)[:, ::-1]
     assert np.abs(probs_rc - probs).max() < 2e-2           # bf16 path: both strands are computed, in swapped roles
-    # bounded sample against the fp32 CPU oracle (C port): bf16 tolerance on probabilities, argmax where confident
+    # bounded sample against the CPU oracle (C port) emulating the bf16 model: bf16 weights, bf16 rounding at the
+    # reference's tensor boundaries, fp32 arithmetic in between; 32 layers deep.  Tolerance on probabilities: a few
+    # bf16 ulps of accumulated rounding-order noise; argmax where the oracle's margin exceeds it.
     from oracle.c_oracle import COracle
     n = 4
     ids = tok.encode_batch(seqs[:n], mask_index=255)
-    lg, _ = COracle(sd, cfg, dtype=torch.bfloat16).forward(ids)
+    lg, _ = COracle(sd, cfg, dtype=torch.bfloat16, emulate_bf16=True).forward(ids)
     z = lg[:, 255, 3:7]
     ref = np.exp(z - z.max(1, keepdims=True))
     ref /= ref.sum(1, keepdims=True)
-    assert np.abs(probs[:n] - ref).max() < 3e-2
+    print("config3: max |p_hip - p_oracle(bf16-emulating)| =", np.abs(probs[:n] - ref).max())
+    assert np.abs(probs[:n] - ref).max() < 1e-2
     top2 = np.sort(ref, 1)[:, -2:]
     conf = (top2[:, 1] - top2[:, 0]) > 6e-2
     assert (probs[:n].argmax(1)[conf] == ref.argmax(1)[conf]).all()
@@ -91,8 +94,8 @@ def test_config3_l32_bf16_example_snps(golden_dir):
 
 def test_config2_l20_bf16_batch1024():
     """BASELINE config 2: PlantCaduceus_l20 bf16, 1024 synthetic 512-bp windows (numpy default_rng(0)), mask at 255.
-    All rows: finite, normalised, reverse-complement equivariant.  A bounded sample against the CPU oracle port:
-    fp32 weights rounded to bf16, fp32 arithmetic (the bf16 path's noise is the tolerance)."""
+    All rows: finite, normalised, reverse-complement equivariant.  A bounded sample against the CPU oracle port in its
+    bf16-emulating mode (bf16 weights and tensor boundaries, fp32 arithmetic in between)."""
     from oracle.c_oracle import COracle
     cfg = make_config("l20")
     sd = synthetic_state_dict(cfg, seed=1234, stress=False)
@@ -109,11 +112,12 @@ def test_config2_l20_bf16_batch1024():
     probs_rc = zero_shot.extract_logits(m, np.ascontiguousarray(rc), DEV, 511 - 255, tok, batch_size=1024)[:, ::-1]
     assert np.abs(probs_rc - probs).max() < 2e-2
     n = 8
-    lg, _ = COracle(sd, cfg, dtype=torch.bfloat16).forward(ids[:n])
+    lg, _ = COracle(sd, cfg, dtype=torch.bfloat16, emulate_bf16=True).forward(ids[:n])
     z = lg[:, 255, 3:7]
     ref = np.exp(z - z.max(1, keepdims=True))
     ref /= ref.sum(1, keepdims=True)
-    assert np.abs(probs[:n] - ref).max() < 3e-2
+    print("config2: max |p_hip - p_oracle(bf16-emulating)| =", np.abs(probs[:n] - ref).max())
+    assert np.abs(probs[:n] - ref).max() < 1e-2
     top2 = np.sort(ref, 1)[:, -2:]
     conf = (top2[:, 1] - top2[:, 0]) > 6e-2
     assert (probs[:n].argmax(1)[conf] == ref.argmax(1)[conf]).all()

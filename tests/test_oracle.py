@@ -110,3 +110,19 @@ def test_bf16_emulation_rounds_at_tensor_boundaries():
     ref = O.forward_strands(ids, O.params_from_state_dict(sd, cfg))
     err = (out["logits"] - ref["logits"]).abs().max() / ref["logits"].abs().max()
     assert 1e-5 < err.item() < 0.1                       # differs from fp32 by bf16-sized noise, not more
+
+
+def test_c_port_bf16_emulation_matches_torch_emulation():
+    """the two bf16-emulating restatements (rounding at the reference's tensor boundaries) agree to a bf16 ulp:
+    they differ only where summation order flips a rounding."""
+    cfg = make_config("x", d_model=128, n_layer=3)
+    sd = synthetic_state_dict(cfg, seed=3)
+    ids = np.random.default_rng(4).integers(3, 7, size=(3, 40)).astype(np.int64)
+    ids[:, 20] = 1
+    ref = O.forward_strands(torch.from_numpy(ids), O.params_from_state_dict(sd, cfg, dtype=torch.bfloat16),
+                            rnd=O.round_bf16, tie_fold=True)
+    from oracle.c_oracle import COracle
+    lg, hid = COracle(sd, cfg, dtype=torch.bfloat16, emulate_bf16=True).forward(ids, want_hidden=True)
+    assert np.abs(lg - ref["logits"].numpy()).max() / np.abs(lg).max() < 2 ** -6
+    assert np.abs(hid - ref["hidden"].numpy()).max() / np.abs(hid).max() < 2 ** -6
+    assert np.array_equal(lg, lg.astype(np.float32)) and np.all(lg == torch.from_numpy(lg).bfloat16().float().numpy())
