@@ -18,6 +18,8 @@ What is pinned, and by what:
                           `vcf.Reader` / `SeqIO` (string slicing semantics) -> window arithmetic and N padding.
   mixer_D*.npz            `transformers.models.mamba.modeling_mamba.MambaMixer` (independent third-party
                           statement of the Mamba-v1 mixer; slow CPU path) with seeded parameters -> in/out.
+  harness_plantcad2.npz   reference `src/zero-shot-eval.py` (stub for `fire`): `SingleMaskDataset`/`MultiMaskDataset` +
+                          `_masked_probs` and `_unmasked_probs` (:75-178) driven with the CPU oracle model.
   model_tiny.npz          this repo's oracle (literal RCPS form) on a synthetic checkpoint -> logits/hidden;
                           a regression pin for the C oracle and the HIP path (after A==B is tested).
   example_snp.tsv         data file copied from the reference's examples/ (Apache-2.0), config-3 input.
@@ -175,6 +177,28 @@ def gen_harness():
     print("windows:", {k: len(v["sequences"]) for k, v in windows.items()})
 
 
+def gen_plantcad2():
+    """reference src/zero-shot-eval.py: Single/MultiMaskDataset + _masked_probs and _unmasked_probs, oracle model in the loop"""
+    sys.modules.setdefault("fire", types.ModuleType("fire"))
+    ev = import_reference("ref_eval", "src/zero-shot-eval.py")
+    from torch.utils.data import DataLoader
+    df = pd.read_csv(os.path.join(REF, "examples", "example_snp.tsv"), delimiter="\t")
+    seqs = df["sequences"].iloc[:6]
+    cfg_kw = dict(d_model=64, n_layer=2)
+    seed = 11
+    cfg = make_config("x", **cfg_kw)
+    model = O.OracleForMaskedLM(O.params_from_state_dict(synthetic_state_dict(cfg, seed=seed), cfg))
+    tok = CaduceusTokenizer()
+    single = ev._masked_probs(model, tok, DataLoader(ev.SingleMaskDataset(seqs, tok, 255), batch_size=4), "cpu")
+    multi_idx = [300, 10, 255]
+    multi = ev._masked_probs(model, tok, DataLoader(ev.MultiMaskDataset(seqs, tok, multi_idx), batch_size=4), "cpu")
+    unm = ev._unmasked_probs(seqs, tok, model, "cpu", 4)
+    np.savez_compressed(os.path.join(OUT, "harness_plantcad2.npz"), model_d_model=cfg_kw["d_model"],
+                        model_n_layer=cfg_kw["n_layer"], model_seed=seed, rows=6, single_idx=255, single=single.astype(np.float32),
+                        multi_idx=np.array(multi_idx), multi=multi.astype(np.float32), unmasked=unm.astype(np.float32))
+    print("plantcad2:", single.shape, multi.shape, unm.shape)
+
+
 def gen_model_tiny():
     cfg = make_config("x", d_model=64, n_layer=3)
     sd = synthetic_state_dict(cfg, seed=2024)
@@ -194,4 +218,5 @@ if __name__ == "__main__":
     gen_mixer(384, 2, 48, 200)
     gen_model_tiny()
     gen_harness()
+    gen_plantcad2()
     print("golden vectors written to", OUT)

@@ -1,0 +1,132 @@
+"""`predict_XGBoost.py` end-to-end — host glue after the embedding path (reference `src/predict_XGBoost.py:19-67`,
+`src/train_XGBoost.py:122-124`): averaged embeddings [N, d_model] -> pre-trained XGBoost classifier -> P(label = 1).
+
+The embedding extraction is the accelerated path (`embeddings.extract_embeddings`); the classifier is a CPU tree
+ensemble.  `xgboost` is not a dependency here: `XGBJsonClassifier` reads the XGBoost JSON model format that
+`XGBClassifier.save_model("*.json")` writes (learner.gradient_booster.model.trees: left_children, right_children,
+split_indices, split_conditions, default_left; leaf value in split_conditions; binary:logistic with base_score in
+probability space) and evaluates it with vectorised numpy.  The 16 classifier JSONs of the reference are large blobs
+that are absent from the reference checkout, so this reader is pinned by hand-built models in tests/test_xgb.py, not
+by the real files.  Same flags, cache files (`<prefix>_embeddings.npz` / `<prefix>_chunk_<i>_embeddings.npz`, key
+`test`) and output (`<prefix>_predictions.tsv`, columns label, prediction) as the reference script.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import logging
+import os
+from typing import Optional, Sequence
+
+import numpy as np
+
+
+class XGBJsonClassifier:
+    def __init__(self):
+        self.trees = []
+        self.base_margin = 0.0
+        self.n_features = 0
+
+    def load_model(self, path: str):
+        with open(path) as f:
+            m = json.load(f)
+        learner = m["learner"]
+        obj = learner.get("objective", {}).get("name", "binary:logistic")
+        if obj not in ("binary:logistic", "binary:logitraw"):
+            raise ValueError(f"unsupported objective {obj}: the reference trains XGBClassifier on 0/1 labels")
+        lp = learner["learner_model_param"]
+        bs = str(lp.get("base_score", "0.5")).strip("[]")
+        base_score = float(bs)
+        self.n_features = int(lp.get("num_feature", 0))
+        self.base_margin = float(np.log(base_score / (1.0 - base_score))) if obj == "binary:logistic" else base_score
+        booster = learner["gradient_booster"]
+        if booster.get("name", "gbtree") != "gbtree":
+            raise ValueError("only gbtree boosters are supported")
+        self.trees = []
+        for t in booster["model"]["trees"]:
+            self.trees.append(dict(
+                left=np.asarray(t["left_children"], dtype=np.int64), right=np.asarray(t["right_children"], dtype=np.int64),
+                feat=np.asarray(t["split_indices"], dtype=np.int64), cond=np.asarray(t["split_conditions"], dtype=np.float32),
+                dleft=np.asarray(t["default_left"], dtype=bool)))
+        return self
+
+    def margin(self, X: np.ndarray) -> np.ndarray:
+        X = np.asarray(X, dtype=np.float32)
+        out = np.full(X.shape[0], self.base_margin, dtype=np.float64)
+        rows = np.arange(X.shape[0])
+        for t in self.trees:
+            node = np.zeros(X.shape[0], dtype=np.int64)
+            active = t["left"][node] != -1
+            while active.any():
+                n = node[active]
+                v = X[rows[active], t["feat"][n]]
+                go_left = np.where(np.isnan(v), t["dleft"][n], v < t["cond"][n])      # xgboost: x < threshold -> left
+                node[active] = np.where(go_left, t["left"][n], t["right"][n])
+                active = t["left"][node] != -1
+            out += t["cond"][node]                                                     # leaf value
+        return out
+
+    def predict_proba(self, X: np.ndarray) -> np.ndarray:
+        p1 = 1.0 / (1.0 + np.exp(-self.margin(X)))
+        return np.stack([1.0 - p1, p1], axis=1).astype(np.float32)
+
+
+def infer_xgboost_model(model, embeddings) -> np.ndarray:
+    logging.info("Inferencing XGBoost model")
+    return model.predict_proba(embeddings)[:, 1]
+
+
+def parse_args(argv: Optional[Sequence[str]] = None):
+    p = argparse.ArgumentParser()
+    p.add_argument("-test", type=str, help="The directory of test data")
+    p.add_argument("-model", type=str, help="The directory of pre-trained model")
+    p.add_argument("-classifier", type=str, help="The directory of trained XGBoost models")
+    p.add_argument("-output", type=str, help="The directory of output")
+    p.add_argument("-device", type=str, default="cuda:0", help="The device to run the model")
+    p.add_argument("-batchSize", type=int, default=128, help="The batch size for the model")
+    p.add_argument("-tokenIdx", type=int, default=255, help="The index of the nucleotide")
+    p.add_argument("-save_memory", action="store_true", help="Flag to save memory, it only works for testing")
+    p.add_argument("-chunk_size", type=int, default=100000, help="The chunk size for testing, with -save_memory")
+    return p.parse_args(argv)
+
+
+def main(argv: Optional[Sequence[str]] = None):
+    import pandas as pd
+    from . import sharding
+    from .embeddings import extract_embeddings, load_data
+    from .zero_shot import load_model_and_tokenizer
+    logging.basicConfig(level=logging.INFO, format="%(asctime)s - %(levelname)s - %(message)s", datefmt="%Y-%m-%d %H:%M:%S")
+    args = parse_args(argv)
+    args.device = sharding.init_from_env(args.device)
+    os.makedirs(args.output, exist_ok=True)
+    model, tokenizer = load_model_and_tokenizer(args.model, args.device)
+    test_sequences, test_labels = load_data(args.test)
+    clf = XGBJsonClassifier().load_model(args.classifier)
+    prefix = os.path.basename(args.test).split(".")[0]
+    rank, _ = sharding.world()
+
+    def embeddings_for(seqs, cache):
+        if os.path.exists(cache):
+            logging.info(f"Found pre-computed embeddings, loading from file {cache}")
+            return np.load(cache)["test"]
+        emb = extract_embeddings(model, seqs, args.device, args.tokenIdx, tokenizer, args.batchSize)
+        if rank == 0:
+            np.savez_compressed(cache, test=emb)
+        return emb
+
+    if args.save_memory:
+        preds = []
+        for i in range(0, len(test_sequences), args.chunk_size):
+            emb = embeddings_for(test_sequences[i:i + args.chunk_size], os.path.join(args.output, f"{prefix}_chunk_{i}_embeddings.npz"))
+            preds.append(infer_xgboost_model(clf, emb))
+        predictions = np.concatenate(preds, axis=0) if preds else np.zeros(0, dtype=np.float32)
+    else:
+        predictions = infer_xgboost_model(clf, embeddings_for(test_sequences, os.path.join(args.output, prefix + "_embeddings.npz")))
+    if rank == 0:
+        pd.DataFrame({"label": test_labels, "prediction": predictions}).to_csv(
+            os.path.join(args.output, f"{prefix}_predictions.tsv"), sep="\t", index=False)
+        logging.info(f"Saved predictions to {os.path.join(args.output, f'{prefix}_predictions.tsv')}")
+
+
+if __name__ == "__main__":
+    main()

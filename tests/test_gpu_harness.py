@@ -121,3 +121,17 @@ def test_config2_l20_bf16_batch1024():
     top2 = np.sort(ref, 1)[:, -2:]
     conf = (top2[:, 1] - top2[:, 0]) > 6e-2
     assert (probs[:n].argmax(1)[conf] == ref.argmax(1)[conf]).all()
+
+
+def test_plantcad2_helpers_through_hip(golden_dir):
+    from plantcaduceus_amd import plantcad2_eval as pe
+    g = np.load(os.path.join(golden_dir, "harness_plantcad2.npz"))
+    df = pd.read_csv(os.path.join(golden_dir, "example_snp.tsv"), delimiter="\t")
+    seqs = df["sequences"].tolist()[: int(g["rows"])]
+    cfg = make_config("x", d_model=int(g["model_d_model"]), n_layer=int(g["model_n_layer"]))
+    m = hip_model(cfg, synthetic_state_dict(cfg, seed=int(g["model_seed"])), torch.float32)
+    tok = CaduceusTokenizer()
+    np.testing.assert_allclose(pe.masked_probs(m, tok, seqs, g["multi_idx"].tolist(), DEV, batch_size=4), g["multi"], rtol=1e-4, atol=1e-6)
+    un = pe.unmasked_probs(seqs, tok, m, DEV, batch_size=4)
+    np.testing.assert_allclose(un, g["unmasked"], rtol=1e-4, atol=1e-6)
+    assert (un.argmax(-1) == g["unmasked"].argmax(-1)).all()

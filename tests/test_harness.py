@@ -141,3 +141,20 @@ def test_cli_table_and_bed_outputs(golden_dir, tmp_path, monkeypatch):
     assert b.shape[1] == 6 and (b[2] - b[1] == 1).all()
     with pytest.raises(SystemExit):
         zero_shot.parse_args(["-input-vcf", "x.vcf", "-model", "m"])
+
+
+def test_plantcad2_probability_helpers_match_reference(golden_dir, snp_df):
+    """masked_probs / unmasked_probs vs the reference's own _masked_probs / _unmasked_probs (src/zero-shot-eval.py)."""
+    from plantcaduceus_amd import plantcad2_eval as pe
+    g = np.load(os.path.join(golden_dir, "harness_plantcad2.npz"))
+    seqs = snp_df["sequences"].tolist()[: int(g["rows"])]
+    model, tok = _oracle_model(g), CaduceusTokenizer()
+    np.testing.assert_allclose(pe.masked_probs(model, tok, seqs, int(g["single_idx"]), "cpu", batch_size=4), g["single"], rtol=2e-5, atol=1e-7)
+    multi = pe.masked_probs(model, tok, seqs, g["multi_idx"].tolist(), "cpu", batch_size=5)
+    assert multi.shape == (len(seqs) * 3, 4)
+    np.testing.assert_allclose(multi, g["multi"], rtol=2e-5, atol=1e-7)
+    un = pe.unmasked_probs(seqs, tok, model, "cpu", batch_size=4)
+    assert un.shape == g["unmasked"].shape == (len(seqs), 512, 4)
+    np.testing.assert_allclose(un, g["unmasked"], rtol=2e-5, atol=1e-7)
+    with pytest.raises(ValueError):
+        pe.unmasked_probs(["ACGT", "ACG"], tok, model, "cpu")
