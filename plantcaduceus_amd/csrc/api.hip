@@ -63,6 +63,7 @@ struct pcad_engine {
     int rdt;        // residual dtype
     int chunk;      // sequences per pass through the layer stack
     int nstreams;   // 1: everything on the caller's stream; 2: chunks alternate between two library streams
+    bool xzsplit;   // in_proj writes x and z as two blocked tensors (needs `blocked`); PCAD_PLAIN_XZ=1 turns it off (A/B knob)
     bool blocked;   // xc and y in the blocked layout (common.hpp::blocked_off); PCAD_PLAIN_LAYOUT=1 turns it off (A/B knob)
     bool bound = false;
     hipStream_t aux[2] = {nullptr, nullptr};
@@ -121,7 +122,7 @@ void carve_weights(pcad_engine* e, Carver& c) {
 }
 
 struct Workspace {
-    void *res, *u, *h, *xz, *xc[2], *dtl[2], *y;
+    void *res, *u, *h, *xz, *zb, *xc[2], *dtl[2], *y;
     float* bc[2];
     size_t bytes;
 };
@@ -134,7 +135,10 @@ Workspace carve_workspace(const pcad_engine* e, void* base, int Bc, int L) {
     w.res = c.take(rows * D * (e->rdt == F32 ? 4 : esz));
     w.u = c.take(rows * D * esz);
     w.h = c.take(rows * D * esz);
-    w.xz = c.take(rows * 2 * E * esz);
+    const size_t rows8z = (rows + 7) / 8 * 8;
+    // in_proj output: plain xz [rows, 2E]; or (xzsplit) x [rows8, E] in `xz` and z [rows8, E] in `zb`, both blocked
+    w.xz = c.take((e->xzsplit ? rows8z : rows * 2) * E * esz);
+    w.zb = e->xzsplit ? c.take(rows8z * E * esz) : nullptr;
     const size_t rows8 = (rows + 7) / 8 * 8;   // xc and y use the blocked layout: whole 8-row blocks
     w.xc[0] = c.take(rows8 * E * esz);
     w.xc[1] = c.take(rows8 * E * esz);
@@ -218,6 +222,7 @@ int pcad_create(const pcad_config* cfg, pcad_handle* out) {
     e->chunk = ck ? atoi(ck) : (131072 + e->E - 1) / e->E;
     if (e->chunk < 1) e->chunk = 1;
     e->blocked = getenv("PCAD_PLAIN_LAYOUT") == nullptr && (e->E * e->esz) % 128 == 0;
+    e->xzsplit = e->blocked && getenv("PCAD_PLAIN_XZ") == nullptr && e->E % 16 == 0;
     const char* ns = getenv("PCAD_STREAMS");
     // default 1: measured on MI355X (r01d) two lanes give 851 vs 852 seq/s -- co-running a VALU-bound scan and an
     // MFMA-bound GEMM slows each by the other's share (shared issue/power budget), so nothing is gained.
@@ -414,11 +419,12 @@ static int forward_impl(pcad_handle h, const int32_t* ids, int B, int L, const i
         }
         // in_proj (tied between directions: once per strand)
         { ProfScope ps(e, PCAD_K_GEMM_IN, s);
-        HIP_TRY(launch_gemm_nt(c.w.u, D, W.W_in, D, c.w.xz, 2 * E, rows, 2 * E, D, dt, dt, false, s)); }
+        if (e->xzsplit) HIP_TRY(launch_gemm_nt_two(c.w.u, D, W.W_in, D, c.w.xz, c.w.zb, E, true, rows, 2 * E, D, dt, s));
+        else HIP_TRY(launch_gemm_nt(c.w.u, D, W.W_in, D, c.w.xz, 2 * E, rows, 2 * E, D, dt, dt, false, s)); }
         // conv1d + SiLU, causal and anti-causal from one read of x
         { ProfScope ps(e, PCAD_K_CONV, s);
-        HIP_TRY(launch_conv_bidir(c.w.xz, 2 * E, W.dir[0].conv_w, W.dir[0].conv_b, W.dir[1].conv_w, W.dir[1].conv_b,
-                                  c.w.xc[0], c.w.xc[1], S, L, E, dt, e->blocked, s)); }
+        HIP_TRY(launch_conv_bidir(c.w.xz, e->xzsplit ? E : 2 * E, W.dir[0].conv_w, W.dir[0].conv_b, W.dir[1].conv_w,
+                                  W.dir[1].conv_b, c.w.xc[0], c.w.xc[1], S, L, E, dt, e->blocked, s, e->xzsplit)); }
         return PCAD_OK;
     };
     auto phase_V = [&](Lane& c, int li) -> int {        // x_proj + fused dt_proj/scan, both directions; out_proj
@@ -434,8 +440,10 @@ static int forward_impl(pcad_handle h, const int32_t* ids, int B, int L, const i
                                          e->blocked)); }
             // dt_proj (on MFMA inside the scan) + bias + softplus + recurrence + D skip + SiLU(z) gate
             ProfScope ps(e, PCAD_K_SCAN, s);
-            HIP_TRY(launch_scan(c.w.xc[d], (const char*)c.w.xz + (size_t)E * esz, 2 * E, nullptr, c.w.dtl[d], Rp, dw.Wdt, Rp,
-                                c.w.bc[d], dw.A2, 1.0f, dw.Dskip, dw.dt_bias, c.w.y, S, L, E, d == 1, d == 1, dt, s, e->blocked));
+            const void* zp = e->xzsplit ? c.w.zb : (const void*)((const char*)c.w.xz + (size_t)E * esz);
+            HIP_TRY(launch_scan(c.w.xc[d], zp, e->xzsplit ? E : 2 * E, nullptr, c.w.dtl[d], Rp, dw.Wdt, Rp,
+                                c.w.bc[d], dw.A2, 1.0f, dw.Dskip, dw.dt_bias, c.w.y, S, L, E, d == 1, d == 1, dt, s, e->blocked,
+                                e->xzsplit));
         }
         // out_proj on (y_fwd + y_rev): the two tied out_proj calls folded by linearity
         { ProfScope ps(e, PCAD_K_GEMM_OUT, s);

@@ -52,7 +52,7 @@ __global__ __launch_bounds__(256) void conv_bidir_kernel(const T* __restrict__ x
                                                          const float* __restrict__ wf, const float* __restrict__ bfw,
                                                          const float* __restrict__ wr, const float* __restrict__ brw,
                                                          T* __restrict__ yf, T* __restrict__ yr, int S, int L, int E,
-                                                         int out_blocked) {
+                                                         int out_blocked, int in_blocked) {
     typedef typename Raw8<T>::type raw_t;
     const int nchunk = E >> 3;
     const int nseg = (L + CONV_SEG - 1) / CONV_SEG;
@@ -65,6 +65,7 @@ __global__ __launch_bounds__(256) void conv_bidir_kernel(const T* __restrict__ x
     const int t0 = (int)(rb - (int64_t)s * nseg) * CONV_SEG;
     const int t1 = min(L, t0 + CONV_SEG);
     const T* xs = x + (int64_t)s * L * ldx + c;
+    const int64_t pieces = ((int64_t)E * sizeof(T)) >> 7;
 
     float wfv[8][4], wrv[8][4], bfv[8], brv[8];
 #pragma unroll
@@ -78,7 +79,9 @@ __global__ __launch_bounds__(256) void conv_bidir_kernel(const T* __restrict__ x
     load8<float>(brw + c, brv);
 
     auto row = [&](int t) -> raw_t {
-        return (t >= 0 && t < L) ? raw_load8<T>(xs + (int64_t)t * ldx) : raw_zero<raw_t>();
+        if (t < 0 || t >= L) return raw_zero<raw_t>();
+        if (in_blocked) return raw_load8<T>(x + blocked_off((int64_t)s * L + t, (int64_t)c * sizeof(T), pieces) / (int64_t)sizeof(T));
+        return raw_load8<T>(xs + (int64_t)t * ldx);
     };
 
     // ext[j] = x[t - 3 + j], j = 0..10 for the group starting at t; ext[0..6] carried, ext[7..10] prefetched
@@ -125,7 +128,7 @@ __global__ __launch_bounds__(256) void conv_bidir_kernel(const T* __restrict__ x
 
 hipError_t launch_conv_bidir(const void* x, int64_t ldx, const float* wf, const float* bf, const float* wr,
                              const float* br, void* yf, void* yr, int S, int L, int E, int dt, bool out_blocked,
-                             hipStream_t s) {
+                             hipStream_t s, bool in_blocked) {
     if (S <= 0 || L <= 0) return hipSuccess;
     if (E % 8) return hipErrorInvalidValue;
     if (out_blocked && (E * (dt == BF16 ? 2 : 4)) % 128) return hipErrorInvalidValue;
@@ -134,10 +137,10 @@ hipError_t launch_conv_bidir(const void* x, int64_t ldx, const float* wf, const 
     if (nb > 0x7fffffff) return hipErrorInvalidValue;
     if (dt == BF16)
         hipLaunchKernelGGL(conv_bidir_kernel<bf16_t>, dim3((unsigned)nb), dim3(256), 0, s, (const bf16_t*)x, ldx, wf,
-                           bf, wr, br, (bf16_t*)yf, (bf16_t*)yr, S, L, E, (int)out_blocked);
+                           bf, wr, br, (bf16_t*)yf, (bf16_t*)yr, S, L, E, (int)out_blocked, (int)in_blocked);
     else
         hipLaunchKernelGGL(conv_bidir_kernel<float>, dim3((unsigned)nb), dim3(256), 0, s, (const float*)x, ldx, wf, bf,
-                           wr, br, (float*)yf, (float*)yr, S, L, E, (int)out_blocked);
+                           wr, br, (float*)yf, (float*)yr, S, L, E, (int)out_blocked, (int)in_blocked);
     return hipGetLastError();
 }
 

@@ -303,7 +303,8 @@ template <typename T, typename OutT>
 __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm256_kernel(const T* __restrict__ A, int64_t lda,
                                                                   const T* __restrict__ W, int64_t ldw,
                                                                   OutT* __restrict__ C, int64_t ldc, int64_t M, int N,
-                                                                  int K, int tiles_m, int tiles_n, int a_blocked) {
+                                                                  int K, int tiles_m, int tiles_n, int a_blocked,
+                                                                  OutT* __restrict__ C2, int nsplit, int out_blocked) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -418,15 +419,29 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm256_kernel(const T* __res
                 lo[rr] = acc[i][0][rr]; lo[4 + rr] = acc[i][1][rr];
                 hi[rr] = acc[i][2][rr]; hi[4 + rr] = acc[i][3][rr];
             }
-            OutT* dst = C + m * ldc + nb;
-            if (nb + 16 <= N) {
+            // two-output form (in_proj): columns [0, nsplit) -> C, [nsplit, N) -> C2, each a tensor of nsplit / N - nsplit
+            // columns, plain or (out_blocked) in the blocked layout that the conv / x_proj / scan kernels read
+            OutT* dst;
+            int nlim = N, col = nb;
+            if (C2 != nullptr) {
+                const bool second = nb >= nsplit;
+                const int width = second ? N - nsplit : nsplit;
+                col = second ? nb - nsplit : nb;
+                nlim = width;
+                OutT* base = second ? C2 : C;
+                dst = base + (out_blocked ? blocked_off(m, (int64_t)col * sizeof(OutT), ((int64_t)width * sizeof(OutT)) >> 7) / (int64_t)sizeof(OutT)
+                                          : m * (int64_t)width + col);
+            } else {
+                dst = C + m * ldc + nb;
+            }
+            if (col + 16 <= nlim) {
                 store8<OutT>(dst, lo);
                 store8<OutT>(dst + 8, hi);
             } else {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
-                    if (nb + e < N) Elem<OutT>::store(dst + e, lo[e]);
-                    if (nb + 8 + e < N) Elem<OutT>::store(dst + 8 + e, hi[e]);
+                    if (col + e < nlim) Elem<OutT>::store(dst + e, lo[e]);
+                    if (col + 8 + e < nlim) Elem<OutT>::store(dst + 8 + e, hi[e]);
                 }
             }
         }
@@ -556,7 +571,8 @@ hipError_t launch_gemm_nt_split(const void* A, int64_t lda, const void* W, int64
 
 template <typename T>
 static hipError_t launch_gemm256_t(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc, int64_t M,
-                                   int N, int K, hipStream_t s, bool a_blocked) {
+                                   int N, int K, hipStream_t s, bool a_blocked, void* C2 = nullptr, int nsplit = 0,
+                                   bool out_blocked = false) {
     const int tiles_m = (int)((M + BM2 - 1) / BM2), tiles_n = (N + BN2 - 1) / BN2;
     dim3 grid((unsigned)persistent_grid(tiles_m * tiles_n)), block(GEMM_THREADS);
     auto kfn = gemm256_kernel<T, T>;
@@ -566,8 +582,22 @@ static hipError_t launch_gemm256_t(const void* A, int64_t lda, const void* W, in
         attr_done = true;
     }
     hipLaunchKernelGGL(kfn, grid, block, GEMM2_LDS, s, (const T*)A, lda, (const T*)W, ldw, (T*)C, ldc, M, N, K, tiles_m,
-                       tiles_n, (int)a_blocked);
+                       tiles_n, (int)a_blocked, (T*)C2, nsplit, (int)out_blocked);
     return hipGetLastError();
+}
+
+// in_proj form on the 256x256 kernel: columns [0, nsplit) -> C1, [nsplit, N) -> C2: two separate tensors of nsplit and
+// N - nsplit columns, plain (contiguous rows) or both in the blocked layout.
+hipError_t launch_gemm_nt_two(const void* A, int64_t lda, const void* W, int64_t ldw, void* C1, void* C2, int nsplit,
+                              bool out_blocked, int64_t M, int N, int K, int dt, hipStream_t s) {
+    if (M <= 0 || N <= 0) return hipSuccess;
+    const int esz = dt == BF16 ? 2 : 4;
+    if (K <= 0 || (K * esz) % ROWB || nsplit % 16 || N % 16 || nsplit <= 0 || nsplit >= N) return hipErrorInvalidValue;
+    if ((lda * esz) % 16 || (ldw * esz) % 16 || ((uintptr_t)A) % 16 || ((uintptr_t)W) % 16) return hipErrorInvalidValue;
+    if (((uintptr_t)C1) % 16 || ((uintptr_t)C2) % 16) return hipErrorInvalidValue;
+    if (out_blocked && ((nsplit * esz) % 128 || ((N - nsplit) * esz) % 128)) return hipErrorInvalidValue;
+    if (dt == BF16) return launch_gemm256_t<bf16_t>(A, lda, W, ldw, C1, nsplit, M, N, K, s, false, C2, nsplit, out_blocked);
+    return launch_gemm256_t<float>(A, lda, W, ldw, C1, nsplit, M, N, K, s, false, C2, nsplit, out_blocked);
 }
 
 hipError_t launch_gemm_nt(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc, int64_t M,

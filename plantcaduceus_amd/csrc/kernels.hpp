@@ -44,11 +44,17 @@ hipError_t launch_gemm_nt_split(const void* A, int64_t lda, const void* W, int64
                                 float* C2, int64_t ldc2, int nsplit, int64_t M, int N, int K, int dt, hipStream_t s,
                                 bool a_blocked = false);
 
+// in_proj form on the 256x256 kernel: columns [0, nsplit) -> C1, [nsplit, N) -> C2 (separate tensors of nsplit and
+// N - nsplit columns; both plain or both blocked).
+hipError_t launch_gemm_nt_two(const void* A, int64_t lda, const void* W, int64_t ldw, void* C1, void* C2, int nsplit,
+                              bool out_blocked, int64_t M, int N, int K, int dt, hipStream_t s);
+
 // conv.hip --------------------------------------------------------------------------------------
 // out_blocked: yf / yr in the blocked layout (common.hpp::blocked_off), buffers padded to a multiple of 8 rows.
+// in_blocked: x is a [S*L, E] tensor in the blocked layout (ldx ignored).
 hipError_t launch_conv_bidir(const void* x, int64_t ldx, const float* wf, const float* bf, const float* wr,
                              const float* br, void* yf, void* yr, int S, int L, int E, int dt, bool out_blocked,
-                             hipStream_t s);
+                             hipStream_t s, bool in_blocked = false);
 
 // scan.hip --------------------------------------------------------------------------------------
 // Selective scan of one direction.  delta == nullptr: fused dt_proj (delta tile = dt_low[rows, Rp] . Wdt[E, Rp]^T on
@@ -56,10 +62,11 @@ hipError_t launch_conv_bidir(const void* x, int64_t ldx, const float* wf, const 
 // bc: fp32 [rows, 32] = B_t | C_t.  The recurrence uses A2 * a_scale as the base-2 decay rate: pass
 // (A * log2(e), 1) or (A, log2(e)).
 // uy_blocked: u and y are in the blocked layout (whole-tensor row index s*L + t, buffers padded to 8 rows).
+// z_blocked (needs uy_blocked): z is a separate [S*L, E] tensor in the same blocked layout (ldz ignored).
 hipError_t launch_scan(const void* u, const void* z, int64_t ldz, const void* delta, const void* dt_low, int64_t lddt,
                        const void* Wdt, int Rp, const float* bc, const float* A2, float a_scale, const float* Dskip,
                        const float* dbias, void* y, int S, int L, int E, bool reverse, bool accumulate, int dt,
-                       hipStream_t s, bool uy_blocked = false);
+                       hipStream_t s, bool uy_blocked = false, bool z_blocked = false);
 
 // pack.hip --------------------------------------------------------------------------------------
 // generic 2-D copy/convert with zero padding: dst[r, c] (dst_dt, ld = dst_ld) = src[r, c] for r < rows, c < cols else 0

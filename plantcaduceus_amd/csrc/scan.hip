@@ -152,7 +152,7 @@ __global__ __launch_bounds__(64, 4) void scan_kernel(const T* __restrict__ u, co
                                                   const float* __restrict__ bc,
                                                   const float* __restrict__ A2, float a_scale,
                                                   const float* __restrict__ Dskip, const float* __restrict__ dbias,
-                                                  const T* yin, T* y, int L, int E, int uyb) {
+                                                  const T* yin, T* y, int L, int E, int uyb, int zblk) {
     __shared__ float dvs[TB][64];
     const int lane = threadIdx.x;
     const int c0 = blockIdx.x * 64;
@@ -188,7 +188,8 @@ __global__ __launch_bounds__(64, 4) void scan_kernel(const T* __restrict__ u, co
     const bool blk = BLK8 || uyb;       // BLK8 instantiations: known at compile time
     const auto u_r = blk ? make_rsrc(u, tot_rows * rowE) : make_rsrc(u + row0 * E + c0, (uint32_t)L * rowE);
     const auto y_r = blk ? make_rsrc(y, tot_rows * rowE) : make_rsrc(y + row0 * E + c0, (uint32_t)L * rowE);   // also the ACC input
-    const auto z_r = make_rsrc(HASZ ? z + row0 * ldz + c0 : u, (uint32_t)L * rowZ);
+    const bool zb_ = HASZ && blk && zblk;      // z: separate tensor in the same blocked layout as u -> same offsets
+    const auto z_r = zb_ ? make_rsrc(z, tot_rows * rowE) : make_rsrc(HASZ ? z + row0 * ldz + c0 : u, (uint32_t)L * rowZ);
     const auto d_r = make_rsrc(FUSED ? u : dsrc + row0 * ldd + c0, (uint32_t)L * rowD);
     const float* __restrict__ bc_s = bc + row0 * (2 * NSTATE);
     const int voff = lane * (int)esz;
@@ -222,7 +223,7 @@ __global__ __launch_bounds__(64, 4) void scan_kernel(const T* __restrict__ u, co
         for (int i = 0; i < CH; ++i) {
             const uint32_t t = (uint32_t)tclamp(s0 + i);
             uu[i] = BufIO<T>::load(u_r, uy_voff(i), uy_soff(s0, i));
-            if constexpr (HASZ) zz[i] = BufIO<T>::load(z_r, voff, t * rowZ);
+            if constexpr (HASZ) zz[i] = zb_ ? BufIO<T>::load(z_r, uy_voff(i), uy_soff(s0, i)) : BufIO<T>::load(z_r, voff, t * rowZ);
             if constexpr (ACC) yy[i] = BufIO<T>::load(y_r, uy_voff(i), uy_soff(s0, i));
             if constexpr (!FUSED) dd[i] = BufIO<T>::load(d_r, voff, t * rowD);
         }
@@ -326,11 +327,11 @@ template <typename T, bool FUSED, bool PRE = false, bool BLK8 = false>
 static hipError_t launch_scan_t(const void* u, const void* z, int64_t ldz, const void* dsrc, int64_t ldd,
                                 const void* Wdt, int Rp, const float* bc, const float* A2, float a_scale,
                                 const float* Dskip, const float* dbias, void* y, int S, int L, int E, bool reverse,
-                                bool accumulate, hipStream_t s, bool uyb) {
+                                bool accumulate, hipStream_t s, bool uyb, bool zblk = false) {
     dim3 grid((unsigned)(E / 64), (unsigned)S), block(64);
 #define PCAD_SCAN(REV, ACC, HZ)                                                                                    \
     hipLaunchKernelGGL((scan_kernel<T, REV, ACC, HZ, FUSED, PRE, BLK8>), grid, block, 0, s, (const T*)u, (const T*)z, ldz,       \
-                       (const T*)dsrc, ldd, (const T*)Wdt, Rp, bc, A2, a_scale, Dskip, dbias, (const T*)y, (T*)y, L, E, (int)uyb)
+                       (const T*)dsrc, ldd, (const T*)Wdt, Rp, bc, A2, a_scale, Dskip, dbias, (const T*)y, (T*)y, L, E, (int)uyb, (int)zblk)
     const bool hz = z != nullptr;
     if (!reverse && !accumulate) { if (hz) PCAD_SCAN(false, false, true); else PCAD_SCAN(false, false, false); }
     else if (!reverse && accumulate) { if (hz) PCAD_SCAN(false, true, true); else PCAD_SCAN(false, true, false); }
@@ -343,7 +344,8 @@ static hipError_t launch_scan_t(const void* u, const void* z, int64_t ldz, const
 hipError_t launch_scan(const void* u, const void* z, int64_t ldz, const void* delta, const void* dt_low, int64_t lddt,
                        const void* Wdt, int Rp, const float* bc, const float* A2, float a_scale, const float* Dskip,
                        const float* dbias, void* y, int S, int L, int E, bool reverse, bool accumulate, int dt,
-                       hipStream_t s, bool uyb) {
+                       hipStream_t s, bool uyb, bool zblk) {
+    if (zblk && !uyb) return hipErrorInvalidValue;
     if (S <= 0 || L <= 0) return hipSuccess;
     if (E % 64) return hipErrorInvalidValue;
     if ((int64_t)L * (ldz > E ? ldz : E) * 4 >= ((int64_t)1 << 31)) return hipErrorInvalidValue;   // 32-bit in-strand offsets
@@ -353,14 +355,14 @@ hipError_t launch_scan(const void* u, const void* z, int64_t ldz, const void* de
     if (fused && (!dt_low || !Wdt || Rp <= 0 || Rp % 64)) return hipErrorInvalidValue;
     if (dt == BF16) {
         if (fused && Rp == 64 && lddt % 8 == 0 && uyb && L % 8 == 0)
-            return launch_scan_t<bf16_t, true, true, true>(u, z, ldz, dt_low, lddt, Wdt, Rp, bc, A2, a_scale, Dskip, dbias, y, S, L, E, reverse, accumulate, s, uyb);
+            return launch_scan_t<bf16_t, true, true, true>(u, z, ldz, dt_low, lddt, Wdt, Rp, bc, A2, a_scale, Dskip, dbias, y, S, L, E, reverse, accumulate, s, uyb, zblk);
         if (fused && Rp == 64 && lddt % 8 == 0)
-            return launch_scan_t<bf16_t, true, true>(u, z, ldz, dt_low, lddt, Wdt, Rp, bc, A2, a_scale, Dskip, dbias, y, S, L, E, reverse, accumulate, s, uyb);
-        if (fused) return launch_scan_t<bf16_t, true>(u, z, ldz, dt_low, lddt, Wdt, Rp, bc, A2, a_scale, Dskip, dbias, y, S, L, E, reverse, accumulate, s, uyb);
-        return launch_scan_t<bf16_t, false>(u, z, ldz, delta, E, nullptr, 0, bc, A2, a_scale, Dskip, dbias, y, S, L, E, reverse, accumulate, s, uyb);
+            return launch_scan_t<bf16_t, true, true>(u, z, ldz, dt_low, lddt, Wdt, Rp, bc, A2, a_scale, Dskip, dbias, y, S, L, E, reverse, accumulate, s, uyb, zblk);
+        if (fused) return launch_scan_t<bf16_t, true>(u, z, ldz, dt_low, lddt, Wdt, Rp, bc, A2, a_scale, Dskip, dbias, y, S, L, E, reverse, accumulate, s, uyb, zblk);
+        return launch_scan_t<bf16_t, false>(u, z, ldz, delta, E, nullptr, 0, bc, A2, a_scale, Dskip, dbias, y, S, L, E, reverse, accumulate, s, uyb, zblk);
     }
-    if (fused) return launch_scan_t<float, true>(u, z, ldz, dt_low, lddt, Wdt, Rp, bc, A2, a_scale, Dskip, dbias, y, S, L, E, reverse, accumulate, s, uyb);
-    return launch_scan_t<float, false>(u, z, ldz, delta, E, nullptr, 0, bc, A2, a_scale, Dskip, dbias, y, S, L, E, reverse, accumulate, s, uyb);
+    if (fused) return launch_scan_t<float, true>(u, z, ldz, dt_low, lddt, Wdt, Rp, bc, A2, a_scale, Dskip, dbias, y, S, L, E, reverse, accumulate, s, uyb, zblk);
+    return launch_scan_t<float, false>(u, z, ldz, delta, E, nullptr, 0, bc, A2, a_scale, Dskip, dbias, y, S, L, E, reverse, accumulate, s, uyb, zblk);
 }
 
 }  // namespace pcad
