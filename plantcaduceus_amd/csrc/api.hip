@@ -48,6 +48,7 @@ struct DirWeights {
 };
 
 struct LayerWeights {
+    float* convw;    // conv taps of both directions packed per K-tile for the fused conv+x_proj kernel
     float* norm_w;   // [D]
     void* W_in;      // [2E, D]
     void* W_out;     // [D, E]
@@ -63,6 +64,7 @@ struct pcad_engine {
     int rdt;        // residual dtype
     int chunk;      // sequences per pass through the layer stack
     int nstreams;   // 1: everything on the caller's stream; 2: chunks alternate between two library streams
+    bool convx;     // conv + x_proj of both directions in one kernel (needs xzsplit and Rp == 64); PCAD_NO_CONVX=1: off
     bool xzsplit;   // in_proj writes x and z as two blocked tensors (needs `blocked`); PCAD_PLAIN_XZ=1 turns it off (A/B knob)
     bool blocked;   // xc and y in the blocked layout (common.hpp::blocked_off); PCAD_PLAIN_LAYOUT=1 turns it off (A/B knob)
     bool bound = false;
@@ -106,6 +108,7 @@ void carve_weights(pcad_engine* e, Carver& c) {
     e->layers.resize(e->nl);
     for (auto& L : e->layers) {
         L.norm_w = (float*)c.take(D * 4);
+        L.convw = (float*)c.take(convx_packed_bytes((int)E, e->cfg.dtype));
         L.W_in = c.take(2 * E * D * esz);
         L.W_out = c.take(D * E * esz);
         for (int d = 0; d < 2; ++d) {
@@ -223,6 +226,7 @@ int pcad_create(const pcad_config* cfg, pcad_handle* out) {
     if (e->chunk < 1) e->chunk = 1;
     e->blocked = getenv("PCAD_PLAIN_LAYOUT") == nullptr && (e->E * e->esz) % 128 == 0;
     e->xzsplit = e->blocked && getenv("PCAD_PLAIN_XZ") == nullptr && e->E % 16 == 0;
+    e->convx = e->xzsplit && e->Rp == 64 && getenv("PCAD_NO_CONVX") == nullptr;
     const char* ns = getenv("PCAD_STREAMS");
     // default 1: measured on MI355X (r01d) two lanes give 851 vs 852 seq/s -- co-running a VALU-bound scan and an
     // MFMA-bound GEMM slows each by the other's share (shared issue/power budget), so nothing is gained.
@@ -329,6 +333,8 @@ int pcad_bind_weights(pcad_handle h, const pcad_tensor* tensors, int n, void* ar
             NEED(t_D, mp + "D", (int64_t)E);
             HIP_TRY(launch_pack2d(t_D->data, t_D->dtype, E, w.Dskip, F32, E, 1, E, 1, E, s));
         }
+        if ((E * e->esz) % 128 == 0)
+            HIP_TRY(launch_pack_convw(L.dir[0].conv_w, L.dir[0].conv_b, L.dir[1].conv_w, L.dir[1].conv_b, L.convw, E, dt, s));
     }
 #undef NEED
     e->bound = true;
@@ -421,10 +427,16 @@ static int forward_impl(pcad_handle h, const int32_t* ids, int B, int L, const i
         { ProfScope ps(e, PCAD_K_GEMM_IN, s);
         if (e->xzsplit) HIP_TRY(launch_gemm_nt_two(c.w.u, D, W.W_in, D, c.w.xz, c.w.zb, E, true, rows, 2 * E, D, dt, s));
         else HIP_TRY(launch_gemm_nt(c.w.u, D, W.W_in, D, c.w.xz, 2 * E, rows, 2 * E, D, dt, dt, false, s)); }
-        // conv1d + SiLU, causal and anti-causal from one read of x
-        { ProfScope ps(e, PCAD_K_CONV, s);
-        HIP_TRY(launch_conv_bidir(c.w.xz, e->xzsplit ? E : 2 * E, W.dir[0].conv_w, W.dir[0].conv_b, W.dir[1].conv_w,
-                                  W.dir[1].conv_b, c.w.xc[0], c.w.xc[1], S, L, E, dt, e->blocked, s, e->xzsplit)); }
+        // conv1d + SiLU, causal and anti-causal from one read of x (fused with x_proj of both directions when possible)
+        if (e->convx) {
+            ProfScope ps(e, PCAD_K_CONV, s);
+            HIP_TRY(launch_convx(c.w.xz, W.convw, W.dir[0].Wx, c.w.xc[0], c.w.dtl[0], c.w.bc[0], W.dir[1].Wx, c.w.xc[1],
+                                 c.w.dtl[1], c.w.bc[1], S, L, E, dt, s));
+        } else {
+            ProfScope ps(e, PCAD_K_CONV, s);
+            HIP_TRY(launch_conv_bidir(c.w.xz, e->xzsplit ? E : 2 * E, W.dir[0].conv_w, W.dir[0].conv_b, W.dir[1].conv_w,
+                                      W.dir[1].conv_b, c.w.xc[0], c.w.xc[1], S, L, E, dt, e->blocked, s, e->xzsplit));
+        }
         return PCAD_OK;
     };
     auto phase_V = [&](Lane& c, int li) -> int {        // x_proj + fused dt_proj/scan, both directions; out_proj
@@ -435,7 +447,7 @@ static int forward_impl(pcad_handle h, const int32_t* ids, int B, int L, const i
         for (int d = 0; d < 2; ++d) {
             const DirWeights& dw = W.dir[d];
             // x_proj -> dt_low [rows, Rp] (model dtype, zero padded) and B_t | C_t [rows, 32] (fp32 side output)
-            { ProfScope ps(e, PCAD_K_GEMM_X, s);
+            if (!e->convx) { ProfScope ps(e, PCAD_K_GEMM_X, s);
             HIP_TRY(launch_gemm_nt_split(c.w.xc[d], E, dw.Wx, E, c.w.dtl[d], Rp, c.w.bc[d], 2 * N, Rp, rows, XP, E, dt, s,
                                          e->blocked)); }
             // dt_proj (on MFMA inside the scan) + bias + softplus + recurrence + D skip + SiLU(z) gate

@@ -56,6 +56,15 @@ hipError_t launch_conv_bidir(const void* x, int64_t ldx, const float* wf, const 
                              const float* br, void* yf, void* yr, int S, int L, int E, int dt, bool out_blocked,
                              hipStream_t s, bool in_blocked = false);
 
+// convx.hip -------------------------------------------------------------------------------------
+// Fused conv1d+SiLU (both directions) + x_proj (both directions), Rp == 64: x [S*L, E] blocked -> xc0 / xc1 [S*L, E]
+// blocked, dtl_d [S*L, 64] (dtype dt), bc_d [S*L, 32] fp32.  convw: taps packed by launch_pack_convw.
+size_t convx_packed_bytes(int E, int dt);
+hipError_t launch_pack_convw(const float* wf, const float* bf, const float* wr, const float* br, float* out, int E, int dt,
+                             hipStream_t s);
+hipError_t launch_convx(const void* x, const float* convw, const void* Wx0, void* xc0, void* dtl0, float* bc0,
+                        const void* Wx1, void* xc1, void* dtl1, float* bc1, int S, int L, int E, int dt, hipStream_t s);
+
 // scan.hip --------------------------------------------------------------------------------------
 // Selective scan of one direction.  delta == nullptr: fused dt_proj (delta tile = dt_low[rows, Rp] . Wdt[E, Rp]^T on
 // MFMA inside the kernel, Rp % 64 == 0, zero-padded K);  delta != nullptr: delta [rows, E] read from memory.
