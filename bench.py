@@ -55,6 +55,9 @@ def algorithmic_work(cfg, rows, esz):
     w["gemm_out_proj"] = dict(flops=2.0 * rows * E * D, bytes=esz * (rows * E + rows * D + E * D))
     w["add_rmsnorm"] = dict(flops=4.0 * rows * D, bytes=rows * D * (2 * esz + 8))
     w["conv1d_bidir"] = dict(flops=2.0 * 2 * 4 * rows * E, bytes=esz * rows * E * 3)
+    # fused conv + SiLU (both directions) + x_proj (both directions): x read once, xc_f / xc_r / dt_low / B|C written
+    w["conv_xproj_fused"] = dict(flops=2.0 * 2 * 4 * rows * E + 2 * 2.0 * rows * E * X,
+                                 bytes=esz * (rows * E * 3 + 2 * rows * Rp + 2 * X * E) + 2 * 4 * rows * 2 * N)
     # per direction launch: read u, z (+ y for the accumulating direction: averaged 0.5), dt_low, B|C (fp32); write y.
     # flops: dt_proj contraction on MFMA (2*R*E) + 6 per state update; valu_cycles: measured issue costs on gfx950
     # (tools/valu_microbench.hip, 4 waves/SIMD, 2.4 GHz nominal): per (t, 64-channel wave) 16 states x (2 pk_mul +
@@ -154,6 +157,8 @@ def main():
         rows = 2 * chunk * L
         work = algorithmic_work(cfg, rows, esz)
         kern = {}
+        if stats.get("conv1d_bidir", (0, 0))[0] and not stats.get("gemm_x_proj", (0, 0))[0]:
+            stats = {("conv_xproj_fused" if k == "conv1d_bidir" else k): v for k, v in stats.items()}   # fused build
         for name, (n, ms) in stats.items():
             if n:
                 avg = ms / n
@@ -161,7 +166,7 @@ def main():
                               "TFLOP/s": round(work[name]["flops"] / (avg * 1e-3) / 1e12, 2),
                               "GB/s": round(work[name]["bytes"] / (avg * 1e-3) / 1e9, 1)}
         if kern:
-            per_step = {"add_rmsnorm": 1, "gemm_in_proj": 1, "conv1d_bidir": 1, "gemm_x_proj": 2, "selective_scan": 2,
+            per_step = {"add_rmsnorm": 1, "gemm_in_proj": 1, "conv1d_bidir": 1, "conv_xproj_fused": 1, "gemm_x_proj": 2, "selective_scan": 2,
                         "gemm_out_proj": 1, "final_head": 0}     # launches per layer and chunk
             for name in kern:
                 kern[name]["est_ms_per_step"] = round(kern[name]["avg_ms"] * per_step.get(name, 0) * cfg.n_layer * nchunks, 2)

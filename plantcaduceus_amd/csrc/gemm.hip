@@ -500,6 +500,269 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm256_kernel(const T* __res
     epilogue(pm0, pn0);
 }
 
+// =====================================================================================================================
+// 256x256 tile, A in a 3-stage ring and W in a 2-stage ring (3 x 32 + 2 x 32 KiB = all 160 KiB of the CU's LDS).
+// Same wave tiling, fragments, phases and epilogue as gemm256_kernel; what changes is WHEN the LDS-DMAs are issued:
+//   * A streams from HBM (each element once), W is re-read from L2 by every m-panel, so A gets the deeper ring:
+//     A(g+3) is issued in four single pieces, one per phase (phase 4 of iteration g ... phase 3 of g+1) and has at least
+//     one whole K-tile to land; W(g+2) is issued in phases 3 and 4 of iteration g (two pieces each) after a second
+//     barrier that marks the end of all reads of W(g) (its last fragment read is in phase 2).
+//   * every phase therefore carries 1, 1, 3, 3 DMA instructions per wave instead of 0, 0, 0, 8, and the two waves of a
+//     SIMD (w, w + 4) issue theirs on opposite sides of the phase's 16 MFMAs, so one wave's MFMAs cover the other's
+//     DMA issue time (measured: an LDS-DMA costs its wave 60-185 issue cycles).
+//   * one counted wait per K-tile: at the barrier that releases K-tile g+1 the younger DMAs still in flight are
+//     A(g+2) (4) and W(g+2)'s first half (2): s_waitcnt vmcnt(6).
+constexpr int GEMM3_A_STAGES = 3, GEMM3_W_STAGES = 2;
+constexpr int GEMM3_OFF_W = GEMM3_A_STAGES * A2_BYTES;
+constexpr int GEMM3_LDS = GEMM3_OFF_W + GEMM3_W_STAGES * W2_BYTES;     // 160 KiB
+
+template <typename T, typename OutT>
+__global__ __launch_bounds__(GEMM_THREADS, 2) void gemm256r_kernel(const T* __restrict__ A, int64_t lda,
+                                                                   const T* __restrict__ W, int64_t ldw,
+                                                                   OutT* __restrict__ C, int64_t ldc, int64_t M, int N,
+                                                                   int K, int tiles_m, int tiles_n, int a_blocked,
+                                                                   OutT* __restrict__ C2, int nsplit, int out_blocked) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);    // 0..7
+    const int gstride = (int)gridDim.x;
+    const int nblk = tiles_m * tiles_n;
+    const int nkt = (K * (int)sizeof(T)) / ROWB;
+    if ((int)blockIdx.x >= nblk) return;
+    const int my_tiles = (nblk - (int)blockIdx.x + gstride - 1) / gstride;
+    const int G = my_tiles * nkt;                                 // K-tiles this block walks
+
+    auto tile_coords = [&](int tile, int64_t& m0, int& n0) {
+        const int xcd = tile & 7, idx = tile >> 3;
+        const int q = nblk >> 3, r = nblk & 7;
+        const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+        const int gsz = GROUP_M * tiles_n;
+        const int g = logical / gsz;
+        const int first_m = g * GROUP_M;
+        const int gm = min(GROUP_M, tiles_m - first_m);
+        const int in_g = logical - g * gsz;
+        m0 = (int64_t)(first_m + in_g % gm) * BM2;
+        n0 = (in_g / gm) * BN2;
+    };
+
+    // two staging cursors (A runs one K-tile further ahead than W); wave stages rows [wave*32, +32) of either tile
+    const char* pa[4];
+    const char* pw[4];
+    auto set_pa = [&](int64_t m0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = wave * 32 + i * 8 + (lane >> 3);
+            int64_t ga = m0 + row; if (ga > M - 1) ga = M - 1;
+            const int64_t abyte = a_blocked ? blocked_off(ga, 0, (lda * (int64_t)sizeof(T)) >> 7) : ga * lda * (int64_t)sizeof(T);
+            pa[i] = reinterpret_cast<const char*>(A) + abyte + (((lane & 7) ^ key_a(row)) << 4);
+        }
+    };
+    auto set_pw = [&](int n0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = wave * 32 + i * 8 + (lane >> 3);
+            int gw = n0 + row; if (gw > N - 1) gw = N - 1;
+            pw[i] = reinterpret_cast<const char*>(W + (int64_t)gw * ldw) + (((lane & 7) ^ key_w(row)) << 4);
+        }
+    };
+    int a_tile = blockIdx.x, a_kt = 0, a_g = 0;       // next A K-tile to issue (global index a_g)
+    int w_tile = blockIdx.x, w_kt = 0, w_g = 0;
+    auto a_piece = [&](int sa, int p) {               // piece p of A(a_g) -> A stage sa
+        if (a_g < G) {
+            const int64_t koa = a_blocked ? (int64_t)a_kt * 1024 : (int64_t)a_kt * ROWB;
+            glds16(pa[p] + koa, smem + sa * A2_BYTES + (wave * 32 + p * 8) * ROWB);
+        }
+    };
+    auto a_advance = [&]() {
+        if (a_g < G) {
+            ++a_g;
+            if (++a_kt == nkt) {
+                a_kt = 0;
+                a_tile += gstride;
+                if (a_tile < nblk) { int64_t m0; int n0; tile_coords(a_tile, m0, n0); set_pa(m0); }
+            }
+        }
+    };
+    auto w_pieces = [&](int sw, int p0) {             // pieces p0, p0 + 1 of W(w_g) -> W stage sw
+        if (w_g < G) {
+            const int64_t ko = (int64_t)w_kt * ROWB;
+            glds16(pw[p0] + ko, smem + GEMM3_OFF_W + sw * W2_BYTES + (wave * 32 + p0 * 8) * ROWB);
+            glds16(pw[p0 + 1] + ko, smem + GEMM3_OFF_W + sw * W2_BYTES + (wave * 32 + (p0 + 1) * 8) * ROWB);
+        }
+    };
+    auto w_advance = [&]() {
+        if (w_g < G) {
+            ++w_g;
+            if (++w_kt == nkt) {
+                w_kt = 0;
+                w_tile += gstride;
+                if (w_tile < nblk) { int64_t m0; int n0; tile_coords(w_tile, m0, n0); set_pw(n0); }
+            }
+        }
+    };
+
+    const int wm = wave >> 2, wn = wave & 3;
+    const int li = lane & 15, lg = lane >> 4;
+    int a_off[8], a_key[8], w_off[4], w_key[4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int ra = wm * 128 + i * 16 + li;
+        a_off[i] = ra * ROWB; a_key[i] = key_a(ra);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int rw = wn * 64 + (li >> 2) * 16 + j * 4 + (li & 3);
+        w_off[j] = GEMM3_OFF_W + rw * ROWB; w_key[j] = key_w(rw);
+    }
+    auto load_a = [&](int sa, int kk, int half, u32x4 (&a)[4]) {
+        const char* base = smem + sa * A2_BYTES;
+        const int chunk = kk * 4 + lg;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            a[i] = *reinterpret_cast<const u32x4*>(base + a_off[half * 4 + i] + ((chunk ^ a_key[half * 4 + i]) << 4));
+    };
+    auto load_w = [&](int sw, int kk, u32x4 (&w)[4]) {
+        const char* base = smem + sw * W2_BYTES;
+        const int chunk = kk * 4 + lg;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) w[j] = *reinterpret_cast<const u32x4*>(base + w_off[j] + ((chunk ^ w_key[j]) << 4));
+    };
+
+    f32x4 acc[8][4];
+    auto zero_acc = [&]() {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    };
+    auto mma = [&](int half, const u32x4 (&a)[4], const u32x4 (&w)[4]) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[half * 4 + i][j] = Mma<T>::run(w[j], a[i], acc[half * 4 + i][j]);
+    };
+    auto epilogue = [&](int64_t m0, int n0) {       // lane: 16 consecutive columns nb .. nb+15 of 8 rows
+        const int nb = n0 + wn * 64 + lg * 16;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int64_t m = m0 + wm * 128 + i * 16 + li;
+            if (m >= M) continue;
+            float lo[8], hi[8];
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                lo[rr] = acc[i][0][rr]; lo[4 + rr] = acc[i][1][rr];
+                hi[rr] = acc[i][2][rr]; hi[4 + rr] = acc[i][3][rr];
+            }
+            OutT* dst;
+            int nlim = N, col = nb;
+            if (C2 != nullptr) {                    // two-output form (in_proj), see gemm256_kernel
+                const bool second = nb >= nsplit;
+                const int width = second ? N - nsplit : nsplit;
+                col = second ? nb - nsplit : nb;
+                nlim = width;
+                OutT* base = second ? C2 : C;
+                dst = base + (out_blocked ? blocked_off(m, (int64_t)col * sizeof(OutT), ((int64_t)width * sizeof(OutT)) >> 7) / (int64_t)sizeof(OutT)
+                                          : m * (int64_t)width + col);
+            } else {
+                dst = C + m * ldc + nb;
+            }
+            if (col + 16 <= nlim) {
+                store8<OutT>(dst, lo);
+                store8<OutT>(dst + 8, hi);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    if (col + e < nlim) Elem<OutT>::store(dst + e, lo[e]);
+                    if (col + 8 + e < nlim) Elem<OutT>::store(dst + 8 + e, hi[e]);
+                }
+            }
+        }
+    };
+
+    int tile = blockIdx.x;
+    int64_t m0; int n0;
+    tile_coords(tile, m0, n0);
+    set_pa(m0);
+    set_pw(n0);
+    // prologue: A(0) W(0) | A(1) W(1) | A(2) piece 0  -> wait for the first eight, leave the rest in flight
+#pragma unroll
+    for (int p = 0; p < 4; ++p) a_piece(0, p);
+    a_advance();
+    w_pieces(0, 0); w_pieces(0, 2); w_advance();
+#pragma unroll
+    for (int p = 0; p < 4; ++p) a_piece(1, p);
+    a_advance();
+    w_pieces(1, 0); w_pieces(1, 2); w_advance();
+    a_piece(2, 0);
+    if (G >= 3) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    u32x4 a0[4], a1[4], w0[4], w1[4];
+    load_a(0, 0, 0, a0);
+    load_w(0, 0, w0);
+    zero_acc();
+    int sa = 0, sw = 0, kt = 0, g = 0;
+    int sa_fill = 2;                      // A stage that A(a_g) is being filled into
+    bool pending = false;
+    int64_t pm0 = 0; int pn0 = 0;
+    while (true) {
+        if (pending) {                    // previous tile's result (all its MFMAs were issued in the last iteration)
+            epilogue(pm0, pn0);
+            zero_acc();
+            pending = false;
+        }
+        const int sa_n = sa == 2 ? 0 : sa + 1;
+        if (wm == 0) a_piece(sa_fill, 1);
+        load_a(sa, 0, 1, a1);             // phase 1: (m lo, k lo)
+        mma(0, a0, w0);
+        if (wm != 0) a_piece(sa_fill, 1);
+
+        if (wm == 0) a_piece(sa_fill, 2);
+        load_a(sa, 1, 0, a0);             // phase 2: (m hi, k lo)
+        load_w(sw, 1, w1);
+        mma(1, a1, w0);
+        if (wm != 0) a_piece(sa_fill, 2);
+        // every wave's reads of W stage sw are complete -> refill it with W(g+2) during phases 3 and 4
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+
+        if (wm == 0) { a_piece(sa_fill, 3); w_pieces(sw, 0); }
+        load_a(sa, 1, 1, a1);             // phase 3: (m lo, k hi)
+        mma(0, a0, w1);
+        if (wm != 0) { a_piece(sa_fill, 3); w_pieces(sw, 0); }
+        a_advance();
+        // K-tile g+1 (A and W) must have landed; younger and allowed in flight: A(g+2) x4, W(g+2) x2
+        if (g + 2 < G) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+
+        sa_fill = sa;                     // A stage sa is free: A(g+3) starts filling it
+        if (wm == 0) { w_pieces(sw, 2); a_piece(sa_fill, 0); }
+        load_a(sa_n, 0, 0, a0);           // phase 4: (m hi, k hi), with the first fragments of K-tile g+1 in flight
+        load_w(sw ^ 1, 0, w0);
+        mma(1, a1, w1);
+        if (wm != 0) { w_pieces(sw, 2); a_piece(sa_fill, 0); }
+        w_advance();
+        sa = sa_n;
+        sw ^= 1;
+        ++g;
+        if (kt + 1 < nkt) {
+            ++kt;
+        } else {
+            pending = true; pm0 = m0; pn0 = n0;
+            tile += gstride;
+            if (tile >= nblk) break;
+            tile_coords(tile, m0, n0);
+            kt = 0;
+        }
+    }
+    epilogue(pm0, pn0);
+}
+
 // persistent launch: 1 resident block of 8 waves per CU (LDS-limited), a multiple of 8 so block b stays on XCD b & 7
 static int persistent_grid(int nblk) {
     static int cus = 0;
@@ -575,6 +838,19 @@ static hipError_t launch_gemm256_t(const void* A, int64_t lda, const void* W, in
                                    bool out_blocked = false) {
     const int tiles_m = (int)((M + BM2 - 1) / BM2), tiles_n = (N + BN2 - 1) / BN2;
     dim3 grid((unsigned)persistent_grid(tiles_m * tiles_n)), block(GEMM_THREADS);
+    static const bool ring = getenv("PCAD_GEMM_NORING") == nullptr;   // developer knob: the 2-stage kernel for A/B runs
+    if (ring) {
+        auto kr = gemm256r_kernel<T, T>;
+        static bool attr_r = false;
+        if (!attr_r) {
+            hipError_t e = hipFuncSetAttribute((const void*)kr, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM3_LDS);
+            if (e != hipSuccess) return e;
+            attr_r = true;
+        }
+        hipLaunchKernelGGL(kr, grid, block, GEMM3_LDS, s, (const T*)A, lda, (const T*)W, ldw, (T*)C, ldc, M, N, K, tiles_m,
+                           tiles_n, (int)a_blocked, (T*)C2, nsplit, (int)out_blocked);
+        return hipGetLastError();
+    }
     auto kfn = gemm256_kernel<T, T>;
     static bool attr_done = false;
     if (!attr_done) {

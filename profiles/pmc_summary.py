@@ -43,7 +43,8 @@ def main():
     cls = {"selective_scan": [k for k in res if "scan_kernel" in k],
            "gemm_in_out_proj": [k for k in res if "gemm256_kernel" in k] or [k for k in res if "gemm_nt_kernel" in k and k.endswith("false>")],
            "gemm_x_proj": [k for k in res if "gemm_nt_kernel" in k and k.endswith("true>")],
-           "conv1d_bidir": [k for k in res if "conv" in k],
+           "conv1d_bidir": [k for k in res if "conv_bidir" in k],
+           "conv_xproj_fused": [k for k in res if "convx_kernel" in k],
            "add_rmsnorm": [k for k in res if "add_rmsnorm" in k and k.endswith("false>")]}
     o = {"source": NOTE_SRC, "correction": NOTE_CORR, "kernels": res, "classes": {}}
     for c, ks in cls.items():

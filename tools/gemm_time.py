@@ -14,4 +14,12 @@ for (M, N, K) in [(65536, 4096, 1024), (65536, 1024, 2048)]:
     for _ in range(20): ops.linear(x, w)
     b.record(); torch.cuda.synchronize()
     ms = a.elapsed_time(b) / 20
-    print(f"no256={os.environ.get('PCAD_GEMM_NO256','')} M={M} N={N} K={K}: {ms:.4f} ms  {2.0*M*N*K/ms/1e9:.0f} TF  relerr {err:.2e} {err2:.2e}")
+    print(f"M={M} N={N} K={K}: {ms:.4f} ms  {2.0*M*N*K/ms/1e9:.0f} TF  relerr {err:.2e} {err2:.2e}")
+    # yardstick only (not used by the product path): the vendor library on the same shape
+    y = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+    for _ in range(3): torch.matmul(x, w.t(), out=y)
+    torch.cuda.synchronize(); a.record()
+    for _ in range(20): torch.matmul(x, w.t(), out=y)
+    b.record(); torch.cuda.synchronize()
+    ms = a.elapsed_time(b) / 20
+    print(f"   vendor library (torch.matmul): {ms:.4f} ms  {2.0*M*N*K/ms/1e9:.0f} TF")

@@ -1,0 +1,20 @@
+#!/bin/bash
+# Run ON the GPU box (via gpurun): default bench + rocprofv3 kernel stats + three PMC passes -> gpurun_out/<tag>/
+#   gpurun --timeout 1500 -- 'tools/profile_round.sh r01s'
+# then here:  python profiles/pmc_summary.py gpurun_out/<tag> profiles/<tag>_pmc_traffic.json ; cp the bench JSON / stats.
+set -u
+TAG="${1:-prof}"
+ROOT="${GRAFT_REPO_ROOT:-$(pwd)}"
+OUT="$ROOT/gpurun_out/$TAG"
+mkdir -p "$OUT"
+cd /tmp && export TMPDIR=/tmp
+timeout 600 python3 "$ROOT/bench.py" > "$OUT/bench.json" 2> "$OUT/bench.err"
+tail -c 600 "$OUT/bench.json"
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- python3 "$ROOT/bench.py" --steps 2 --warmup 1 --cpu-seqs 0 --no-profile > "$OUT/stats.log" 2>&1
+f=$(find "$OUT/stats" -name "*kernel_stats.csv" | head -1); cp "$f" "$OUT/kernel_stats.csv"; find "$OUT/stats" -type f ! -name "*kernel_stats.csv" -delete
+for C in FETCH_SIZE WRITE_SIZE; do
+  timeout 600 rocprofv3 --kernel-trace --pmc $C --output-format csv -d "$OUT/$C" -o p -- python3 "$ROOT/bench.py" --steps 1 --warmup 1 --cpu-seqs 0 --no-profile --batch 128 > "$OUT/$C.log" 2>&1
+done
+timeout 600 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d "$OUT/SQ" -o p -- python3 "$ROOT/bench.py" --steps 1 --warmup 1 --cpu-seqs 0 --no-profile --batch 128 > "$OUT/SQ.log" 2>&1
+for C in FETCH_SIZE WRITE_SIZE SQ; do f=$(find "$OUT/$C" -name "*counter_collection.csv" | head -1); [ -n "$f" ] && mv "$f" "$OUT/$C/p_counter_collection.csv"; find "$OUT/$C" -type f ! -name "p_counter_collection.csv" -delete; done
+ls -la "$OUT" "$OUT/SQ"
