@@ -26,6 +26,7 @@
 //   * tile -> (m, n) map is XCD-aware: each XCD walks a contiguous range of tiles, m-fastest inside
 //     groups of 8 m-panels, so the A panels and the current W rows stay in that XCD's 4 MiB L2.
 #include <cstdlib>
+#include <type_traits>
 
 #include "common.hpp"
 #include "kernels.hpp"
@@ -763,6 +764,289 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm256r_kernel(const T* __re
     epilogue(pm0, pn0);
 }
 
+// =====================================================================================================================
+// 256x256 tile on FOUR waves (one per SIMD, up to 512 registers each): wave tile 128x128 = 8x8 MFMA tiles (256 accumulator
+// registers), full tiles only (M, N multiples of 256).  Against the 8-wave kernels: 0.25 instead of 0.375 ds_read_b128 per
+// MFMA, half as many waves at every barrier, ONE barrier per K-tile.  Same LDS ring as gemm256r (A x3, W x2), same
+// fragment images.  A K-tile is two k-steps of 64 MFMAs; the 16 fragments of the next k-step are read while the current
+// one computes (two register sets), and each k-step also carries 8 LDS-DMAs (A(g+2) in k-step 0, W(g+2) in k-step 1),
+// issued unconditionally so that they sit in the same basic block as the MFMAs: beyond the last K-tile the cursors stop
+// and the DMAs re-read the last K-tile into ring slots nobody reads again.
+//   barrier (between the two k-steps of K-tile g): every wave's fragment reads of K-tile g are complete (stage free for
+//   refill) and, by the counted vmcnt(8) in front of it, K-tile g+1 has landed (the 8 younger DMAs are A(g+2)).
+constexpr int GEMMQ_THREADS = 256;
+
+// MFMA with the accumulator pinned to AGPRs: at 256 accumulator registers per wave the register allocator otherwise
+// shuttles accumulators between the two halves of the register file around every MFMA.
+template <typename T> struct MmaAcc;
+template <> struct MmaAcc<bf16_t> {
+    static __device__ __forceinline__ void run(const u32x4& w, const u32x4& a, f32x4& c) {
+        asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(w), "v"(a));
+    }
+    static __device__ __forceinline__ void run0(const u32x4& w, const u32x4& a, f32x4& c) {      // c = w . a (no zeroing pass)
+        asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=a"(c) : "v"(w), "v"(a));
+    }
+};
+template <> struct MmaAcc<float> {
+    static __device__ __forceinline__ void run(const u32x4& w, const u32x4& a, f32x4& c) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+            asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+a"(c) : "v"(__uint_as_float(w[s])), "v"(__uint_as_float(a[s])));
+    }
+    static __device__ __forceinline__ void run0(const u32x4& w, const u32x4& a, f32x4& c) {
+        asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, 0" : "=a"(c) : "v"(__uint_as_float(w[0])), "v"(__uint_as_float(a[0])));
+#pragma unroll
+        for (int s = 1; s < 4; ++s)
+            asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+a"(c) : "v"(__uint_as_float(w[s])), "v"(__uint_as_float(a[s])));
+    }
+};
+
+template <typename T, typename OutT>
+__global__ __launch_bounds__(GEMMQ_THREADS, 1) void gemm256q_kernel(const T* __restrict__ A, int64_t lda,
+                                                                    const T* __restrict__ W, int64_t ldw,
+                                                                    OutT* __restrict__ C, int64_t ldc, int64_t M, int N,
+                                                                    int K, int tiles_m, int tiles_n, int a_blocked,
+                                                                    OutT* __restrict__ C2, int nsplit, int out_blocked) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);    // 0..3
+    const int gstride = (int)gridDim.x;
+    const int nblk = tiles_m * tiles_n;
+    const int nkt = (K * (int)sizeof(T)) / ROWB;
+    if ((int)blockIdx.x >= nblk) return;
+    const int my_tiles = (nblk - (int)blockIdx.x + gstride - 1) / gstride;
+    const int G = my_tiles * nkt;                                 // K-tiles this block walks
+
+    auto tile_coords = [&](int tile, int64_t& m0, int& n0) {
+        const int xcd = tile & 7, idx = tile >> 3;
+        const int q = nblk >> 3, r = nblk & 7;
+        const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+        const int gsz = GROUP_M * tiles_n;
+        const int g = logical / gsz;
+        const int first_m = g * GROUP_M;
+        const int gm = min(GROUP_M, tiles_m - first_m);
+        const int in_g = logical - g * gsz;
+        m0 = (int64_t)(first_m + in_g % gm) * BM2;
+        n0 = (in_g / gm) * BN2;
+    };
+
+    // staging: wave stages rows [wave*64, +64) of the A tile and of the W tile, 8 pieces of 8 rows each.  The per-lane
+    // part of every source address does not depend on the tile (full tiles): 32-bit lane offsets + a wave-uniform base.
+    const int64_t a_pieces = (lda * (int64_t)sizeof(T)) >> 7;
+    uint32_t a_lo[8], w_lo[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int row = wave * 64 + i * 8 + (lane >> 3);
+        const int64_t ab = a_blocked ? ((int64_t)(row >> 3) * a_pieces << 10) + ((row & 7) << 7) : (int64_t)row * lda * (int64_t)sizeof(T);
+        a_lo[i] = (uint32_t)(ab + (((lane & 7) ^ key_a(row)) << 4));
+        w_lo[i] = (uint32_t)((int64_t)row * ldw * (int64_t)sizeof(T) + (((lane & 7) ^ key_w(row)) << 4));
+    }
+    const char* a_base;
+    const char* w_base;
+    auto set_pa = [&](int64_t m0) {
+        a_base = reinterpret_cast<const char*>(A) + (a_blocked ? ((m0 >> 3) * a_pieces << 10) : m0 * lda * (int64_t)sizeof(T));
+    };
+    auto set_pw = [&](int n0) { w_base = reinterpret_cast<const char*>(W) + (int64_t)n0 * ldw * (int64_t)sizeof(T); };
+    int a_tile = blockIdx.x, a_kt = 0, a_g = 0;
+    int w_tile = blockIdx.x, w_kt = 0, w_g = 0;
+    // wave-uniform 64-bit base through readfirstlane: keeps it in SGPRs (saddr + 32-bit lane offset addressing) and
+    // keeps loop-strength-reduction from turning the 16 piece addresses into 16 loop-carried 64-bit vector registers
+    auto uniform_ptr = [&](const char* q) -> const char* {
+        const uint64_t b = (uint64_t)q;
+        const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)b), hi = __builtin_amdgcn_readfirstlane((uint32_t)(b >> 32));
+        return (const char*)(((uint64_t)hi << 32) | lo);
+    };
+    auto a_piece = [&](int sa, int p) {               // piece p of A(a_g) -> A stage sa
+        const char* src = uniform_ptr(a_base + (a_blocked ? (int64_t)a_kt * 1024 : (int64_t)a_kt * ROWB));
+        glds16(src + a_lo[p], smem + sa * A2_BYTES + (wave * 64 + p * 8) * ROWB);
+    };
+    auto a_issue = [&](int sa) {
+#pragma unroll
+        for (int p = 0; p < 8; ++p) a_piece(sa, p);
+    };
+    auto a_advance = [&]() {
+        if (a_g + 1 < G) {
+            ++a_g;
+            if (++a_kt == nkt) {
+                a_kt = 0;
+                a_tile += gstride;
+                int64_t m0; int n0;
+                tile_coords(a_tile, m0, n0);
+                set_pa(m0);
+            }
+        }
+    };
+    auto w_piece = [&](int sw, int p) {
+        const char* src = uniform_ptr(w_base + (int64_t)w_kt * ROWB);
+        glds16(src + w_lo[p], smem + GEMM3_OFF_W + sw * W2_BYTES + (wave * 64 + p * 8) * ROWB);
+    };
+    auto w_issue = [&](int sw) {
+#pragma unroll
+        for (int p = 0; p < 8; ++p) w_piece(sw, p);
+    };
+    auto w_advance = [&]() {
+        if (w_g + 1 < G) {
+            ++w_g;
+            if (++w_kt == nkt) {
+                w_kt = 0;
+                w_tile += gstride;
+                int64_t m0; int n0;
+                tile_coords(w_tile, m0, n0);
+                set_pw(n0);
+            }
+        }
+    };
+
+    const int wm = wave >> 1, wn = wave & 1;
+    const int li = lane & 15, lg = lane >> 4;
+    int a_fo[8], w_fo[8];                             // fragment byte offsets inside a stage for k-step 0 (swizzle applied);
+#pragma unroll                                        // k-step 1 is the same address with bit 6 flipped
+    for (int i = 0; i < 8; ++i) {
+        const int ra = wm * 128 + i * 16 + li;
+        a_fo[i] = ra * ROWB + ((lg ^ key_a(ra)) << 4);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int rw = wn * 128 + (j >> 2) * 64 + (li >> 2) * 16 + (j & 3) * 4 + (li & 3);
+        w_fo[j] = GEMM3_OFF_W + rw * ROWB + ((lg ^ key_w(rw)) << 4);
+    }
+    auto load_frags = [&](int sa, int sw, int kk, u32x4 (&a)[8], u32x4 (&w)[8]) {
+        const int ab = sa * A2_BYTES, wb = sw * W2_BYTES, kx = kk << 6;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) w[j] = *reinterpret_cast<const u32x4*>(smem + ((wb + w_fo[j]) ^ kx));
+#pragma unroll
+        for (int i = 0; i < 8; ++i) a[i] = *reinterpret_cast<const u32x4*>(smem + ((ab + a_fo[i]) ^ kx));
+    };
+
+    f32x4 acc[8][8];
+    // One k-step: 8 rows of 8 MFMAs on (ac, wc).  With one wave per SIMD nothing else covers a burst of non-MFMA
+    // instructions, so the 16 fragment reads of the NEXT k-step and the 8 LDS-DMA pieces are pinned one at a time behind
+    // every second MFMA (an MFMA holds the pipe for 16 cycles = 4 issue slots; a read or DMA with its address math is 3-4):
+    //   rows 0-3: next W fragments (a second register set) and the DMA pieces, alternating;
+    //   rows 4-6: next A fragments 6, 7 (spare registers) and 0..5 into the registers of rows that are already done;
+    //   row 7: nothing, so every read was issued at least 8 MFMAs before the k-step ends.
+    auto kstep = [&](const u32x4 (&ac)[8], const u32x4 (&wc)[8], u32x4 (&an)[8], u32x4 (&wn)[8], int nsa, int nsw, int nkk,
+                     bool dma_a, int dma_stage, auto first_tag) {
+        constexpr bool FIRST = decltype(first_tag)::value;          // first k-step of an output tile: acc = product
+        const int abn = nsa * A2_BYTES, wbn = nsw * W2_BYTES, kx = nkk << 6;
+        auto lda = [&](int f) { an[f] = *reinterpret_cast<const u32x4*>(smem + ((abn + a_fo[f]) ^ kx)); };
+        auto ldw = [&](int f) { wn[f] = *reinterpret_cast<const u32x4*>(smem + ((wbn + w_fo[f]) ^ kx)); };
+        auto dma = [&](int p) { if (dma_a) a_piece(dma_stage, p); else w_piece(dma_stage, p); };
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+#pragma unroll
+                for (int j = 2 * k; j < 2 * k + 2; ++j) {
+                    if (FIRST) MmaAcc<T>::run0(wc[j], ac[r], acc[r][j]);
+                    else MmaAcc<T>::run(wc[j], ac[r], acc[r][j]);
+                }
+                if (r < 4) {
+                    if (k == 0) ldw(2 * r);
+                    else if (k == 1) dma(2 * r);
+                    else if (k == 2) ldw(2 * r + 1);
+                    else dma(2 * r + 1);
+                } else if (r == 4) {
+                    if (k == 0) lda(6); else if (k == 1) lda(7); else if (k == 2) lda(0);
+                } else if (r == 5) {
+                    if (k < 3) lda(1 + k);
+                } else if (r == 6) {
+                    if (k < 2) lda(4 + k);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    };
+    // lane: 2 x 16 consecutive columns (jg) of 8 rows (i).  Every destination is lane_base + i * row_step + jg * 128 bytes
+    // (plain and blocked layouts alike; in the two-output form the 64-column group jg lies wholly in one output because
+    // nsplit is a multiple of 64), so the address math is one 64-bit lane value per tile plus wave-uniform steps.
+    auto epilogue = [&](int64_t m0, int n0) {
+        const int64_t mrow = m0 + wm * 128 + li;
+#pragma unroll
+        for (int jg = 0; jg < 2; ++jg) {
+            const int nbase = n0 + wn * 128 + jg * 64;                 // wave-uniform
+            char* lane_dst;
+            int64_t row_step;                                          // bytes between rows m and m + 16
+            if (C2 != nullptr) {                                       // two-output form (in_proj), see gemm256_kernel
+                const bool second = nbase >= nsplit;
+                const int width = second ? N - nsplit : nsplit;
+                const int col = (second ? nbase - nsplit : nbase) + lg * 16;
+                char* base = reinterpret_cast<char*>(second ? C2 : C);
+                if (out_blocked) {
+                    lane_dst = base + blocked_off(mrow, (int64_t)col * sizeof(OutT), ((int64_t)width * sizeof(OutT)) >> 7);
+                    row_step = 2 * ((((int64_t)width * sizeof(OutT)) >> 7) << 10);
+                } else {
+                    lane_dst = base + (mrow * width + col) * (int64_t)sizeof(OutT);
+                    row_step = 16 * (int64_t)width * sizeof(OutT);
+                }
+            } else {
+                lane_dst = reinterpret_cast<char*>(C) + (mrow * ldc + nbase + lg * 16) * (int64_t)sizeof(OutT);
+                row_step = 16 * ldc * (int64_t)sizeof(OutT);
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                // the AGPR -> VGPR copies of this group only, here (otherwise all 256 are hoisted to the top of the epilogue)
+                f32x4 t0 = acc[i][jg * 4 + 0], t1 = acc[i][jg * 4 + 1], t2 = acc[i][jg * 4 + 2], t3 = acc[i][jg * 4 + 3];
+                asm volatile("" : "+v"(t0), "+v"(t1), "+v"(t2), "+v"(t3));
+                float lo[8], hi[8];
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) {
+                    lo[rr] = t0[rr]; lo[4 + rr] = t1[rr];
+                    hi[rr] = t2[rr]; hi[4 + rr] = t3[rr];
+                }
+                OutT* dst = reinterpret_cast<OutT*>(lane_dst + i * row_step);
+                store8<OutT>(dst, lo);
+                store8<OutT>(dst + 8, hi);
+                __builtin_amdgcn_sched_barrier(0);      // keep the epilogue's register footprint at one 16-column group
+            }
+        }
+    };
+
+    int tile = blockIdx.x;
+    int64_t m0; int n0;
+    tile_coords(tile, m0, n0);
+    set_pa(m0);
+    set_pw(n0);
+    // prologue: A(0) W(0) A(1) W(1); wait for the first 16 pieces
+    a_issue(0); a_advance();
+    w_issue(0); w_advance();
+    a_issue(1); a_advance();
+    w_issue(1); w_advance();
+    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    u32x4 fa0[8], fw0[8], fa1[8], fw1[8];
+    load_frags(0, 0, 0, fa0, fw0);
+    int sa = 0, sw = 0, kt = 0;
+    while (true) {
+        const int sa_n = sa == 2 ? 0 : sa + 1;
+        const int sa_f = sa == 0 ? 2 : sa - 1;          // stage of K-tile g-1 == stage of K-tile g+2
+        // k-step 0: MFMAs on (g, k-step 0); reads (g, k-step 1); DMAs A(g+2)
+        if (kt == 0) kstep(fa0, fw0, fa1, fw1, sa, sw, 1, true, sa_f, std::true_type{});
+        else kstep(fa0, fw0, fa1, fw1, sa, sw, 1, true, sa_f, std::false_type{});
+        a_advance();
+        asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        // k-step 1: MFMAs on (g, k-step 1); reads (g+1, k-step 0); DMAs W(g+2) into the W stage just freed
+        kstep(fa1, fw1, fa0, fw0, sa_n, sw ^ 1, 0, false, sw, std::false_type{});
+        w_advance();
+        sa = sa_n;
+        sw ^= 1;
+        if (kt + 1 < nkt) {
+            ++kt;
+        } else {
+            epilogue(m0, n0);
+            tile += gstride;
+            if (tile >= nblk) break;
+            tile_coords(tile, m0, n0);
+            kt = 0;
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // trailing (unused) DMAs must not outlive the block's LDS
+}
+
 // persistent launch: 1 resident block of 8 waves per CU (LDS-limited), a multiple of 8 so block b stays on XCD b & 7
 static int persistent_grid(int nblk) {
     static int cus = 0;
@@ -838,6 +1122,19 @@ static hipError_t launch_gemm256_t(const void* A, int64_t lda, const void* W, in
                                    bool out_blocked = false) {
     const int tiles_m = (int)((M + BM2 - 1) / BM2), tiles_n = (N + BN2 - 1) / BN2;
     dim3 grid((unsigned)persistent_grid(tiles_m * tiles_n)), block(GEMM_THREADS);
+    static const bool quad = getenv("PCAD_GEMM_NOQUAD") == nullptr;   // developer knob: the 8-wave kernels for A/B runs
+    if (quad && M % BM2 == 0 && N % BN2 == 0 && (C2 == nullptr || nsplit % 64 == 0)) {
+        auto kq = gemm256q_kernel<T, T>;
+        static bool attr_q = false;
+        if (!attr_q) {
+            hipError_t e = hipFuncSetAttribute((const void*)kq, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM3_LDS);
+            if (e != hipSuccess) return e;
+            attr_q = true;
+        }
+        hipLaunchKernelGGL(kq, grid, dim3(GEMMQ_THREADS), GEMM3_LDS, s, (const T*)A, lda, (const T*)W, ldw, (T*)C, ldc, M, N, K,
+                           tiles_m, tiles_n, (int)a_blocked, (T*)C2, nsplit, (int)out_blocked);
+        return hipGetLastError();
+    }
     static const bool ring = getenv("PCAD_GEMM_NORING") == nullptr;   // developer knob: the 2-stage kernel for A/B runs
     if (ring) {
         auto kr = gemm256r_kernel<T, T>;
