@@ -41,7 +41,7 @@ def main():
             res[k]["valu_busy_frac"] = round(row["SQ_ACTIVE_INST_VALU"] * 4 / 1024 / gui, 3)   # quad-cycles
             res[k]["mfma_busy_frac"] = round(row["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024 / gui, 3)
     cls = {"selective_scan": [k for k in res if "scan_kernel" in k],
-           "gemm_in_out_proj": [k for k in res if "gemm256_kernel" in k] or [k for k in res if "gemm_nt_kernel" in k and k.endswith("false>")],
+           "gemm_in_out_proj": [k for k in res if "gemm256" in k] or [k for k in res if "gemm_nt_kernel" in k and k.endswith("false>")],
            "gemm_x_proj": [k for k in res if "gemm_nt_kernel" in k and k.endswith("true>")],
            "conv1d_bidir": [k for k in res if "conv_bidir" in k],
            "conv_xproj_fused": [k for k in res if "convx_kernel" in k],
