@@ -156,8 +156,9 @@ int pcad_causal_conv1d_silu(const void* x, int64_t ldx, const float* w_fwd, cons
 /* selective_scan_fn(u, delta, A, B, C, D, z, delta_bias, delta_softplus=True), token-major:
  *   u, delta [S, L, E] dtype; z [S, L, ldz>=E] dtype or NULL; bc fp32 [S*L, 32] = B_t (16) | C_t (16) per token;
  *   A fp32 [E, 16] (negative real, NOT pre-scaled); Dskip, delta_bias fp32 [E];
- *   reverse != 0 walks t = L-1..0;  accumulate != 0 adds into y (bi-directional "add" strategy).
- *   y [S, L, E] dtype. */
+ *   reverse != 0 walks t = L-1..0;  accumulate: 0 y = out;  1 y = round(out) + y (bi-directional "add" strategy: each
+ *   direction gated and rounded, as the reference's two Mamba calls are);  2 y = (y + out_ungated) * silu(z), z required
+ *   (the sum of both directions gated once - what the engine runs).  y [S, L, E] dtype. */
 int pcad_selective_scan(const void* u, const void* delta, const void* z, int64_t ldz, const float* bc,
                         const float* A, const float* Dskip, const float* delta_bias,
                         void* y, int S, int L, int E, int reverse, int accumulate,

@@ -64,6 +64,7 @@ struct pcad_engine {
     int rdt;        // residual dtype
     int chunk;      // sequences per pass through the layer stack
     int nstreams;   // 1: everything on the caller's stream; 2: chunks alternate between two library streams
+    bool gate_once; // SiLU(z) applied once to y_fwd + y_rev (reverse scan) instead of once per direction
     bool convx;     // conv + x_proj of both directions in one kernel (needs xzsplit and Rp == 64); PCAD_NO_CONVX=1: off
     bool xzsplit;   // in_proj writes x and z as two blocked tensors (needs `blocked`); PCAD_PLAIN_XZ=1 turns it off (A/B knob)
     bool blocked;   // xc and y in the blocked layout (common.hpp::blocked_off); PCAD_PLAIN_LAYOUT=1 turns it off (A/B knob)
@@ -227,6 +228,7 @@ int pcad_create(const pcad_config* cfg, pcad_handle* out) {
     e->blocked = getenv("PCAD_PLAIN_LAYOUT") == nullptr && (e->E * e->esz) % 128 == 0;
     e->xzsplit = e->blocked && getenv("PCAD_PLAIN_XZ") == nullptr && e->E % 16 == 0;
     e->convx = e->xzsplit && e->Rp == 64 && getenv("PCAD_NO_CONVX") == nullptr;
+    e->gate_once = getenv("PCAD_GATE_EACH") == nullptr;
     const char* ns = getenv("PCAD_STREAMS");
     // default 1: measured on MI355X (r01d) two lanes give 851 vs 852 seq/s -- co-running a VALU-bound scan and an
     // MFMA-bound GEMM slows each by the other's share (shared issue/power budget), so nothing is gained.
@@ -453,9 +455,13 @@ static int forward_impl(pcad_handle h, const int32_t* ids, int B, int L, const i
             // dt_proj (on MFMA inside the scan) + bias + softplus + recurrence + D skip + SiLU(z) gate
             ProfScope ps(e, PCAD_K_SCAN, s);
             const void* zp = e->xzsplit ? c.w.zb : (const void*)((const char*)c.w.xz + (size_t)E * esz);
-            HIP_TRY(launch_scan(c.w.xc[d], zp, e->xzsplit ? E : 2 * E, nullptr, c.w.dtl[d], Rp, dw.Wdt, Rp,
-                                c.w.bc[d], dw.A2, 1.0f, dw.Dskip, dw.dt_bias, c.w.y, S, L, E, d == 1, d == 1, dt, s, e->blocked,
-                                e->xzsplit));
+            // gate_once: the forward scan stores its ungated output, the reverse scan adds its own and applies SiLU(z)
+            // to the sum (one SiLU per element instead of two, z read once; a rounding-order difference from
+            // y_f*g + y_r*g, like the out_proj fold below).  PCAD_GATE_EACH=1: each direction gated and rounded.
+            const bool gated = !e->gate_once || d == 1;
+            HIP_TRY(launch_scan(c.w.xc[d], gated ? zp : nullptr, e->xzsplit ? E : 2 * E, nullptr, c.w.dtl[d], Rp, dw.Wdt, Rp,
+                                c.w.bc[d], dw.A2, 1.0f, dw.Dskip, dw.dt_bias, c.w.y, S, L, E, d == 1,
+                                d == 1 ? (e->gate_once ? 2 : 1) : 0, dt, s, e->blocked, e->xzsplit));
         }
         // out_proj on (y_fwd + y_rev): the two tied out_proj calls folded by linearity
         { ProfScope ps(e, PCAD_K_GEMM_OUT, s);
@@ -604,7 +610,7 @@ int pcad_selective_scan(const void* u, const void* delta, const void* z, int64_t
     if (S == 0 || L == 0) return PCAD_OK;
     // raw A is scaled by log2(e) when the kernel loads it into registers (the engine passes pre-scaled A)
     HIP_TRY(launch_scan(u, z, ldz, delta, nullptr, 0, nullptr, 0, bc, A, 1.4426950408889634f, Dskip, delta_bias, y, S, L,
-                        E, reverse != 0, accumulate != 0, dtype, (hipStream_t)stream));
+                        E, reverse != 0, accumulate, dtype, (hipStream_t)stream));
     return PCAD_OK;
 }
 
@@ -619,7 +625,7 @@ int pcad_selective_scan_dtproj(const void* u, const void* dt_low, int64_t lddt, 
     if (int rc = scan_args_ok(u, bc, A, Dskip, delta_bias, y, S, L, E)) return rc;
     if (S == 0 || L == 0) return PCAD_OK;
     HIP_TRY(launch_scan(u, z, ldz, nullptr, dt_low, lddt, Wdt, Rp, bc, A, 1.4426950408889634f, Dskip, delta_bias, y, S, L,
-                        E, reverse != 0, accumulate != 0, dtype, (hipStream_t)stream));
+                        E, reverse != 0, accumulate, dtype, (hipStream_t)stream));
     return PCAD_OK;
 }
 

@@ -74,7 +74,7 @@ hipError_t launch_convx(const void* x, const float* convw, const void* Wx0, void
 // z_blocked (needs uy_blocked): z is a separate [S*L, E] tensor in the same blocked layout (ldz ignored).
 hipError_t launch_scan(const void* u, const void* z, int64_t ldz, const void* delta, const void* dt_low, int64_t lddt,
                        const void* Wdt, int Rp, const float* bc, const float* A2, float a_scale, const float* Dskip,
-                       const float* dbias, void* y, int S, int L, int E, bool reverse, bool accumulate, int dt,
+                       const float* dbias, void* y, int S, int L, int E, bool reverse, int accumulate, int dt,
                        hipStream_t s, bool uy_blocked = false, bool z_blocked = false);
 
 // pack.hip --------------------------------------------------------------------------------------

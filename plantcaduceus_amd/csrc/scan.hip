@@ -18,7 +18,8 @@
 //   * B_t / C_t (shared by all channels) are fp32 rows written by the x_proj GEMM epilogue; the address is
 //     wave-uniform so they arrive through the scalar unit (s_load_dwordx16) as SGPR operands of the VALU ops.
 //   * u / z (/ y of the other direction) are 128-byte coalesced row reads, prefetched one 4-step chunk ahead.
-//   * The reverse direction walks t = L-1..0 on the same rows (no flipped copy); `accumulate` adds the forward
+//   * The reverse direction walks t = L-1..0 on the same rows (no flipped copy); `accumulate` (1: after the gate, each
+//     direction rounded as the reference does; 2: before the gate, one SiLU(z) for both directions) adds the forward
 //     direction's output (BiMambaWrapper strategy "add", tied out_proj folded by linearity).
 // VALU/transcendental bound (measured on gfx950: v_exp_f32 8.5, v_fma_f32 3.7, v_pk_fma_f32 5.2 cycles per
 // wave-instruction at 4 waves/SIMD, not overlapping): ~19 cycles per (t, channel, state).
@@ -145,7 +146,7 @@ template <> struct DeltaTile<float> {
 // PRE (bf16, FUSED, Rp == 64): dt_low operand prefetched one block ahead.
 // BLK8: u / y in the blocked layout AND L % 8 == 0 (the engine's case): one scalar block offset per 4-step chunk, the
 // per-step +-128 bytes ride in the buffer instruction's immediate offset.
-template <typename T, bool REV, bool ACC, bool HASZ, bool FUSED, bool PRE, bool BLK8>
+template <typename T, bool REV, int ACC, bool HASZ, bool FUSED, bool PRE, bool BLK8>
 __global__ __launch_bounds__(64, 4) void scan_kernel(const T* __restrict__ u, const T* __restrict__ z, int64_t ldz,
                                                   const T* __restrict__ dsrc, int64_t ldd,
                                                   const T* __restrict__ Wdt, int Rp,
@@ -224,7 +225,7 @@ __global__ __launch_bounds__(64, 4) void scan_kernel(const T* __restrict__ u, co
             const uint32_t t = (uint32_t)tclamp(s0 + i);
             uu[i] = BufIO<T>::load(u_r, uy_voff(i), uy_soff(s0, i));
             if constexpr (HASZ) zz[i] = zb_ ? BufIO<T>::load(z_r, uy_voff(i), uy_soff(s0, i)) : BufIO<T>::load(z_r, voff, t * rowZ);
-            if constexpr (ACC) yy[i] = BufIO<T>::load(y_r, uy_voff(i), uy_soff(s0, i));
+            if constexpr (ACC != 0) yy[i] = BufIO<T>::load(y_r, uy_voff(i), uy_soff(s0, i));
             if constexpr (!FUSED) dd[i] = BufIO<T>::load(d_r, voff, t * rowD);
         }
     };
@@ -268,8 +269,9 @@ __global__ __launch_bounds__(64, 4) void scan_kernel(const T* __restrict__ u, co
         }
         const f2 yacc = yacc0 + yacc1;
         float yv = yacc[0] + yacc[1];
+        if constexpr (ACC == 2) yv += Elem<T>::to_f32(yraw);                        // sum of both directions, gated once
         if constexpr (HASZ) yv *= silu(Elem<T>::to_f32(zraw));
-        if constexpr (ACC) yv = Elem<T>::round(yv) + Elem<T>::to_f32(yraw);    // each direction is rounded, then summed
+        if constexpr (ACC == 1) yv = Elem<T>::round(yv) + Elem<T>::to_f32(yraw);    // each direction is rounded, then summed
         BufIO<T>::store(Elem<T>::from_f32(yv), y_r, vy, oy);
 #pragma unroll
         for (int p = 0; p < NSTATE; ++p) bcc[p] = bcn[p];
@@ -327,23 +329,27 @@ template <typename T, bool FUSED, bool PRE = false, bool BLK8 = false>
 static hipError_t launch_scan_t(const void* u, const void* z, int64_t ldz, const void* dsrc, int64_t ldd,
                                 const void* Wdt, int Rp, const float* bc, const float* A2, float a_scale,
                                 const float* Dskip, const float* dbias, void* y, int S, int L, int E, bool reverse,
-                                bool accumulate, hipStream_t s, bool uyb, bool zblk = false) {
+                                int accumulate, hipStream_t s, bool uyb, bool zblk = false) {
     dim3 grid((unsigned)(E / 64), (unsigned)S), block(64);
 #define PCAD_SCAN(REV, ACC, HZ)                                                                                    \
     hipLaunchKernelGGL((scan_kernel<T, REV, ACC, HZ, FUSED, PRE, BLK8>), grid, block, 0, s, (const T*)u, (const T*)z, ldz,       \
                        (const T*)dsrc, ldd, (const T*)Wdt, Rp, bc, A2, a_scale, Dskip, dbias, (const T*)y, (T*)y, L, E, (int)uyb, (int)zblk)
     const bool hz = z != nullptr;
-    if (!reverse && !accumulate) { if (hz) PCAD_SCAN(false, false, true); else PCAD_SCAN(false, false, false); }
-    else if (!reverse && accumulate) { if (hz) PCAD_SCAN(false, true, true); else PCAD_SCAN(false, true, false); }
-    else if (reverse && !accumulate) { if (hz) PCAD_SCAN(true, false, true); else PCAD_SCAN(true, false, false); }
-    else { if (hz) PCAD_SCAN(true, true, true); else PCAD_SCAN(true, true, false); }
+    if (accumulate == 2) {                    // (y_prev + y) * silu(z): the bi-directional sum gated once
+        if (!hz) return hipErrorInvalidValue;
+        if (reverse) PCAD_SCAN(true, 2, true); else PCAD_SCAN(false, 2, true);
+    }
+    else if (!reverse && !accumulate) { if (hz) PCAD_SCAN(false, 0, true); else PCAD_SCAN(false, 0, false); }
+    else if (!reverse && accumulate) { if (hz) PCAD_SCAN(false, 1, true); else PCAD_SCAN(false, 1, false); }
+    else if (reverse && !accumulate) { if (hz) PCAD_SCAN(true, 0, true); else PCAD_SCAN(true, 0, false); }
+    else { if (hz) PCAD_SCAN(true, 1, true); else PCAD_SCAN(true, 1, false); }
 #undef PCAD_SCAN
     return hipGetLastError();
 }
 
 hipError_t launch_scan(const void* u, const void* z, int64_t ldz, const void* delta, const void* dt_low, int64_t lddt,
                        const void* Wdt, int Rp, const float* bc, const float* A2, float a_scale, const float* Dskip,
-                       const float* dbias, void* y, int S, int L, int E, bool reverse, bool accumulate, int dt,
+                       const float* dbias, void* y, int S, int L, int E, bool reverse, int accumulate, int dt,
                        hipStream_t s, bool uyb, bool zblk) {
     if (zblk && !uyb) return hipErrorInvalidValue;
     if (S <= 0 || L <= 0) return hipSuccess;

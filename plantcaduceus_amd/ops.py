@@ -90,9 +90,19 @@ def _scan_common(u, B, C, A, D, z, delta_bias):
     return u_tm, z_tm, bc, A32, Dv, db
 
 
+def _acc_mode(accumulate_into, gate_sum) -> int:
+    if accumulate_into is None:
+        if gate_sum:
+            raise ValueError("gate_sum needs accumulate_into (the other direction's ungated output)")
+        return 0
+    return 2 if gate_sum else 1
+
+
 def selective_scan_fn(u, delta, A, B, C, D=None, z=None, delta_bias=None, delta_softplus=False,
-                      return_last_state=False, reverse=False, accumulate_into=None):
-    """u, delta, z: (B, E, L); A: (E, 16); B, C: (B, 16, L); D, delta_bias: (E).  Returns (B, E, L)."""
+                      return_last_state=False, reverse=False, accumulate_into=None, gate_sum=False):
+    """u, delta, z: (B, E, L); A: (E, 16); B, C: (B, 16, L); D, delta_bias: (E).  Returns (B, E, L).
+    accumulate_into: add this call's gated output to an earlier one (bi-directional "add"); with gate_sum=True the
+    earlier output is taken as UNGATED (its call had z=None) and SiLU(z) is applied once to the sum (the engine's form)."""
     _require_gpu(u, "u")
     if not delta_softplus:
         raise NotImplementedError("the Caduceus path always uses delta_softplus=True")
@@ -106,13 +116,13 @@ def selective_scan_fn(u, delta, A, B, C, D=None, z=None, delta_bias=None, delta_
     with torch.cuda.device(u.device):
         _check(lib.pcad_selective_scan(u_tm.data_ptr(), d_tm.data_ptr(), z_tm.data_ptr() if z_tm is not None else None,
                                        E, bc.data_ptr(), A32.data_ptr(), Dv.data_ptr(), db.data_ptr(), y.data_ptr(),
-                                       Bsz, L, E, int(bool(reverse)), int(accumulate_into is not None), _dt(u_tm),
+                                       Bsz, L, E, int(bool(reverse)), _acc_mode(accumulate_into, gate_sum), _dt(u_tm),
                                        _stream_ptr()), "pcad_selective_scan")
     return y.transpose(1, 2)
 
 
 def selective_scan_dtproj_fn(u, dt_low, dt_proj_weight, A, B, C, D=None, z=None, delta_bias=None, reverse=False,
-                             accumulate_into=None):
+                             accumulate_into=None, gate_sum=False):
     """mamba_inner_fn's tail: delta = dt_proj_weight @ dt_low (on MFMA inside the kernel), then selective_scan_fn.
     u, z: (B, E, L); dt_low: (B, L, R); dt_proj_weight: (E, R)."""
     _require_gpu(u, "u")
@@ -130,7 +140,7 @@ def selective_scan_dtproj_fn(u, dt_low, dt_proj_weight, A, B, C, D=None, z=None,
         _check(lib.pcad_selective_scan_dtproj(u_tm.data_ptr(), dl.data_ptr(), Rp, W.data_ptr(), Rp,
                                               z_tm.data_ptr() if z_tm is not None else None, E, bc.data_ptr(),
                                               A32.data_ptr(), Dv.data_ptr(), db.data_ptr(), y.data_ptr(), Bsz, L, E,
-                                              int(bool(reverse)), int(accumulate_into is not None), _dt(u_tm),
+                                              int(bool(reverse)), _acc_mode(accumulate_into, gate_sum), _dt(u_tm),
                                               _stream_ptr()), "pcad_selective_scan_dtproj")
     return y.transpose(1, 2)
 

@@ -96,6 +96,17 @@ def test_selective_scan_fp32(ops, L):
     out2 = ops.selective_scan_fn(to(u), to(delta), to(A), to(Bm), to(Cm), to(D), z=to(z), delta_bias=to(db),
                                  delta_softplus=True, reverse=True, accumulate_into=out)
     assert relerr(out2, ref + ref_rev) < 2e-5
+    # the engine's form: forward ungated, reverse adds and gates the sum once: (y_f + y_r) * silu(z)
+    raw_f = O.selective_scan_fn(u, delta, A, Bm, Cm, D, z=None, delta_bias=db, delta_softplus=True)
+    raw_r = O.selective_scan_fn(u.flip(-1), delta.flip(-1), A, Bm.flip(-1), Cm.flip(-1), D, z=None, delta_bias=db,
+                                delta_softplus=True).flip(-1)
+    o_f = ops.selective_scan_fn(to(u), to(delta), to(A), to(Bm), to(Cm), to(D), z=None, delta_bias=to(db),
+                                delta_softplus=True)
+    assert relerr(o_f, raw_f) < 2e-5
+    o_s = ops.selective_scan_fn(to(u), to(delta), to(A), to(Bm), to(Cm), to(D), z=to(z), delta_bias=to(db),
+                                delta_softplus=True, reverse=True, accumulate_into=o_f, gate_sum=True)
+    assert relerr(o_s, (raw_f + raw_r) * torch.nn.functional.silu(z)) < 2e-5
+    assert relerr(o_s, ref + ref_rev) < 2e-5            # == y_f*g + y_r*g up to fp32 rounding
 
 
 @pytest.mark.parametrize("L,R,dtype", [(512, 64, torch.float32), (70, 24, torch.float32), (33, 48, torch.float32),
@@ -123,6 +134,10 @@ def test_selective_scan_fused_dtproj(ops, L, R, dtype):
     out2 = ops.selective_scan_dtproj_fn(to(u), to(dt_low), to(Wdt), f(A), to(Bm), to(Cm), f(D), z=to(z), delta_bias=f(db),
                                         reverse=True, accumulate_into=out)
     assert relerr(out2, rnd(ref + ref_rev)) < 2 * tol
+    o_f = ops.selective_scan_dtproj_fn(to(u), to(dt_low), to(Wdt), f(A), to(Bm), to(Cm), f(D), z=None, delta_bias=f(db))
+    o_s = ops.selective_scan_dtproj_fn(to(u), to(dt_low), to(Wdt), f(A), to(Bm), to(Cm), f(D), z=to(z), delta_bias=f(db),
+                                       reverse=True, accumulate_into=o_f, gate_sum=True)
+    assert relerr(o_s, rnd(ref + ref_rev)) < 2 * tol    # gate-once form: a rounding-order difference only
 
 
 def test_selective_scan_softplus_threshold_and_small_dt(ops):
