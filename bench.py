@@ -205,7 +205,7 @@ def main():
                                          "timed region" % max(1, args.profile_stride))
             res["kernels"] = kern
         # ---- host-CPU baseline: the oracle port, same model / same kind of input, bounded sample ------
-        ncpu = args.cpu_seqs
+        ncpu = args.cpu_seqs if world == 1 else 0                 # reported at N=1 only
         if ncpu != 0:
             try:
                 from oracle.c_oracle import COracle

@@ -167,7 +167,9 @@ def test_selective_scan_bf16(ops):
     assert relerr(out, ref) < 2 ** -7
 
 
-@pytest.mark.parametrize("M,N,K", [(1, 8, 32), (128, 128, 32), (300, 96, 768), (1000, 1536, 384), (257, 56, 2048), (513, 384, 64)])
+# (2048, 512, 96), (2304, 768, 32): full 256x256 tiles -> the 4-wave kernel with 3 / 1 K-tiles; (2100, 520, 64): its 8-wave edge-tile sibling
+@pytest.mark.parametrize("M,N,K", [(1, 8, 32), (128, 128, 32), (300, 96, 768), (1000, 1536, 384), (257, 56, 2048), (513, 384, 64),
+                                   (2048, 512, 96), (2304, 768, 32), (2100, 520, 64)])
 def test_linear_fp32(ops, M, N, K):
     g = torch.Generator().manual_seed(M + N + K)
     x = torch.randn(M, K, generator=g)
@@ -177,7 +179,10 @@ def test_linear_fp32(ops, M, N, K):
     assert relerr(out, ref) < 2e-6      # exact-fp32 MFMA: only summation-order differences
 
 
-@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 96, 768), (1000, 1536, 384), (2048, 4096, 1024), (513, 1024, 2048)])
+# (2048, 4096, 1024), (2304, 768, 64), (2560, 512, 192): 4-wave 256x256 kernel (16 / 1 / 3 K-tiles, 1..9 tiles per block);
+# (2100, 1000, 128): the 8-wave ring kernel with edge tiles in M and N
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 96, 768), (1000, 1536, 384), (2048, 4096, 1024), (513, 1024, 2048),
+                                   (2304, 768, 64), (2560, 512, 192), (2100, 1000, 128), (65536, 512, 128)])
 def test_linear_bf16(ops, M, N, K):
     g = torch.Generator().manual_seed(M + N + K)
     x = torch.randn(M, K, generator=g).bfloat16()
