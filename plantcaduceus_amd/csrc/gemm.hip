@@ -776,6 +776,13 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm256r_kernel(const T* __re
 //   refill) and, by the counted vmcnt(8) in front of it, K-tile g+1 has landed (the 8 younger DMAs are A(g+2)).
 constexpr int GEMMQ_THREADS = 256;
 
+// LDS-DMA through a buffer descriptor: address = descriptor base + voff (per lane) + soff (wave-uniform), 16 B per lane
+// to lds_wave_base + lane * 16.  (Device-only builtins live in __device__ helpers so the host pass still emits the stub.)
+__device__ __forceinline__ void blds16(const void* base, uint32_t voff, uint32_t soff, char* lds_wave_base) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(__builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0x7ffffffc, 0x00020000),
+                                             (__attribute__((address_space(3))) void*)lds_wave_base, 16, (int)voff, (int)soff, 0, 0);
+}
+
 // MFMA with the accumulator pinned to AGPRs: at 256 accumulator registers per wave the register allocator otherwise
 // shuttles accumulators between the two halves of the register file around every MFMA.
 template <typename T> struct MmaAcc;
@@ -831,8 +838,10 @@ __global__ __launch_bounds__(GEMMQ_THREADS, 1) void gemm256q_kernel(const T* __r
         n0 = (in_g / gm) * BN2;
     };
 
-    // staging: wave stages rows [wave*64, +64) of the A tile and of the W tile, 8 pieces of 8 rows each.  The per-lane
-    // part of every source address does not depend on the tile (full tiles): 32-bit lane offsets + a wave-uniform base.
+    // staging: wave stages rows [wave*64, +64) of the A tile and of the W tile, 8 pieces of 8 rows each, by
+    // buffer_load_dwordx4 ... lds: address = descriptor base + per-lane offset (VGPR, constant for the whole kernel: full
+    // tiles, so the lane part does not depend on the tile) + wave-uniform tile/K-tile offset (SGPR): no vector address
+    // arithmetic per DMA, only the M0 (LDS destination) update.  Offsets are 32-bit: the launcher checks the tensor sizes.
     const int64_t a_pieces = (lda * (int64_t)sizeof(T)) >> 7;
     uint32_t a_lo[8], w_lo[8];
 #pragma unroll
@@ -842,28 +851,28 @@ __global__ __launch_bounds__(GEMMQ_THREADS, 1) void gemm256q_kernel(const T* __r
         a_lo[i] = (uint32_t)(ab + (((lane & 7) ^ key_a(row)) << 4));
         w_lo[i] = (uint32_t)((int64_t)row * ldw * (int64_t)sizeof(T) + (((lane & 7) ^ key_w(row)) << 4));
     }
-    const char* a_base;
-    const char* w_base;
+    uint32_t a_base, w_base;                          // wave-uniform byte offset of the cursor's tile
     auto set_pa = [&](int64_t m0) {
-        a_base = reinterpret_cast<const char*>(A) + (a_blocked ? ((m0 >> 3) * a_pieces << 10) : m0 * lda * (int64_t)sizeof(T));
+        a_base = (uint32_t)(a_blocked ? ((m0 >> 3) * a_pieces << 10) : m0 * lda * (int64_t)sizeof(T));
     };
-    auto set_pw = [&](int n0) { w_base = reinterpret_cast<const char*>(W) + (int64_t)n0 * ldw * (int64_t)sizeof(T); };
+    auto set_pw = [&](int n0) { w_base = (uint32_t)((int64_t)n0 * ldw * (int64_t)sizeof(T)); };
     int a_tile = blockIdx.x, a_kt = 0, a_g = 0;
     int w_tile = blockIdx.x, w_kt = 0, w_g = 0;
-    // wave-uniform 64-bit base through readfirstlane: keeps it in SGPRs (saddr + 32-bit lane offset addressing) and
-    // keeps loop-strength-reduction from turning the 16 piece addresses into 16 loop-carried 64-bit vector registers
-    auto uniform_ptr = [&](const char* q) -> const char* {
-        const uint64_t b = (uint64_t)q;
-        const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)b), hi = __builtin_amdgcn_readfirstlane((uint32_t)(b >> 32));
-        return (const char*)(((uint64_t)hi << 32) | lo);
-    };
     auto a_piece = [&](int sa, int p) {               // piece p of A(a_g) -> A stage sa
-        const char* src = uniform_ptr(a_base + (a_blocked ? (int64_t)a_kt * 1024 : (int64_t)a_kt * ROWB));
-        glds16(src + a_lo[p], smem + sa * A2_BYTES + (wave * 64 + p * 8) * ROWB);
+        const uint32_t soff = a_base + (uint32_t)a_kt * (a_blocked ? 1024u : (uint32_t)ROWB);
+        blds16(A, a_lo[p], soff, smem + sa * A2_BYTES + (wave * 64 + p * 8) * ROWB);
     };
     auto a_issue = [&](int sa) {
 #pragma unroll
         for (int p = 0; p < 8; ++p) a_piece(sa, p);
+    };
+    auto w_piece = [&](int sw, int p) {
+        const uint32_t soff = w_base + (uint32_t)w_kt * (uint32_t)ROWB;
+        blds16(W, w_lo[p], soff, smem + GEMM3_OFF_W + sw * W2_BYTES + (wave * 64 + p * 8) * ROWB);
+    };
+    auto w_issue = [&](int sw) {
+#pragma unroll
+        for (int p = 0; p < 8; ++p) w_piece(sw, p);
     };
     auto a_advance = [&]() {
         if (a_g + 1 < G) {
@@ -876,14 +885,6 @@ __global__ __launch_bounds__(GEMMQ_THREADS, 1) void gemm256q_kernel(const T* __r
                 set_pa(m0);
             }
         }
-    };
-    auto w_piece = [&](int sw, int p) {
-        const char* src = uniform_ptr(w_base + (int64_t)w_kt * ROWB);
-        glds16(src + w_lo[p], smem + GEMM3_OFF_W + sw * W2_BYTES + (wave * 64 + p * 8) * ROWB);
-    };
-    auto w_issue = [&](int sw) {
-#pragma unroll
-        for (int p = 0; p < 8; ++p) w_piece(sw, p);
     };
     auto w_advance = [&]() {
         if (w_g + 1 < G) {
@@ -923,9 +924,9 @@ __global__ __launch_bounds__(GEMMQ_THREADS, 1) void gemm256q_kernel(const T* __r
     // One k-step: 8 rows of 8 MFMAs on (ac, wc).  With one wave per SIMD nothing else covers a burst of non-MFMA
     // instructions, so the 16 fragment reads of the NEXT k-step and the 8 LDS-DMA pieces are pinned one at a time behind
     // every second MFMA (an MFMA holds the pipe for 16 cycles = 4 issue slots; a read or DMA with its address math is 3-4):
-    //   rows 0-3: next W fragments (a second register set) and the DMA pieces, alternating;
-    //   rows 4-6: next A fragments 6, 7 (spare registers) and 0..5 into the registers of rows that are already done;
-    //   row 7: nothing, so every read was issued at least 8 MFMAs before the k-step ends.
+    //   rows 0-3: next W fragments (a second register set); rows 4-6: next A fragments 6, 7 (spare registers) and 0..5 into
+    //   the registers of rows that are already done; every row: one DMA piece; row 7: no reads, so every read was
+    //   issued at least 8 MFMAs before the k-step ends.
     auto kstep = [&](const u32x4 (&ac)[8], const u32x4 (&wc)[8], u32x4 (&an)[8], u32x4 (&wn)[8], int nsa, int nsw, int nkk,
                      bool dma_a, int dma_stage, auto first_tag) {
         constexpr bool FIRST = decltype(first_tag)::value;          // first k-step of an output tile: acc = product
@@ -942,17 +943,18 @@ __global__ __launch_bounds__(GEMMQ_THREADS, 1) void gemm256q_kernel(const T* __r
                     if (FIRST) MmaAcc<T>::run0(wc[j], ac[r], acc[r][j]);
                     else MmaAcc<T>::run(wc[j], ac[r], acc[r][j]);
                 }
-                if (r < 4) {
+                // slot k of row r: W' in rows 0-3, A' in rows 4-6, ONE DMA piece per row (4 waves x 1 KiB every 8 MFMAs keeps
+                // the CU's L1 half busy; all eight pieces within rows 0-3 saturated it and stalled the issue: TA stalled-by-TC x7)
+                if (k == 1) dma(r);
+                else if (r < 4) {
                     if (k == 0) ldw(2 * r);
-                    else if (k == 1) dma(2 * r);
                     else if (k == 2) ldw(2 * r + 1);
-                    else dma(2 * r + 1);
                 } else if (r == 4) {
-                    if (k == 0) lda(6); else if (k == 1) lda(7); else if (k == 2) lda(0);
+                    if (k == 0) lda(6); else if (k == 2) lda(7);
                 } else if (r == 5) {
-                    if (k < 3) lda(1 + k);
+                    if (k == 0) lda(0); else if (k == 2) lda(1); else lda(2);
                 } else if (r == 6) {
-                    if (k < 2) lda(4 + k);
+                    if (k == 0) lda(3); else if (k == 2) lda(4); else lda(5);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -1123,7 +1125,9 @@ static hipError_t launch_gemm256_t(const void* A, int64_t lda, const void* W, in
     const int tiles_m = (int)((M + BM2 - 1) / BM2), tiles_n = (N + BN2 - 1) / BN2;
     dim3 grid((unsigned)persistent_grid(tiles_m * tiles_n)), block(GEMM_THREADS);
     static const bool quad = getenv("PCAD_GEMM_NOQUAD") == nullptr;   // developer knob: the 8-wave kernels for A/B runs
-    if (quad && M % BM2 == 0 && N % BN2 == 0 && (C2 == nullptr || nsplit % 64 == 0)) {
+    const int64_t esz_ = (int64_t)sizeof(T);
+    if (quad && M % BM2 == 0 && N % BN2 == 0 && (C2 == nullptr || nsplit % 64 == 0) && M * lda * esz_ < ((int64_t)1 << 31) &&
+        (int64_t)N * ldw * esz_ < ((int64_t)1 << 31)) {
         auto kq = gemm256q_kernel<T, T>;
         static bool attr_q = false;
         if (!attr_q) {

@@ -1,12 +1,12 @@
 #!/bin/bash
 # developer tool (run on the GPU box): PMC passes over tools/gemm_time.py, ours vs the vendor library kernel on the same shapes
 ROOT="${GRAFT_REPO_ROOT:-$(pwd)}"; OUT="$ROOT/gpurun_out/gemm_pmc"; mkdir -p "$OUT"; cd /tmp; export TMPDIR=/tmp
-P1="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAIT_INST_LDS"
-P2="SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_INST_CYCLES_VMEM_RD SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"
+P1="TCC_HIT TCC_MISS TCC_REQ TCC_READ TCC_TAG_STALL TCC_BUSY GRBM_GUI_ACTIVE"
+P2="TCP_TCC_READ_REQ_LATENCY TCP_TCC_READ_REQ TCP_PENDING_STALL_CYCLES TA_TA_BUSY TA_ADDR_STALLED_BY_TC_CYCLES TCP_TOTAL_ACCESSES"
 P3="SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_MFMA SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES SQ_INSTS_VMEM_WR SQ_INSTS_SMEM"
 P4="SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_MFMA SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES SQ_INSTS_VMEM_WR SQ_INSTS_SMEM"
 i=0
-for P in "$P1" "$P2" "$P3"; do i=$((i+1))
+for P in "$P1" "$P2"; do i=$((i+1))
   timeout 300 rocprofv3 --kernel-trace --pmc $P --output-format csv -d "$OUT/p$i" -o p -- python3 "$ROOT/tools/gemm_time.py" > "$OUT/p$i.log" 2>&1
   f=$(find "$OUT/p$i" -name "*counter_collection.csv" | head -1); [ -n "$f" ] && cp "$f" "$OUT/p$i.csv"; rm -rf "$OUT/p$i"
 done
