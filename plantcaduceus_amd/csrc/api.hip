@@ -430,7 +430,8 @@ static int forward_impl(pcad_handle h, const int32_t* ids, int B, int L, const i
         if (e->xzsplit) HIP_TRY(launch_gemm_nt_two(c.w.u, D, W.W_in, D, c.w.xz, c.w.zb, E, true, rows, 2 * E, D, dt, s));
         else HIP_TRY(launch_gemm_nt(c.w.u, D, W.W_in, D, c.w.xz, 2 * E, rows, 2 * E, D, dt, dt, false, s)); }
         // conv1d + SiLU, causal and anti-causal from one read of x (fused with x_proj of both directions when possible)
-        if (e->convx) {
+        const bool convx = e->convx && ((int64_t)rows + 8) * E * esz < ((int64_t)1 << 31);      // the fused kernel's 32-bit offsets
+        if (convx) {
             ProfScope ps(e, PCAD_K_CONV, s);
             HIP_TRY(launch_convx(c.w.xz, W.convw, W.dir[0].Wx, c.w.xc[0], c.w.dtl[0], c.w.bc[0], W.dir[1].Wx, c.w.xc[1],
                                  c.w.dtl[1], c.w.bc[1], S, L, E, dt, s));
@@ -449,7 +450,7 @@ static int forward_impl(pcad_handle h, const int32_t* ids, int B, int L, const i
         for (int d = 0; d < 2; ++d) {
             const DirWeights& dw = W.dir[d];
             // x_proj -> dt_low [rows, Rp] (model dtype, zero padded) and B_t | C_t [rows, 32] (fp32 side output)
-            if (!e->convx) { ProfScope ps(e, PCAD_K_GEMM_X, s);
+            if (!(e->convx && ((int64_t)rows + 8) * E * esz < ((int64_t)1 << 31))) { ProfScope ps(e, PCAD_K_GEMM_X, s);
             HIP_TRY(launch_gemm_nt_split(c.w.xc[d], E, dw.Wx, E, c.w.dtl[d], Rp, c.w.bc[d], 2 * N, Rp, rows, XP, E, dt, s,
                                          e->blocked)); }
             // dt_proj (on MFMA inside the scan) + bias + softplus + recurrence + D skip + SiLU(z) gate

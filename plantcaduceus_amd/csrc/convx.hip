@@ -2,17 +2,24 @@
 //
 // Replaces, per layer, causal_conv1d_fn x4 and the x_proj GEMM x4 of the reference — in this
 // engine previously three launches: conv_bidir (read x, write xc_f / xc_r) and two x_proj GEMMs (each re-reading its xc).
-// Here x is read ONCE: a block owns 128 consecutive timesteps of one strand and walks the channels in 128-byte K-tiles;
-// per K-tile
-//   1. the raw x tile (128 rows + 3 halo rows on each side) arrives by LDS-DMA from the blocked x tensor (1 KiB blocks),
-//      two K-tiles ahead, together with that K-tile's Wx slabs (both directions) and conv taps;
-//   2. conv pass (VALU): thread = (direction, 16-byte channel chunk, 4 consecutive rows): 7 raw rows and 5 tap vectors
-//      from LDS, fp32 taps + bias + SiLU, result rounded to the model dtype and written into the LDS tiles cf / cr in
-//      the MFMA A-fragment image (XOR swizzle);
-//   3. MFMA pass: wave = (direction, 32 rows): x_dbl += c{f,r} . Wx^T, accumulators stay in registers across K-tiles;
-//      the same waves copy cf / cr to the blocked xc tensors the scan reads, 1 KiB contiguous per store instruction.
+// Here x is read ONCE: a block (8 waves; waves 0-3 own the causal direction, 4-7 the anti-causal one) owns 128
+// consecutive timesteps of one strand and walks the channels in 128-byte K-tiles as a software pipeline with ONE barrier
+// per K-tile.  In iteration `it`
+//   * the LDS-DMAs (buffer_load ... lds: constant 32-bit lane offsets + scalar offsets) of Wx(it), taps(it+1) and the raw
+//     x tile (it+1) (128 rows + 3 halo rows on each side, from the blocked x tensor) are issued, each into the slot whose
+//     last reader finished one iteration earlier;
+//   * conv of K-tile it (VALU): thread = (16-byte channel chunk, 4 consecutive rows), convolved in two 8-byte halves
+//     (7 raw rows and 5 tap vectors from LDS each; channel pairs through the packed fp32 pipe; fp32 taps + bias + SiLU),
+//     result rounded to the model dtype and written into conv stage it & 1 in the MFMA A-fragment image (XOR swizzle);
+//   * MFMA of K-tile it-1 (matrix pipe): wave = 32 rows, x_dbl += c . Wx^T from conv stage (it-1) & 1, accumulators stay
+//     in registers across K-tiles; the same waves copy that conv stage to the blocked xc tensors the scan reads (1 KiB
+//     contiguous per store instruction).
 // Epilogue: dt_low [rows, 64] (model dtype) and B_t | C_t [rows, 32] (fp32) per direction, as the split-epilogue GEMM wrote.
 // HBM traffic per row: read E*s (x) + write 2*E*s (xc) instead of read 3*E*s + write 2*E*s, and one launch instead of three.
+// Measured: instruction-issue bound (VALU busy 44 %, ~500 wave-instructions per K-tile of which the conv
+// arithmetic is about half); removing the conv math, the MFMAs or the xc stores from the kernel saves 7 %, 6 % and 16 %.
+// Register pressure is a hard constraint: a spilled value is reloaded by a scratch load that shares vmcnt with the
+// DMAs in flight and drains them (an early version with 19 spilled dwords ran 1.8x slower).
 #include <type_traits>
 
 #include "common.hpp"
@@ -26,16 +33,15 @@ constexpr int CX_ROWS = 128;                 // output rows (timesteps) per bloc
 constexpr int CX_RAW = CX_ROWS + 8;          // raw rows staged per K-tile (3 + 128 + 3, padded to 17 groups of 8)
 constexpr int CX_ROWB = 128;                 // bytes of K per K-tile row
 constexpr int CX_RAW_BYTES = CX_RAW * CX_ROWB;           // 17408
-constexpr int CX_NRAW = 3;                   // raw ring depth
+constexpr int CX_NRAW = 2;                   // raw ring depth
 constexpr int CX_TILE_BYTES = CX_ROWS * CX_ROWB;         // 16384: cf, cr
 constexpr int CX_WROWS = 96;
 constexpr int CX_W_BYTES = CX_WROWS * CX_ROWB;           // 12288 per direction
 constexpr int CX_CW_BYTES = 3072;            // conv taps of one K-tile: [dir][5][KC] fp32, padded
-constexpr int CX_OFF_CF = CX_NRAW * CX_RAW_BYTES;
-constexpr int CX_OFF_CR = CX_OFF_CF + CX_TILE_BYTES;
-constexpr int CX_OFF_W = CX_OFF_CR + CX_TILE_BYTES;      // [2 stages][2 dirs]
+constexpr int CX_OFF_C = CX_NRAW * CX_RAW_BYTES;         // conv outputs: [2 stages][cf, cr]
+constexpr int CX_OFF_W = CX_OFF_C + 2 * 2 * CX_TILE_BYTES;   // [2 stages][2 dirs]
 constexpr int CX_OFF_CW = CX_OFF_W + 2 * 2 * CX_W_BYTES; // [2 stages]
-constexpr int CX_LDS = CX_OFF_CW + 2 * CX_CW_BYTES;      // 140288
+constexpr int CX_LDS = CX_OFF_CW + 2 * CX_CW_BYTES;      // 155648
 constexpr int CX_THREADS = 512;
 
 __device__ __forceinline__ int cx_key(int r) { return (r >> 1) & 7; }
@@ -43,6 +49,12 @@ __device__ __forceinline__ int cx_key(int r) { return (r >> 1) & 7; }
 __device__ __forceinline__ void cx_glds16(const char* gsrc, char* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+// LDS-DMA through a buffer descriptor: descriptor base + per-lane 32-bit offset + wave-uniform 32-bit offset
+__device__ __forceinline__ void cx_blds16(const void* base, uint32_t voff, uint32_t soff, char* lds_wave_base) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(__builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0x7ffffffc, 0x00020000),
+                                             (__attribute__((address_space(3))) void*)lds_wave_base, 16, (int)voff, (int)soff, 0, 0);
 }
 
 template <typename T> struct CxMma;
@@ -65,6 +77,11 @@ template <> struct CxMma<float> {
 template <typename T> struct Chunk;
 template <> struct Chunk<bf16_t> {
     static constexpr int CPC = 8;
+    static __device__ __forceinline__ void unpack_half(const u32x2& r, float (&v)[4]) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) { v[2 * i] = bf16lo_to_f32(r[i]); v[2 * i + 1] = bf16hi_to_f32(r[i]); }
+    }
+    static __device__ __forceinline__ u32x2 pack_half(const float (&v)[4]) { return u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])}; }
     static __device__ __forceinline__ void unpack(const u32x4& r, float (&v)[8]) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) { v[2 * i] = bf16lo_to_f32(r[i]); v[2 * i + 1] = bf16hi_to_f32(r[i]); }
@@ -78,6 +95,8 @@ template <> struct Chunk<bf16_t> {
 };
 template <> struct Chunk<float> {
     static constexpr int CPC = 4;
+    static __device__ __forceinline__ void unpack_half(const u32x2& r, float (&v)[2]) { v[0] = __uint_as_float(r[0]); v[1] = __uint_as_float(r[1]); }
+    static __device__ __forceinline__ u32x2 pack_half(const float (&v)[2]) { return u32x2{__float_as_uint(v[0]), __float_as_uint(v[1])}; }
     static __device__ __forceinline__ void unpack(const u32x4& r, float (&v)[4]) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) v[i] = __uint_as_float(r[i]);
@@ -114,166 +133,188 @@ __global__ __launch_bounds__(CX_THREADS, 2) void convx_kernel(const T* __restric
 
     // ---- staging (every wave issues exactly 7 LDS-DMAs per K-tile: 3 raw + 3 Wx + 1 taps) -------------------------
     // raw: 17 groups of 8 rows; wave w stages groups w, w + 8 and (all waves, redundantly) group 16
-    const char* xb = reinterpret_cast<const char*>(x);
-    int64_t raw_src[3];
+    uint32_t raw_src[3];                                          // 32-bit offsets (launcher checks the tensor sizes)
     int raw_dst[3];
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
         const int grp = i < 2 ? wave + 8 * i : 16;
         const int q = grp * 8 + (lane >> 3);                      // raw row index: t = t0 - 3 + q
         const int t = min(max(t0 - 3 + q, 0), L - 1);             // clamped address; masked in the conv
-        raw_src[i] = blocked_off(row0 + t, 0, pieces) + ((lane & 7) << 4);
+        raw_src[i] = (uint32_t)(blocked_off(row0 + t, 0, pieces) + ((lane & 7) << 4));
         raw_dst[i] = grp * 8 * CX_ROWB;
     }
     // Wx slabs: per direction 96 rows = 12 groups of 8; 24 groups over 8 waves = 3 each
-    const char* w_src[3];
-    int w_dst[3];
+    uint32_t w_src[3];
+    int w_dst[3], w_dir[3];
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
         const int grp = wave * 3 + i;                              // 0..23
         const int dir = grp / 12, g = grp - dir * 12;
         const int r = g * 8 + (lane >> 3);
-        const T* Wd = (const T*)(dir == 0 ? d0.Wx : d1.Wx);
-        w_src[i] = reinterpret_cast<const char*>(Wd + (int64_t)r * E) + (((lane & 7) ^ cx_key(r)) << 4);
+        w_dir[i] = dir;
+        w_src[i] = (uint32_t)((int64_t)r * E * (int64_t)sizeof(T) + (((lane & 7) ^ cx_key(r)) << 4));
         w_dst[i] = dir * CX_W_BYTES + g * 8 * CX_ROWB;
     }
-    const char* cw_src = reinterpret_cast<const char*>(convw) + (wave % CW_PIECES) * 1024 + lane * 16;
+    const uint32_t cw_src = (uint32_t)((wave % CW_PIECES) * 1024 + lane * 16);
     const int cw_dst = (wave % CW_PIECES) * 1024;
 
     auto stage_raw = [&](int kt) {
         char* base = smem + (kt % CX_NRAW) * CX_RAW_BYTES;
 #pragma unroll
-        for (int i = 0; i < 3; ++i) cx_glds16(xb + raw_src[i] + (int64_t)kt * 1024, base + raw_dst[i]);
+        for (int i = 0; i < 3; ++i) cx_blds16(x, raw_src[i], (uint32_t)kt * 1024u, base + raw_dst[i]);
     };
     auto stage_w = [&](int kt) {
         char* wb = smem + CX_OFF_W + (kt & 1) * 2 * CX_W_BYTES;
 #pragma unroll
-        for (int i = 0; i < 3; ++i) cx_glds16(w_src[i] + (int64_t)kt * CX_ROWB, wb + w_dst[i]);
-        cx_glds16(cw_src + (int64_t)kt * CX_CW_BYTES, smem + CX_OFF_CW + (kt & 1) * CX_CW_BYTES + cw_dst);
+        for (int i = 0; i < 3; ++i) cx_blds16(w_dir[i] ? d1.Wx : d0.Wx, w_src[i], (uint32_t)kt * (uint32_t)CX_ROWB, wb + w_dst[i]);
+    };
+    auto stage_taps = [&](int kt) {
+        cx_blds16(convw, cw_src, (uint32_t)kt * (uint32_t)CX_CW_BYTES, smem + CX_OFF_CW + (kt & 1) * CX_CW_BYTES + cw_dst);
     };
 
-    // ---- conv-pass mapping: direction, 16-byte chunk, 4 consecutive rows ---------------------------------------
-    const int cdir = __builtin_amdgcn_readfirstlane(tid >> 8);     // waves 0-3: causal, 4-7: anti-causal (wave-uniform)
+    // ---- a wave works on ONE direction in both passes: waves 0-3 causal, 4-7 anti-causal (wave-uniform) ---------
+    const int cdir = __builtin_amdgcn_readfirstlane(tid >> 8);
+    // conv mapping: 16-byte chunk, 4 consecutive rows
     const int c8 = tid & 7;
     const int g4 = ((tid >> 3) & 31) * 4;      // first output row (tile-relative)
     const int qbase = g4 + (cdir ? 3 : 0);     // first raw row of the 7-row window: fwd q = r .. r+3, rev q = r+3 .. r+6
-    // ---- MFMA-pass mapping: direction, 32 rows ------------------------------------------------------------------
-    const int mdir = wave >> 2, mq = wave & 3;
+    // MFMA mapping: 32 rows
+    const int mq = wave & 3;
     const int li = lane & 15, lg = lane >> 4;
-    int a_off[2], a_key[2], wf_off[6], wf_key[6];
+    // fragment byte offset inside a tile for k-step kk: rows of one fragment are 16 apart and cx_key(r + 16) == cx_key(r),
+    // so ONE lane offset per kk serves every A and W fragment (+ a compile-time row-block offset)
+    int frag_lo[2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) { const int r = mq * 32 + i * 16 + li; a_off[i] = r * CX_ROWB; a_key[i] = cx_key(r); }
-#pragma unroll
-    for (int j = 0; j < 6; ++j) { const int r = j * 16 + li; wf_off[j] = r * CX_ROWB; wf_key[j] = cx_key(r); }
+    for (int kk = 0; kk < 2; ++kk) frag_lo[kk] = li * CX_ROWB + (((kk * 4 + lg) ^ cx_key(li)) << 4);
     f32x4 acc[2][6];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 6; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    // ---- xc store-pass mapping: wave w copies rows 16w .. 16w+15 of cf and of cr (8 rows x 128 B per instruction) ---
+    // xc store mapping: wave w copies rows 16w .. 16w+15 of cf and of cr (8 rows x 128 B per instruction)
     T* xcf = (T*)d0.xc;
     T* xcr = (T*)d1.xc;
+    const bool full_tile = t0 + CX_ROWS <= L;          // every xc store instruction is issued
 
-    // prologue: K-tiles 0 and 1 of raw, K-tile 0 of W / taps
-    stage_w(0);
-    stage_raw(0);
-    if (nkt > 1) stage_raw(1);
-    for (int kt = 0; kt < nkt; ++kt) {
-        // issue order per iteration: W(kt+1), taps(kt+1), raw(kt+2); needed now: raw(kt), W(kt), taps(kt).  DMAs retire in
-        // order, so "at most 3 outstanding" (the raw DMAs of kt+1) means everything needed has landed.
-        if (kt + 1 < nkt) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();          // (1) this K-tile's inputs are in LDS; cf / cr are free (MFMA + copy of kt-1 done)
-        asm volatile("" ::: "memory");
-        if (kt + 1 < nkt) stage_w(kt + 1);
-        if (kt + 2 < nkt) stage_raw(kt + 2);
-
-        // ---------------- conv pass ----------------
-        auto conv_pass = [&](auto rev_tag) {
-            constexpr bool REVC = decltype(rev_tag)::value;       // static window indices (no dynamic register indexing)
-            const char* raw = smem + (kt % CX_NRAW) * CX_RAW_BYTES;
-            const float* cw = reinterpret_cast<const float*>(smem + CX_OFF_CW + (kt & 1) * CX_CW_BYTES) + (REVC ? 5 * KC : 0) + c8 * CPC;
-            float wt[4][CPC], bias[CPC];
+    // Software pipeline, ONE barrier per K-tile: iteration `it` runs the conv of K-tile it (VALU, writes conv stage it&1)
+    // and the MFMAs + xc copy-out of K-tile it-1 (matrix pipe + LDS, reads conv stage (it-1)&1) in the same barrier
+    // interval, so the two pipes overlap instead of alternating.  DMAs issued at the start of iteration it: Wx(it),
+    // taps(it+1), raw(it+1), each into the slot whose last reader finished in iteration it-1.
+    auto mfma_half = [&](int mt, int kk) {
+        const char* at = smem + CX_OFF_C + (mt & 1) * 2 * CX_TILE_BYTES + cdir * CX_TILE_BYTES;
+        const char* wb = smem + CX_OFF_W + (mt & 1) * 2 * CX_W_BYTES + cdir * CX_W_BYTES;
+        u32x4 af[2], wfr[6];
 #pragma unroll
-            for (int k = 0; k < 4; ++k)
+        for (int i = 0; i < 2; ++i) af[i] = *reinterpret_cast<const u32x4*>(at + (mq * 32 + i * 16) * CX_ROWB + frag_lo[kk]);
 #pragma unroll
-                for (int e = 0; e < CPC; e += 4) {
-                    const f32x4 v = *reinterpret_cast<const f32x4*>(cw + k * KC + e);
-                    wt[k][e] = v[0]; wt[k][e + 1] = v[1]; wt[k][e + 2] = v[2]; wt[k][e + 3] = v[3];
+        for (int j = 0; j < 6; ++j) wfr[j] = *reinterpret_cast<const u32x4*>(wb + j * 16 * CX_ROWB + frag_lo[kk]);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 6; ++j) acc[i][j] = CxMma<T>::run(wfr[j], af[i], acc[i][j]);
+    };
+    // xc copy-out: lane offset of row r0 = 16 * wave + lane / 8 (the i = 1 row is 8 rows = one 1 KiB row-block further)
+    const int cr0 = wave * 16 + (lane >> 3);
+    const uint32_t xc_lo = (uint32_t)(blocked_off(row0 + t0 + cr0, 0, pieces) + ((lane & 7) << 4));
+    const uint32_t xc_blk = (uint32_t)(pieces << 10);
+    int c_lds[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) c_lds[i] = (cr0 + i * 8) * CX_ROWB + (((lane & 7) ^ cx_key(cr0 + i * 8)) << 4);
+    auto copy_out = [&](int mt) {
+#pragma unroll
+        for (int d = 0; d < 2; ++d) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const u32x4 v = *reinterpret_cast<const u32x4*>(smem + CX_OFF_C + (mt & 1) * 2 * CX_TILE_BYTES + d * CX_TILE_BYTES +
+                                                               c_lds[i]);
+                if (t0 + cr0 + i * 8 < L) {
+                    char* dst = reinterpret_cast<char*>(d ? xcr : xcf) + (xc_lo + (uint32_t)i * xc_blk + (uint32_t)mt * 1024u);
+                    *reinterpret_cast<u32x4*>(dst) = v;
                 }
-#pragma unroll
-            for (int e = 0; e < CPC; e += 4) {
-                const f32x4 v = *reinterpret_cast<const f32x4*>(cw + 4 * KC + e);
-                bias[e] = v[0]; bias[e + 1] = v[1]; bias[e + 2] = v[2]; bias[e + 3] = v[3];
             }
-            float win[7][CPC];
+        }
+    };
+    auto conv_pass = [&](int kt, auto rev_tag, bool with_mfma) {
+        constexpr bool REVC = decltype(rev_tag)::value;       // static window indices (no dynamic register indexing)
+        const char* raw = smem + (kt % CX_NRAW) * CX_RAW_BYTES;
+        const float* cw = reinterpret_cast<const float*>(smem + CX_OFF_CW + (kt & 1) * CX_CW_BYTES) + (REVC ? 5 * KC : 0) + c8 * CPC;
+        if (with_mfma) mfma_half(kt - 1, 0);
+        char* ct = smem + CX_OFF_C + (kt & 1) * 2 * CX_TILE_BYTES + (REVC ? CX_TILE_BYTES : 0);
+        const f32x2_t nl2e = {-kLog2e, -kLog2e}, one = {1.0f, 1.0f};
+        // The 16-byte chunk is convolved in two halves of HC channels (8-byte LDS accesses: same LDS cycles, half the live
+        // registers: a spill here costs far more than its load - a scratch reload shares vmcnt with the LDS-DMAs in flight
+        // and drains them).  Channel pairs go through the packed fp32 pipe: taps, bias and window as (e, e+1) pairs.
+        constexpr int HC = CPC / 2;
+        auto conv_half = [&](int h) {
+            f32x2_t wt[4][HC / 2], bias[HC / 2];
+#pragma unroll
+            for (int k = 0; k < 5; ++k)
+#pragma unroll
+                for (int e = 0; e < HC; e += 2) {
+                    const f32x2_t v = *reinterpret_cast<const f32x2_t*>(cw + k * KC + h * HC + e);
+                    if (k < 4) wt[k][e / 2] = v; else bias[e / 2] = v;
+                }
+            f32x2_t win[7][HC / 2];
 #pragma unroll
             for (int j = 0; j < 7; ++j) {
                 const int q = qbase + j;
                 const int t = t0 - 3 + q;
-                u32x4 r = *reinterpret_cast<const u32x4*>(raw + q * CX_ROWB + c8 * 16);
+                u32x2 r = *reinterpret_cast<const u32x2*>(raw + q * CX_ROWB + c8 * 16 + h * 8);
                 const unsigned keep = 0u - (unsigned)((unsigned)t < (unsigned)L);   // zero padding at the sequence ends,
-                r &= u32x4{keep, keep, keep, keep};                                  // branch-free (loads stay batched)
-                Chunk<T>::unpack(r, win[j]);
+                r &= u32x2{keep, keep};                                              // branch-free (loads stay batched)
+                float w1[HC];
+                Chunk<T>::unpack_half(r, w1);
+#pragma unroll
+                for (int e = 0; e < HC / 2; ++e) win[j][e] = f32x2_t{w1[2 * e], w1[2 * e + 1]};
             }
-            char* ct = smem + (REVC ? CX_OFF_CR : CX_OFF_CF);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                float o[CPC];
+                float o[HC];
 #pragma unroll
-                for (int e = 0; e < CPC; ++e) {
-                    float a = bias[e];
+                for (int e = 0; e < HC / 2; ++e) {
+                    f32x2_t a = bias[e];
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) a += wt[k][e] * win[REVC ? (j + 3 - k) : (j + k)][e];   // x[t+3-k] / x[t-3+k]
-                    o[e] = silu(a);
+                    for (int k = 0; k < 4; ++k) a = wt[k][e] * win[REVC ? (j + 3 - k) : (j + k)][e] + a;   // x[t+3-k] / x[t-3+k]
+                    const f32x2_t x2 = a * nl2e;                                  // silu(a) = a / (1 + 2^(-a log2 e))
+                    const f32x2_t den = f32x2_t{fast_exp2(x2[0]), fast_exp2(x2[1])} + one;
+                    const f32x2_t sv = a * f32x2_t{fast_rcp(den[0]), fast_rcp(den[1])};
+                    o[2 * e] = sv[0]; o[2 * e + 1] = sv[1];
                 }
                 const int r = g4 + j;
-                *reinterpret_cast<u32x4*>(ct + r * CX_ROWB + ((c8 ^ cx_key(r)) << 4)) = Chunk<T>::pack(o);
+                *reinterpret_cast<u32x2*>(ct + r * CX_ROWB + ((c8 ^ cx_key(r)) << 4) + h * 8) = Chunk<T>::pack_half(o);
             }
         };
-        if (cdir) conv_pass(std::true_type{});
-        else conv_pass(std::false_type{});
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();          // (2) cf / cr complete
-        asm volatile("" ::: "memory");
+        conv_half(0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (with_mfma) mfma_half(kt - 1, 1);
+        conv_half(1);
+        if (with_mfma) copy_out(kt - 1);
+    };
 
-        // ---------------- MFMA pass + copy of cf / cr to the blocked xc tensors ----------------
-        {
-            const char* at = smem + (mdir ? CX_OFF_CR : CX_OFF_CF);
-            const char* wb = smem + CX_OFF_W + (kt & 1) * 2 * CX_W_BYTES + mdir * CX_W_BYTES;
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-                const int chunk = kk * 4 + lg;
-                u32x4 af[2], wfr[6];
-#pragma unroll
-                for (int i = 0; i < 2; ++i) af[i] = *reinterpret_cast<const u32x4*>(at + a_off[i] + ((chunk ^ a_key[i]) << 4));
-#pragma unroll
-                for (int j = 0; j < 6; ++j) wfr[j] = *reinterpret_cast<const u32x4*>(wb + wf_off[j] + ((chunk ^ wf_key[j]) << 4));
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-#pragma unroll
-                    for (int j = 0; j < 6; ++j) acc[i][j] = CxMma<T>::run(wfr[j], af[i], acc[i][j]);
-            }
-#pragma unroll
-            for (int d = 0; d < 2; ++d) {
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    const int r = wave * 16 + i * 8 + (lane >> 3);
-                    const int t = t0 + r;
-                    const u32x4 v = *reinterpret_cast<const u32x4*>(smem + (d ? CX_OFF_CR : CX_OFF_CF) + r * CX_ROWB +
-                                                                   (((lane & 7) ^ cx_key(r)) << 4));
-                    if (t < L) {
-                        char* dst = reinterpret_cast<char*>(d ? xcr : xcf) + blocked_off(row0 + t, 0, pieces) + (int64_t)kt * 1024 +
-                                    ((lane & 7) << 4);
-                        *reinterpret_cast<u32x4*>(dst) = v;
-                    }
-                }
-            }
+    // prologue: taps(0), raw(0)
+    stage_taps(0);
+    stage_raw(0);
+    for (int it = 0; it <= nkt; ++it) {
+        // everything issued in the previous iteration (Wx(it-1), taps(it), raw(it)) must have landed; younger than those are
+        // only that iteration's 4 xc stores (vmcnt retires in issue order, loads and stores alike)
+        if (full_tile && it >= 2) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (it < nkt) stage_w(it);
+        if (it + 1 < nkt) { stage_taps(it + 1); stage_raw(it + 1); }
+        if (it < nkt) {
+            if (cdir) { if (it > 0) conv_pass(it, std::true_type{}, true); else conv_pass(it, std::true_type{}, false); }
+            else { if (it > 0) conv_pass(it, std::false_type{}, true); else conv_pass(it, std::false_type{}, false); }
+        } else {
+            mfma_half(it - 1, 0);
+            mfma_half(it - 1, 1);
+            copy_out(it - 1);
         }
     }
 
     // ---- epilogue: lane (li = row, lg): fragment j -> columns j*16 + lg*4 .. +3 --------------------------------
-    const ConvxDir dd = mdir ? d1 : d0;
+    const ConvxDir dd = cdir ? d1 : d0;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int t = t0 + mq * 32 + i * 16 + li;
@@ -336,6 +377,7 @@ hipError_t launch_convx(const void* x, const float* convw, const void* Wx0, void
     if (S <= 0 || L <= 0) return hipSuccess;
     const int esz = dt == BF16 ? 2 : 4;
     if ((E * esz) % CX_ROWB) return hipErrorInvalidValue;
+    if (((int64_t)S * L + 8) * E * esz >= ((int64_t)1 << 31)) return hipErrorInvalidValue;     // 32-bit in-tensor offsets
     ConvxDir d0{Wx0, xc0, dtl0, bc0}, d1{Wx1, xc1, dtl1, bc1};
     const int tiles = S * ((L + CX_ROWS - 1) / CX_ROWS);
     static bool attr_b = false, attr_f = false;
