@@ -62,7 +62,8 @@ struct pcad_engine {
     int D, E, N, R, Rp, XP, V, nl;
     int esz;        // bytes per activation element
     int rdt;        // residual dtype
-    int chunk;      // sequences per pass through the layer stack
+    int chunk;      // PCAD_CHUNK_SEQS override: sequences per pass through the layer stack (0: derive from chunk_rows)
+    int64_t chunk_rows;   // token-rows (2 strands x L per window) per pass through the layer stack
     int nstreams;   // 1: everything on the caller's stream; 2: chunks alternate between two library streams
     bool gate_once; // SiLU(z) applied once to y_fwd + y_rev (reverse scan) instead of once per direction
     bool convx;     // conv + x_proj of both directions in one kernel (needs xzsplit and Rp == 64); PCAD_NO_CONVX=1: off
@@ -221,10 +222,14 @@ int pcad_create(const pcad_config* cfg, pcad_handle* out) {
     e->esz = cfg->dtype == PCAD_BF16 ? 2 : 4;
     e->rdt = (cfg->residual_in_fp32 || cfg->dtype == PCAD_F32) ? F32 : BF16;
     const char* ck = getenv("PCAD_CHUNK_SEQS");
-    // windows per chunk such that the scan launch (2 strands x E/64 waves per window) is 4096 waves = 4 per SIMD, its
-    // occupancy: 64 at l32 (E = 2048), 85 at l28, 128 at l24, 170 at l20
-    e->chunk = ck ? atoi(ck) : (131072 + e->E - 1) / e->E;
-    if (e->chunk < 1) e->chunk = 1;
+    // Token-rows per chunk: as many as the kernels' 32-bit in-tensor byte offsets allow (rows * E * esz < 2^31 in the fused
+    // conv+x_proj kernel and the 4-wave GEMM, rows * E * 4 < 2^32 in the scan): 2^30 / (E * esz) = 262144 rows = 256 windows of
+    // 512 bp at l32 bf16 (7.7 GB of workspace).  Fewer, larger launches: 1024 windows as 4 chunks instead of 16 measured +6 %
+    // (each of the 193 launches per chunk pays a fill/drain of the chip).  Floor: one launch of the scan should fill the
+    // chip's 4096 wave slots (2 strands x E/64 waves per window).
+    e->chunk = ck ? atoi(ck) : 0;
+    if (e->chunk < 0) e->chunk = 0;
+    e->chunk_rows = ((int64_t)1 << 30) / ((int64_t)e->E * e->esz);
     e->blocked = getenv("PCAD_PLAIN_LAYOUT") == nullptr && (e->E * e->esz) % 128 == 0;
     e->xzsplit = e->blocked && getenv("PCAD_PLAIN_XZ") == nullptr && e->E % 16 == 0;
     e->convx = e->xzsplit && e->Rp == 64 && getenv("PCAD_NO_CONVX") == nullptr;
@@ -343,15 +348,18 @@ int pcad_bind_weights(pcad_handle h, const pcad_tensor* tensors, int n, void* ar
     return PCAD_OK;
 }
 
-// windows per chunk for a batch of B: the fewest chunks of at most `chunk` windows, evenly sized (no small tail chunk)
-static int chunk_for(const pcad_engine* e, int B) {
-    const int n = (B + e->chunk - 1) / e->chunk;
-    return (B + n - 1) / n;
+// windows per chunk for a batch of B windows of L positions: the fewest chunks within the row limit, evenly sized (no small
+// tail chunk)
+static int chunk_for(const pcad_engine* e, int B, int L) {
+    int64_t cap = e->chunk > 0 ? e->chunk : e->chunk_rows / (2 * (int64_t)L);
+    if (cap < 1) cap = 1;
+    const int64_t n = (B + cap - 1) / cap;
+    return (int)((B + n - 1) / n);
 }
 
 size_t pcad_workspace_bytes(pcad_handle h, int batch, int seqlen) {
     if (!h || batch <= 0 || seqlen <= 0) return 0;
-    const int Bc = chunk_for(h, batch);
+    const int Bc = chunk_for(h, batch, seqlen);
     const int nchunks = (batch + Bc - 1) / Bc;
     const int lanes = (h->nstreams == 2 && nchunks >= 2) ? 2 : 1;     // one workspace slab per concurrent chunk
     return carve_workspace(h, nullptr, Bc, seqlen).bytes * lanes;
@@ -385,7 +393,7 @@ static int forward_impl(pcad_handle h, const int32_t* ids, int B, int L, const i
     const size_t esz = e->esz;
     const float eps = e->cfg.eps;
     const int Q = pos_per_seq ? 1 : (P ? P : L);
-    const int chunk = chunk_for(e, B);
+    const int chunk = chunk_for(e, B, L);
     const int nchunks = (B + chunk - 1) / chunk;
     const int lanes = (e->nstreams == 2 && nchunks >= 2) ? 2 : 1;
     const size_t slab = carve_workspace(e, nullptr, chunk, L).bytes;
