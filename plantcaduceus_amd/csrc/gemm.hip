@@ -780,7 +780,7 @@ constexpr int GEMMQ_THREADS = 256;
 // to lds_wave_base + lane * 16.  (Device-only builtins live in __device__ helpers so the host pass still emits the stub.)
 __device__ __forceinline__ void blds16(const void* base, uint32_t voff, uint32_t soff, char* lds_wave_base) {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(__builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0x7ffffffc, 0x00020000),
-                                             (__attribute__((address_space(3))) void*)lds_wave_base, 16, (int)voff, (int)soff, 0, 0);
+                                             (__attribute__((address_space(3))) void*)lds_wave_base, 16, (int)voff, (int)soff, 0, 1);   // aux 1 = sc0: +2-3 % on in_proj in a same-box A/B (nt: -8 %)
 }
 
 // MFMA with the accumulator pinned to AGPRs: at 256 accumulator registers per wave the register allocator otherwise
