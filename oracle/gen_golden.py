@@ -199,6 +199,52 @@ def gen_plantcad2():
     print("plantcad2:", single.shape, multi.shape, unm.shape)
 
 
+def gen_plantcad2_metrics():
+    """reference src/zero-shot-eval.py:181-320: the task metrics (token / motif accuracy, AUROC, AUPRC, ref-prob and
+    true-prob scores, SV boundary LLR) on seeded synthetic tables -> inputs (json) + the reference's outputs (npz)."""
+    import json
+    sys.modules.setdefault("fire", types.ModuleType("fire"))
+    ev = import_reference("ref_eval_m", "src/zero-shot-eval.py")
+    from sklearn.metrics import average_precision_score
+    rng = np.random.default_rng(21)
+    n, Ls, positions, motif_len = 48, 40, [17, 18, 19], 3
+    alphabet = np.array(list("ACGTacgtNn"))
+    seqs = ["".join(rng.choice(alphabet, size=Ls, p=[.2, .2, .2, .2, .04, .04, .04, .04, .02, .02])) for _ in range(n)]
+    labels = rng.integers(0, 2, size=n)
+    probs3 = rng.dirichlet([0.7] * 4, size=n * motif_len)
+    probs1 = np.round(rng.dirichlet([0.7] * 4, size=n), 2)          # rounding -> tied scores
+    probs1 /= probs1.sum(1, keepdims=True)
+    df = pd.DataFrame({"sequence": seqs, "label": labels})
+    tt = ev._compute_true_tokens_from_seq(df["sequence"], positions)
+    for r, b in enumerate(tt):                                      # a model that is right about 70 % of the time
+        if b in "ACGT" and rng.random() < 0.7:
+            probs3[r, "ACGT".index(b)] += 2.0
+    probs3 /= probs3.sum(1, keepdims=True)
+    out = dict(token_acc=ev._metric_token_accuracy(probs3, tt), motif_acc=ev._metric_motif_accuracy(probs3, tt, motif_len),
+               auroc=ev._compute_auroc(df, probs1, 18, "sequence"), refprob=ev._refprob_scores(df, probs1, 18, "sequence"),
+               avgtrue=ev._avg_trueprob_scores(probs3, tt, motif_len))
+    out["auprc"] = float(average_precision_score(labels, out["refprob"]))
+    out["auroc_avgtrue"] = float(ev.auc(*ev.roc_curve(labels, out["avgtrue"])[:2]))
+    # SV: windows of length Lw, central 2*flanking positions mutated; left/right 1-based boundaries with room for the flanks
+    Lw, F = 48, 5
+    ref_seqs = ["".join(rng.choice(alphabet, size=Lw, p=[.2, .2, .2, .2, .04, .04, .04, .04, .02, .02])) for _ in range(n)]
+    mut_seqs = ["".join(rng.choice(alphabet, size=Lw, p=[.2, .2, .2, .2, .04, .04, .04, .04, .02, .02])) for _ in range(n)]
+    left = rng.integers(F + 1, 18, size=n)
+    right = rng.integers(24, Lw - F, size=n)
+    ref_p = rng.dirichlet([0.5] * 4, size=(n, Lw))
+    mut_p = rng.dirichlet([0.5] * 4, size=(n, Lw))
+    mut_p[0, Lw // 2, :] = [0.0, 1.0, 0.0, 0.0]                    # exercises the 1e-12 floor
+    sv_df = pd.DataFrame({"RefSeq": ref_seqs, "MutSeq": mut_seqs, "left": left, "right": right, "label": labels})
+    out["sv_scores"] = ev._sv_llr_boundary(sv_df, ref_p, mut_p, F)
+    out["sv_auprc"] = float(average_precision_score(labels, out["sv_scores"]))
+    np.savez_compressed(os.path.join(OUT, "harness_plantcad2_metrics.npz"), labels=labels, probs3=probs3, probs1=probs1,
+                        positions=np.array(positions), motif_len=motif_len, token_idx=18, left=left, right=right, ref_p=ref_p,
+                        mut_p=mut_p, flanking=F, true_tokens=tt, **{k: np.asarray(v) for k, v in out.items()})
+    with open(os.path.join(OUT, "harness_plantcad2_metrics.json"), "w") as f:
+        json.dump({"sequences": seqs, "RefSeq": ref_seqs, "MutSeq": mut_seqs}, f)
+    print("plantcad2 metrics:", {k: (float(v) if np.ndim(v) == 0 else np.shape(v)) for k, v in out.items()})
+
+
 def gen_model_tiny():
     cfg = make_config("x", d_model=64, n_layer=3)
     sd = synthetic_state_dict(cfg, seed=2024)
@@ -219,4 +265,5 @@ if __name__ == "__main__":
     gen_model_tiny()
     gen_harness()
     gen_plantcad2()
+    gen_plantcad2_metrics()
     print("golden vectors written to", OUT)

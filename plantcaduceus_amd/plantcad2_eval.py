@@ -6,13 +6,18 @@
                   (sequence, ascending position) order (the order of the reference's `torch.masked_select`)
   unmasked_probs  `_unmasked_probs` (:143-178): per-position probabilities of the un-masked sequence -> [N, L, 4]
 
-Only the head rows that are read are evaluated (`positions=`); tokenisation is the vectorised LUT.  The task drivers
-built on these in the reference (SV boundary LLR, AUROC tables, HF `datasets` loading) are CPU-side bookkeeping and
-are not reproduced.
+Only the head rows that are read are evaluated (`positions=`); tokenisation is the vectorised LUT.
+
+Task metrics and drivers on top of them (same file, `:181-320` and `ZeroShotEval` `:323-530`), vectorised numpy, no
+sklearn: `true_tokens`, `token_accuracy`, `motif_accuracy`, `refprob_scores`, `auroc`, `average_precision`,
+`avg_trueprob_scores`, `sv_llr_boundary`, and the four tasks `evo_cons`, `motif_acc`, `core_noncore`, `sv_effect`, which
+take a DataFrame (or a local .tsv/.csv/.parquet path - there is no network for HF `datasets` here) and print / return
+the reference's metric lines.  Pinned by `tests/golden/harness_plantcad2_metrics.*` (outputs of the reference's functions).
 """
 from __future__ import annotations
 
-from typing import Sequence, Union
+import json
+from typing import Dict, Optional, Sequence, Union
 
 import numpy as np
 import torch
@@ -52,3 +57,233 @@ def unmasked_probs(sequences: Sequence[str], tokenizer, model, device, batch_siz
             lg = model(input_ids=ids_all[b0:b0 + batch_size].to(device)).logits[..., cols]
             out[b0:b0 + batch_size] = torch.softmax(lg.float(), dim=-1).cpu().numpy()
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# task metrics (reference src/zero-shot-eval.py:181-320)
+NUCLEOTIDES = ("A", "C", "G", "T")
+_CODE = np.full(256, -1, dtype=np.int64)
+for _i, _b in enumerate(NUCLEOTIDES):
+    _CODE[ord(_b)] = _i
+    _CODE[ord(_b.lower())] = _i
+
+
+def _codes(sequences, positions) -> np.ndarray:
+    """[N, len(positions)] index into A,C,G,T of sequence[p] (case-insensitive), -1 for anything else."""
+    pos = np.asarray(list(positions), dtype=np.int64)
+    seqs = [str(x) for x in sequences]
+    out = np.full((len(seqs), len(pos)), -1, dtype=np.int64)
+    for i, q in enumerate(seqs):                       # strings may differ in length; positions must exist (as in the reference)
+        b = np.frombuffer(q.encode("latin-1", "replace"), dtype=np.uint8)
+        out[i] = _CODE[b[pos]]
+    return out
+
+
+def true_tokens(sequences, positions: Sequence[int]) -> np.ndarray:
+    """`_compute_true_tokens_from_seq` (:246-251): upper-cased base at every position of every sequence, row-major."""
+    return np.array([str(q)[int(p)].upper() for q in sequences for p in positions])
+
+
+def _token_codes(tokens) -> np.ndarray:
+    t = np.asarray(tokens)
+    lut = {b: i for i, b in enumerate(NUCLEOTIDES)}
+    return np.array([lut.get(str(x), -1) for x in t], dtype=np.int64)
+
+
+def token_accuracy(probs: np.ndarray, tokens) -> float:
+    """`_metric_token_accuracy` (:254-261): arg-max call vs truth over the positions whose truth is A/C/G/T."""
+    c = _token_codes(tokens)
+    ok = c >= 0
+    if not ok.any():
+        return 0.0
+    return float((np.asarray(probs).argmax(axis=1)[ok] == c[ok]).mean())
+
+
+def motif_accuracy(probs: np.ndarray, tokens, motif_len: int) -> float:
+    """`_metric_motif_accuracy` (:264-274): all positions of a motif called right, over motifs without unknown bases."""
+    c = _token_codes(tokens)
+    if len(c) % motif_len:
+        raise AssertionError("total masked positions not divisible by motif_len")
+    c = c.reshape(-1, motif_len)
+    pred = np.asarray(probs).argmax(axis=1).reshape(-1, motif_len)
+    ok = (c >= 0).all(axis=1)
+    if not ok.any():
+        return 0.0
+    return float((pred[ok] == c[ok]).all(axis=1).mean())
+
+
+def refprob_scores(sequences, probs: np.ndarray, token_idx: int) -> np.ndarray:
+    """`_refprob_scores` (:290-298): probability of the sequence's own base at the masked index (0 for N etc.)."""
+    c = _codes(sequences, [token_idx])[:, 0]
+    p = np.asarray(probs).reshape(len(c), -1)
+    out = np.zeros(len(c), dtype=float)
+    ok = c >= 0
+    out[ok] = p[ok, c[ok]]
+    return out
+
+
+def _midranks(x: np.ndarray) -> np.ndarray:
+    order = np.argsort(x, kind="mergesort")
+    xs = x[order]
+    first = np.r_[True, xs[1:] != xs[:-1]]
+    start = np.flatnonzero(first)
+    end = np.r_[start[1:], len(xs)]
+    r = np.empty(len(xs), dtype=float)
+    for a, b in zip(start, end):
+        r[a:b] = 0.5 * (a + b - 1) + 1.0
+    out = np.empty(len(xs), dtype=float)
+    out[order] = r
+    return out
+
+
+def auroc(y_true, scores) -> float:
+    """area under `roc_curve` (`_compute_auroc` :277-288) = Mann-Whitney statistic with mid-ranks for ties."""
+    y = np.asarray(y_true).astype(int)
+    s = np.asarray(scores, dtype=float)
+    n1, n0 = int((y == 1).sum()), int((y == 0).sum())
+    if n1 == 0 or n0 == 0:
+        return float("nan")
+    r = _midranks(s)
+    return float((r[y == 1].sum() - n1 * (n1 + 1) / 2.0) / (n1 * n0))
+
+
+def average_precision(y_true, scores) -> float:
+    """sklearn's `average_precision_score`: sum over distinct thresholds of (recall step) x precision."""
+    y = np.asarray(y_true).astype(int)
+    s = np.asarray(scores, dtype=float)
+    order = np.argsort(-s, kind="mergesort")
+    y, s = y[order], s[order]
+    last = np.r_[s[1:] != s[:-1], True]                 # last element of every tie group
+    tp = np.cumsum(y)[last].astype(float)
+    n = (np.flatnonzero(last) + 1).astype(float)
+    npos = float(y.sum())
+    if npos == 0:
+        return 0.0
+    recall = tp / npos
+    return float(np.sum(np.diff(np.r_[0.0, recall]) * (tp / n)))
+
+
+def avg_trueprob_scores(probs: np.ndarray, tokens, motif_len: int) -> np.ndarray:
+    """`_avg_trueprob_scores` (:301-320): mean probability of the true base over the masked positions of each example."""
+    c = _token_codes(tokens)
+    if len(c) % motif_len:
+        raise AssertionError("total masked positions not divisible by motif_len")
+    p = np.asarray(probs)
+    v = np.zeros(len(c), dtype=float)
+    ok = c >= 0
+    v[ok] = p[np.flatnonzero(ok), c[ok]]
+    return v.reshape(-1, motif_len).mean(axis=1)
+
+
+def sv_llr_boundary(left, right, mut_seqs, ref_probs: np.ndarray, mut_probs: np.ndarray, flanking: int) -> np.ndarray:
+    """`_sv_llr_boundary` (:181-243): -mean over 2*flanking positions of log(p_mut / p_ref) of the MUTATED sequence's base;
+    ref windows (1-based `left`, `right`): [left-flanking, left-1] and [right+1, right+flanking]; mut window: the central
+    2*flanking positions of the mutated sequence; unknown bases contribute 0; probabilities floored at 1e-12."""
+    ref_probs, mut_probs = np.asarray(ref_probs), np.asarray(mut_probs)
+    n, L = ref_probs.shape[0], ref_probs.shape[1]
+    c0 = L // 2
+    k = np.arange(flanking)
+    left = np.asarray(left, dtype=np.int64)
+    right = np.asarray(right, dtype=np.int64)
+    ref_pos = np.concatenate([left[:, None] - flanking + k[None, :] - 1, right[:, None] + k[None, :]], axis=1)   # 0-based
+    mut_pos = np.arange(c0 - flanking, c0 + flanking)
+    base = _codes(mut_seqs, mut_pos)                                                # [n, 2F]
+    rows = np.arange(n)[:, None]
+    j = np.where(base >= 0, base, 0)
+    r = np.maximum(ref_probs[rows, ref_pos, j], 1e-12)
+    m = np.maximum(mut_probs[rows, mut_pos[None, :], j], 1e-12)
+    llr = np.where(base >= 0, np.log(m / r), 0.0)
+    return -llr.mean(axis=1)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# task drivers (reference `ZeroShotEval` :323-530); `data`: DataFrame or path to a local .tsv / .csv / .parquet table
+def _frame(data):
+    import pandas as pd
+    if isinstance(data, pd.DataFrame):
+        return data.reset_index(drop=True)
+    path = str(data)
+    if path.endswith(".parquet"):
+        return pd.read_parquet(path)
+    return pd.read_csv(path, sep="\t" if path.endswith((".tsv", ".txt")) else ",")
+
+
+def _probs_or_infer(df_col, model, tokenizer, device, idx, batch_size, logits_path, save_logits):
+    import pandas as pd
+    if logits_path is not None:
+        return pd.read_csv(logits_path, sep="\t").values
+    if model is None:
+        raise ValueError("either a model or logits_path is needed")
+    probs = masked_probs(model, tokenizer, list(df_col), idx, device, batch_size)
+    if save_logits:
+        pd.DataFrame(probs, columns=list(NUCLEOTIDES)).to_csv(save_logits, sep="\t", index=False)
+    return probs
+
+
+def _emit(metrics: Dict[str, float], metrics_json: Optional[str], extra: Optional[dict] = None) -> Dict[str, float]:
+    for key, v in metrics.items():
+        print(f"{key}\t{v:.6f}")
+    if metrics_json:
+        with open(metrics_json, "w") as f:
+            json.dump({**{k.lower(): v for k, v in metrics.items()}, **(extra or {})}, f, indent=2)
+    return metrics
+
+
+def evo_cons(data, model=None, tokenizer=None, device="cuda:0", token_idx: int = 255, batch_size: int = 128,
+             seq_column: str = "sequence", save_logits=None, logits_path=None, metrics_json=None) -> Dict[str, float]:
+    """:324-372 - masked probabilities at one index; AUROC / AUPRC of the reference-base probability against `label`."""
+    df = _frame(data)
+    probs = _probs_or_infer(df[seq_column], model, tokenizer, device, token_idx, batch_size, logits_path, save_logits)
+    assert probs.shape[0] == len(df), f"Row mismatch: probs={probs.shape[0]} examples={len(df)}"
+    sc = refprob_scores(df[seq_column], probs, token_idx)
+    y = df["label"].astype(int).to_numpy()
+    return _emit({"AUROC": auroc(y, sc), "AUPRC": average_precision(y, sc)}, metrics_json, {"token_idx": token_idx})
+
+
+def motif_acc(data, model=None, tokenizer=None, device="cuda:0", mask_idx: Sequence[int] = (255, 256, 257), motif_len: int = 3,
+              batch_size: int = 128, seq_column: str = "sequence", save_logits=None, logits_path=None,
+              metrics_json=None) -> Dict[str, float]:
+    """:374-428 - multi-position masking; token and whole-motif accuracy."""
+    df = _frame(data)
+    positions = [int(x) for x in mask_idx]
+    assert len(positions) == motif_len, "mask_idx count must equal motif_len"
+    probs = _probs_or_infer(df[seq_column], model, tokenizer, device, positions, batch_size, logits_path, save_logits)
+    assert probs.shape[0] == len(df) * len(positions), f"Row mismatch: probs={probs.shape[0]} expected={len(df) * len(positions)}"
+    tt = true_tokens(df[seq_column], sorted(positions))
+    return _emit({"token_accuracy": token_accuracy(probs, tt), "motif_accuracy": motif_accuracy(probs, tt, motif_len)},
+                 metrics_json)
+
+
+def core_noncore(data, model=None, tokenizer=None, device="cuda:0", mask_idx: Sequence[int] = (255, 256, 257),
+                 motif_len: int = 3, batch_size: int = 128, seq_column: str = "sequence", label_column: str = "label",
+                 save_logits=None, logits_path=None, metrics_json=None) -> Dict[str, float]:
+    """:478-530 - AUROC of the mean true-base probability over the masked positions against `label_column`."""
+    df = _frame(data)
+    positions = [int(x) for x in mask_idx]
+    assert len(positions) == motif_len, "mask_idx count must equal motif_len"
+    probs = _probs_or_infer(df[seq_column], model, tokenizer, device, positions, batch_size, logits_path, save_logits)
+    assert probs.shape[0] == len(df) * len(positions)
+    sc = avg_trueprob_scores(probs, true_tokens(df[seq_column], sorted(positions)), motif_len)
+    return _emit({"AUROC": auroc(df[label_column].astype(int).to_numpy(), sc)}, metrics_json)
+
+
+def sv_effect(data, model, tokenizer, device="cuda:0", batch_size: int = 64, flanking: int = 5, output=None,
+              save_ref_logits=None, save_mut_logits=None) -> Dict[str, float]:
+    """:430-476 - un-masked probabilities of RefSeq and MutSeq, boundary LLR per row, AUPRC against `label`."""
+    df = _frame(data)
+    missing = [c for c in ("RefSeq", "MutSeq", "left", "right", "label") if c not in df.columns]
+    if missing:
+        raise KeyError(f"Missing required columns: {missing}")
+    ref_p = unmasked_probs(df["RefSeq"], tokenizer, model, device, batch_size)
+    mut_p = unmasked_probs(df["MutSeq"], tokenizer, model, device, batch_size)
+    if save_ref_logits:
+        np.savez_compressed(save_ref_logits, logits=ref_p)
+    if save_mut_logits:
+        np.savez_compressed(save_mut_logits, logits=mut_p)
+    scores = sv_llr_boundary(df["left"], df["right"], df["MutSeq"], ref_p, mut_p, flanking)
+    res = _emit({"AUPRC": average_precision(df["label"].astype(int).to_numpy(), scores)}, None)
+    if output:
+        out = df.copy()
+        out["score"] = scores
+        out.drop(columns=["Left5_Positions", "Right5_Positions"], errors="ignore").to_csv(output, sep="\t", index=False)
+    return res

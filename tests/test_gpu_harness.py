@@ -135,3 +135,32 @@ def test_plantcad2_helpers_through_hip(golden_dir):
     un = pe.unmasked_probs(seqs, tok, m, DEV, batch_size=4)
     np.testing.assert_allclose(un, g["unmasked"], rtol=1e-4, atol=1e-6)
     assert (un.argmax(-1) == g["unmasked"].argmax(-1)).all()
+
+
+def test_plantcad2_sv_effect_and_motif_tasks_through_hip(golden_dir, tmp_path):
+    """task drivers end to end on the HIP model: sv_effect (un-masked probabilities of RefSeq / MutSeq -> boundary LLR ->
+    AUPRC) and motif_acc (multi-mask) agree with the same drivers' arithmetic on the oracle model's probabilities."""
+    from plantcaduceus_amd import plantcad2_eval as pe
+    import oracle.caduceus_oracle as O
+    cfg = make_config("x", d_model=64, n_layer=2)
+    sd = synthetic_state_dict(cfg, seed=5)
+    m = hip_model(cfg, sd, torch.float32)
+    om = O.OracleForMaskedLM(O.params_from_state_dict(sd, cfg))
+    tok = CaduceusTokenizer()
+    rng = np.random.default_rng(4)
+    n, L, F = 10, 64, 5
+    mk = lambda: "".join(rng.choice(list("ACGTN"), size=L, p=[.24, .24, .24, .24, .04]))
+    df = pd.DataFrame({"RefSeq": [mk() for _ in range(n)], "MutSeq": [mk() for _ in range(n)],
+                       "left": rng.integers(F + 1, 24, size=n), "right": rng.integers(36, L - F, size=n),
+                       "label": rng.integers(0, 2, size=n)})
+    out = tmp_path / "sv.tsv"
+    res = pe.sv_effect(df, m, tok, DEV, batch_size=4, flanking=F, output=str(out))
+    ref_scores = pe.sv_llr_boundary(df["left"], df["right"], df["MutSeq"], pe.unmasked_probs(df["RefSeq"], tok, om, "cpu", 4),
+                                    pe.unmasked_probs(df["MutSeq"], tok, om, "cpu", 4), F)
+    got = pd.read_csv(out, sep="\t")["score"].to_numpy()
+    np.testing.assert_allclose(got, ref_scores, rtol=1e-3, atol=1e-5)
+    assert res["AUPRC"] == pytest.approx(pe.average_precision(df["label"], ref_scores), abs=1e-6)
+    d2 = pd.DataFrame({"sequence": df["RefSeq"], "label": df["label"]})
+    a = pe.motif_acc(d2, m, tok, DEV, mask_idx=(30, 31, 32), motif_len=3, batch_size=4)
+    b = pe.motif_acc(d2, om, tok, "cpu", mask_idx=(30, 31, 32), motif_len=3, batch_size=4)
+    assert a == b

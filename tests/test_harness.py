@@ -158,3 +158,45 @@ def test_plantcad2_probability_helpers_match_reference(golden_dir, snp_df):
     np.testing.assert_allclose(un, g["unmasked"], rtol=2e-5, atol=1e-7)
     with pytest.raises(ValueError):
         pe.unmasked_probs(["ACGT", "ACG"], tok, model, "cpu")
+
+
+def test_plantcad2_task_metrics_match_reference(golden_dir, tmp_path, capsys):
+    """token / motif accuracy, AUROC, AUPRC, ref-prob and true-prob scores, SV boundary LLR: outputs of the reference's
+    src/zero-shot-eval.py:181-320 (sklearn roc_curve / average_precision_score where it uses them) on seeded tables with
+    lower-case and N bases, tied scores and a zero probability."""
+    import json
+    import pandas as pd
+    from plantcaduceus_amd import plantcad2_eval as pe
+    g = np.load(os.path.join(golden_dir, "harness_plantcad2_metrics.npz"))
+    tab = json.load(open(os.path.join(golden_dir, "harness_plantcad2_metrics.json")))
+    seqs, labels = tab["sequences"], g["labels"]
+    pos, ml, ti = [int(x) for x in g["positions"]], int(g["motif_len"]), int(g["token_idx"])
+    tt = pe.true_tokens(seqs, pos)
+    assert list(tt) == list(g["true_tokens"])
+    assert pe.token_accuracy(g["probs3"], tt) == pytest.approx(float(g["token_acc"]), abs=1e-12)
+    assert pe.motif_accuracy(g["probs3"], tt, ml) == pytest.approx(float(g["motif_acc"]), abs=1e-12)
+    assert 0.2 < float(g["motif_acc"]) < 0.9
+    ref = pe.refprob_scores(seqs, g["probs1"], ti)
+    np.testing.assert_allclose(ref, g["refprob"], rtol=0, atol=1e-15)
+    assert pe.auroc(labels, ref) == pytest.approx(float(g["auroc"]), abs=1e-12)
+    assert pe.average_precision(labels, ref) == pytest.approx(float(g["auprc"]), abs=1e-12)
+    avg = pe.avg_trueprob_scores(g["probs3"], tt, ml)
+    np.testing.assert_allclose(avg, g["avgtrue"], rtol=0, atol=1e-15)
+    assert pe.auroc(labels, avg) == pytest.approx(float(g["auroc_avgtrue"]), abs=1e-12)
+    sv = pe.sv_llr_boundary(g["left"], g["right"], tab["MutSeq"], g["ref_p"], g["mut_p"], int(g["flanking"]))
+    np.testing.assert_allclose(sv, g["sv_scores"], rtol=1e-12, atol=1e-12)
+    assert pe.average_precision(labels, sv) == pytest.approx(float(g["sv_auprc"]), abs=1e-12)
+    # drivers from saved probability tables (the reference's `logits_path` mode): same numbers, same printed lines
+    df = pd.DataFrame({"sequence": seqs, "label": labels})
+    p1, p3 = tmp_path / "p1.tsv", tmp_path / "p3.tsv"
+    pd.DataFrame(g["probs1"], columns=list("ACGT")).to_csv(p1, sep="\t", index=False)
+    pd.DataFrame(g["probs3"], columns=list("ACGT")).to_csv(p3, sep="\t", index=False)
+    m = pe.evo_cons(df, token_idx=ti, logits_path=str(p1), metrics_json=str(tmp_path / "m.json"))
+    assert m["AUROC"] == pytest.approx(float(g["auroc"]), abs=1e-9) and m["AUPRC"] == pytest.approx(float(g["auprc"]), abs=1e-9)
+    assert json.load(open(tmp_path / "m.json"))["token_idx"] == ti
+    m = pe.motif_acc(df, mask_idx=pos, motif_len=ml, logits_path=str(p3))
+    assert m["motif_accuracy"] == pytest.approx(float(g["motif_acc"]), abs=1e-9)
+    m = pe.core_noncore(df, mask_idx=pos, motif_len=ml, logits_path=str(p3))
+    assert m["AUROC"] == pytest.approx(float(g["auroc_avgtrue"]), abs=1e-9)
+    out = capsys.readouterr().out
+    assert "AUROC\t" in out and "token_accuracy\t" in out and "motif_accuracy\t" in out
