@@ -151,7 +151,7 @@ def main():
                                    % (args.model, cfg.d_model, cfg.n_layer, args.dtype, B, L, p),
                        "batch_per_gpu": B, "seq_len": L, "parallelism": "dp%d (batch-sharded, all_gather of [B,4])" % world},
         }
-        chunk_max = int(os.environ.get("PCAD_CHUNK_SEQS", str(max(1, (1 << 30) // (cfg.d_inner * esz) // (2 * L)))))   # as api.hip
+        chunk_max = int(os.environ.get("PCAD_CHUNK_SEQS", str(max(1, (1 << 31) // (cfg.d_inner * esz) // (2 * L)))))   # as api.hip
         nchunks = -(-B // chunk_max)
         chunk = -(-B // nchunks)                                  # even split, as pcad_forward does
         rows = 2 * chunk * L

@@ -222,14 +222,14 @@ int pcad_create(const pcad_config* cfg, pcad_handle* out) {
     e->esz = cfg->dtype == PCAD_BF16 ? 2 : 4;
     e->rdt = (cfg->residual_in_fp32 || cfg->dtype == PCAD_F32) ? F32 : BF16;
     const char* ck = getenv("PCAD_CHUNK_SEQS");
-    // Token-rows per chunk: as many as the kernels' 32-bit in-tensor byte offsets allow (rows * E * esz < 2^31 in the fused
-    // conv+x_proj kernel and the 4-wave GEMM, rows * E * 4 < 2^32 in the scan): 2^30 / (E * esz) = 262144 rows = 256 windows of
-    // 512 bp at l32 bf16 (7.7 GB of workspace).  Fewer, larger launches: 1024 windows as 4 chunks instead of 16 measured +6 %
+    // Token-rows per chunk: bounded by the kernels' unsigned 32-bit in-tensor byte offsets (rows * E * esz < 2^32 in the scan,
+    // the fused conv+x_proj kernel and the 4-wave GEMM); 2^31 / (E * esz) = 524288 rows = 512 windows of 512 bp at l32 bf16
+    // (15 GB of workspace) keeps a factor 2 of margin.  Fewer, larger launches: 1024 windows as 4 chunks instead of 16 measured +6 %
     // (each of the 193 launches per chunk pays a fill/drain of the chip).  Floor: one launch of the scan should fill the
     // chip's 4096 wave slots (2 strands x E/64 waves per window).
     e->chunk = ck ? atoi(ck) : 0;
     if (e->chunk < 0) e->chunk = 0;
-    e->chunk_rows = ((int64_t)1 << 30) / ((int64_t)e->E * e->esz);
+    e->chunk_rows = ((int64_t)1 << 31) / ((int64_t)e->E * e->esz);
     e->blocked = getenv("PCAD_PLAIN_LAYOUT") == nullptr && (e->E * e->esz) % 128 == 0;
     e->xzsplit = e->blocked && getenv("PCAD_PLAIN_XZ") == nullptr && e->E % 16 == 0;
     e->convx = e->xzsplit && e->Rp == 64 && getenv("PCAD_NO_CONVX") == nullptr;
@@ -438,7 +438,7 @@ static int forward_impl(pcad_handle h, const int32_t* ids, int B, int L, const i
         if (e->xzsplit) HIP_TRY(launch_gemm_nt_two(c.w.u, D, W.W_in, D, c.w.xz, c.w.zb, E, true, rows, 2 * E, D, dt, s));
         else HIP_TRY(launch_gemm_nt(c.w.u, D, W.W_in, D, c.w.xz, 2 * E, rows, 2 * E, D, dt, dt, false, s)); }
         // conv1d + SiLU, causal and anti-causal from one read of x (fused with x_proj of both directions when possible)
-        const bool convx = e->convx && ((int64_t)rows + 8) * E * esz < ((int64_t)1 << 31);      // the fused kernel's 32-bit offsets
+        const bool convx = e->convx && ((int64_t)rows + 16) * E * esz < ((int64_t)1 << 32);      // the fused kernel's 32-bit offsets
         if (convx) {
             ProfScope ps(e, PCAD_K_CONV, s);
             HIP_TRY(launch_convx(c.w.xz, W.convw, W.dir[0].Wx, c.w.xc[0], c.w.dtl[0], c.w.bc[0], W.dir[1].Wx, c.w.xc[1],
@@ -458,7 +458,7 @@ static int forward_impl(pcad_handle h, const int32_t* ids, int B, int L, const i
         for (int d = 0; d < 2; ++d) {
             const DirWeights& dw = W.dir[d];
             // x_proj -> dt_low [rows, Rp] (model dtype, zero padded) and B_t | C_t [rows, 32] (fp32 side output)
-            if (!(e->convx && ((int64_t)rows + 8) * E * esz < ((int64_t)1 << 31))) { ProfScope ps(e, PCAD_K_GEMM_X, s);
+            if (!(e->convx && ((int64_t)rows + 16) * E * esz < ((int64_t)1 << 32))) { ProfScope ps(e, PCAD_K_GEMM_X, s);
             HIP_TRY(launch_gemm_nt_split(c.w.xc[d], E, dw.Wx, E, c.w.dtl[d], Rp, c.w.bc[d], 2 * N, Rp, rows, XP, E, dt, s,
                                          e->blocked)); }
             // dt_proj (on MFMA inside the scan) + bias + softplus + recurrence + D skip + SiLU(z) gate

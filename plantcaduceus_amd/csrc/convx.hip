@@ -53,7 +53,7 @@ __device__ __forceinline__ void cx_glds16(const char* gsrc, char* lds_wave_base)
 
 // LDS-DMA through a buffer descriptor: descriptor base + per-lane 32-bit offset + wave-uniform 32-bit offset
 __device__ __forceinline__ void cx_blds16(const void* base, uint32_t voff, uint32_t soff, char* lds_wave_base) {
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(__builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0x7ffffffc, 0x00020000),
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(__builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)0xfffffffcu, 0x00020000),
                                              (__attribute__((address_space(3))) void*)lds_wave_base, 16, (int)voff, (int)soff, 0, 0);
 }
 
@@ -377,7 +377,7 @@ hipError_t launch_convx(const void* x, const float* convw, const void* Wx0, void
     if (S <= 0 || L <= 0) return hipSuccess;
     const int esz = dt == BF16 ? 2 : 4;
     if ((E * esz) % CX_ROWB) return hipErrorInvalidValue;
-    if (((int64_t)S * L + 8) * E * esz >= ((int64_t)1 << 31)) return hipErrorInvalidValue;     // 32-bit in-tensor offsets
+    if (((int64_t)S * L + 16) * E * esz >= ((int64_t)1 << 32)) return hipErrorInvalidValue;    // unsigned 32-bit in-tensor offsets
     ConvxDir d0{Wx0, xc0, dtl0, bc0}, d1{Wx1, xc1, dtl1, bc1};
     const int tiles = S * ((L + CX_ROWS - 1) / CX_ROWS);
     static bool attr_b = false, attr_f = false;

@@ -779,7 +779,7 @@ constexpr int GEMMQ_THREADS = 256;
 // LDS-DMA through a buffer descriptor: address = descriptor base + voff (per lane) + soff (wave-uniform), 16 B per lane
 // to lds_wave_base + lane * 16.  (Device-only builtins live in __device__ helpers so the host pass still emits the stub.)
 __device__ __forceinline__ void blds16(const void* base, uint32_t voff, uint32_t soff, char* lds_wave_base) {
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(__builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0x7ffffffc, 0x00020000),
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(__builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)0xfffffffcu, 0x00020000),
                                              (__attribute__((address_space(3))) void*)lds_wave_base, 16, (int)voff, (int)soff, 0, 1);   // aux 1 = sc0: +2-3 % on in_proj in a same-box A/B (nt: -8 %)
 }
 
@@ -1126,8 +1126,8 @@ static hipError_t launch_gemm256_t(const void* A, int64_t lda, const void* W, in
     dim3 grid((unsigned)persistent_grid(tiles_m * tiles_n)), block(GEMM_THREADS);
     static const bool quad = getenv("PCAD_GEMM_NOQUAD") == nullptr;   // developer knob: the 8-wave kernels for A/B runs
     const int64_t esz_ = (int64_t)sizeof(T);
-    if (quad && M % BM2 == 0 && N % BN2 == 0 && (C2 == nullptr || nsplit % 64 == 0) && M * lda * esz_ < ((int64_t)1 << 31) &&
-        (int64_t)N * ldw * esz_ < ((int64_t)1 << 31)) {
+    if (quad && M % BM2 == 0 && N % BN2 == 0 && (C2 == nullptr || nsplit % 64 == 0) && M * lda * esz_ < ((int64_t)1 << 32) - 65536 &&
+        (int64_t)N * ldw * esz_ < ((int64_t)1 << 32) - 65536) {     // unsigned 32-bit buffer offsets
         auto kq = gemm256q_kernel<T, T>;
         static bool attr_q = false;
         if (!attr_q) {

@@ -355,7 +355,7 @@ hipError_t launch_scan(const void* u, const void* z, int64_t ldz, const void* de
     if (S <= 0 || L <= 0) return hipSuccess;
     if (E % 64) return hipErrorInvalidValue;
     if ((int64_t)L * (ldz > E ? ldz : E) * 4 >= ((int64_t)1 << 31)) return hipErrorInvalidValue;   // 32-bit in-strand offsets
-    if (uyb && (((int64_t)S * L + 7) / 8 * 8 * E * 4 >= ((int64_t)1 << 32) || (E * (dt == BF16 ? 2 : 4)) % 128))
+    if (uyb && (((int64_t)S * L + 7) / 8 * 8 * E * (dt == BF16 ? 2 : 4) >= ((int64_t)1 << 32) || (E * (dt == BF16 ? 2 : 4)) % 128))
         return hipErrorInvalidValue;     // blocked layout: 32-bit whole-tensor offsets
     const bool fused = delta == nullptr;
     if (fused && (!dt_low || !Wdt || Rp <= 0 || Rp % 64)) return hipErrorInvalidValue;

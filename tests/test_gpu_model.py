@@ -148,3 +148,28 @@ def test_long_window_8192():
     hid = out.hidden_states[-1].cpu().numpy()
     assert np.abs(hid - hid_ref[:, sel]).max() / np.abs(hid_ref).max() < 1e-4
     assert (lg[:, 0, 3:7].argmax(-1) == lg_ref[:, 4095, 3:7].argmax(-1)).all()
+
+
+def test_maximum_chunk_bit_identical_to_small_chunks(monkeypatch):
+    """maximum sizes: at the l32 width one default chunk is 512 windows = 524 288 token-rows, whose x / xc / y tensors are
+    2 GiB each, so the kernels' unsigned 32-bit byte offsets run past 2^31.  Rows are independent, so the result must be
+    bit-identical to the same batch walked in 64-window chunks."""
+    cfg = make_config("l32", n_layer=1)
+    sd = synthetic_state_dict(cfg, seed=8)
+    ids = rand_ids(520, 512, 77, mask=255)           # 520 -> chunks of 260 + 260 by default; rows of the 2nd half past 2^31 B / 2
+    pos = [255, 0, 511]
+    monkeypatch.delenv("PCAD_CHUNK_SEQS", raising=False)
+    big = build(cfg, sd, torch.bfloat16)
+    a = big(input_ids=ids[:512].to(DEV), output_hidden_states=True, positions=pos)       # ONE chunk of 512 windows
+    b = big(input_ids=ids.to(DEV), output_hidden_states=True, positions=pos)
+    la, ha = a.logits.cpu(), a.hidden_states[-1].float().cpu()
+    lb, hb = b.logits.cpu(), b.hidden_states[-1].float().cpu()
+    del big, a, b
+    torch.cuda.empty_cache()
+    monkeypatch.setenv("PCAD_CHUNK_SEQS", "64")
+    small = build(cfg, sd, torch.bfloat16)
+    c = small(input_ids=ids.to(DEV), output_hidden_states=True, positions=pos)
+    lc, hc = c.logits.cpu(), c.hidden_states[-1].float().cpu()
+    assert torch.isfinite(lc).all()
+    assert torch.equal(la, lc[:512]) and torch.equal(ha, hc[:512])
+    assert torch.equal(lb, lc) and torch.equal(hb, hc)
