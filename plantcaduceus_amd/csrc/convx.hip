@@ -52,8 +52,9 @@ __device__ __forceinline__ void cx_glds16(const char* gsrc, char* lds_wave_base)
 }
 
 // LDS-DMA through a buffer descriptor: descriptor base + per-lane 32-bit offset + wave-uniform 32-bit offset
-__device__ __forceinline__ void cx_blds16(const void* base, uint32_t voff, uint32_t soff, char* lds_wave_base) {
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(__builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)0xfffffffcu, 0x00020000),
+__device__ __forceinline__ void cx_blds16(const void* base, uint32_t voff, uint32_t soff, char* lds_wave_base,
+                                          uint32_t num_records = 0xfffffffcu) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(__builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)num_records, 0x00020000),
                                              (__attribute__((address_space(3))) void*)lds_wave_base, 16, (int)voff, (int)soff, 0, 0);
 }
 
@@ -114,7 +115,10 @@ struct ConvxDir {
 };
 
 // convw: per K-tile CX_CW_BYTES of fp32 [dir][tap 0..3, bias][KC]  (packed at bind time by launch_pack_convw)
-template <typename T>
+// ZFILL (L % 8 == 0: a strand is a contiguous byte range of the blocked tensor): the raw tile is fetched through a
+// descriptor that covers exactly the strand, so the halo rows outside [0, L) are out of range and arrive as zeros (a
+// negative strand-relative offset wraps to a huge unsigned one) - the conv pass then needs no per-element masking.
+template <typename T, bool ZFILL>
 __global__ __launch_bounds__(CX_THREADS, 2) void convx_kernel(const T* __restrict__ x, const float* __restrict__ convw,
                                                               ConvxDir d0, ConvxDir d1, int S, int L, int E) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -135,12 +139,23 @@ __global__ __launch_bounds__(CX_THREADS, 2) void convx_kernel(const T* __restric
     // raw: 17 groups of 8 rows; wave w stages groups w, w + 8 and (all waves, redundantly) group 16
     uint32_t raw_src[3];                                          // 32-bit offsets (launcher checks the tensor sizes)
     int raw_dst[3];
+    const char* raw_base = reinterpret_cast<const char*>(x);
+    uint32_t raw_records = 0xfffffffcu;
+    if (ZFILL) {                                                  // strand-relative offsets, descriptor = the strand
+        raw_base += (row0 >> 3) * pieces * 1024;
+        raw_records = (uint32_t)((int64_t)(L >> 3) * pieces * 1024);
+    }
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
         const int grp = i < 2 ? wave + 8 * i : 16;
         const int q = grp * 8 + (lane >> 3);                      // raw row index: t = t0 - 3 + q
-        const int t = min(max(t0 - 3 + q, 0), L - 1);             // clamped address; masked in the conv
-        raw_src[i] = (uint32_t)(blocked_off(row0 + t, 0, pieces) + ((lane & 7) << 4));
+        if (ZFILL) {
+            const int t = t0 - 3 + q;                             // t < 0 wraps out of range, t >= L is out of range
+            raw_src[i] = (uint32_t)((int64_t)(t >> 3) * pieces * 1024 + ((t & 7) << 7) + ((lane & 7) << 4));
+        } else {
+            const int t = min(max(t0 - 3 + q, 0), L - 1);         // clamped address; masked in the conv
+            raw_src[i] = (uint32_t)(blocked_off(row0 + t, 0, pieces) + ((lane & 7) << 4));
+        }
         raw_dst[i] = grp * 8 * CX_ROWB;
     }
     // Wx slabs: per direction 96 rows = 12 groups of 8; 24 groups over 8 waves = 3 each
@@ -161,7 +176,7 @@ __global__ __launch_bounds__(CX_THREADS, 2) void convx_kernel(const T* __restric
     auto stage_raw = [&](int kt) {
         char* base = smem + (kt % CX_NRAW) * CX_RAW_BYTES;
 #pragma unroll
-        for (int i = 0; i < 3; ++i) cx_blds16(x, raw_src[i], (uint32_t)kt * 1024u, base + raw_dst[i]);
+        for (int i = 0; i < 3; ++i) cx_blds16(raw_base, raw_src[i], (uint32_t)kt * 1024u, base + raw_dst[i], raw_records);
     };
     auto stage_w = [&](int kt) {
         char* wb = smem + CX_OFF_W + (kt & 1) * 2 * CX_W_BYTES;
@@ -260,8 +275,10 @@ __global__ __launch_bounds__(CX_THREADS, 2) void convx_kernel(const T* __restric
                 const int q = qbase + j;
                 const int t = t0 - 3 + q;
                 u32x2 r = *reinterpret_cast<const u32x2*>(raw + q * CX_ROWB + c8 * 16 + h * 8);
-                const unsigned keep = 0u - (unsigned)((unsigned)t < (unsigned)L);   // zero padding at the sequence ends,
-                r &= u32x2{keep, keep};                                              // branch-free (loads stay batched)
+                if (!ZFILL) {
+                    const unsigned keep = 0u - (unsigned)((unsigned)t < (unsigned)L);   // zero padding at the sequence ends,
+                    r &= u32x2{keep, keep};                                              // branch-free (loads stay batched)
+                }
                 float w1[HC];
                 Chunk<T>::unpack_half(r, w1);
 #pragma unroll
@@ -380,16 +397,17 @@ hipError_t launch_convx(const void* x, const float* convw, const void* Wx0, void
     if (((int64_t)S * L + 16) * E * esz >= ((int64_t)1 << 32)) return hipErrorInvalidValue;    // unsigned 32-bit in-tensor offsets
     ConvxDir d0{Wx0, xc0, dtl0, bc0}, d1{Wx1, xc1, dtl1, bc1};
     const int tiles = S * ((L + CX_ROWS - 1) / CX_ROWS);
-    static bool attr_b = false, attr_f = false;
-    if (dt == BF16) {
-        auto k = convx_kernel<bf16_t>;
-        if (!attr_b) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, CX_LDS); attr_b = true; }
-        hipLaunchKernelGGL(k, dim3((unsigned)tiles), dim3(CX_THREADS), CX_LDS, s, (const bf16_t*)x, convw, d0, d1, S, L, E);
-    } else {
-        auto k = convx_kernel<float>;
-        if (!attr_f) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, CX_LDS); attr_f = true; }
-        hipLaunchKernelGGL(k, dim3((unsigned)tiles), dim3(CX_THREADS), CX_LDS, s, (const float*)x, convw, d0, d1, S, L, E);
-    }
+    const bool zfill = L % 8 == 0;
+#define PCAD_CONVX(T, Z)                                                                                              \
+    do {                                                                                                                \
+        auto k = convx_kernel<T, Z>;                                                                                    \
+        static bool attr = false;                                                                                       \
+        if (!attr) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, CX_LDS); attr = true; } \
+        hipLaunchKernelGGL(k, dim3((unsigned)tiles), dim3(CX_THREADS), CX_LDS, s, (const T*)x, convw, d0, d1, S, L, E);  \
+    } while (0)
+    if (dt == BF16) { if (zfill) PCAD_CONVX(bf16_t, true); else PCAD_CONVX(bf16_t, false); }
+    else { if (zfill) PCAD_CONVX(float, true); else PCAD_CONVX(float, false); }
+#undef PCAD_CONVX
     return hipGetLastError();
 }
 
