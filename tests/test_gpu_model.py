@@ -173,3 +173,19 @@ def test_maximum_chunk_bit_identical_to_small_chunks(monkeypatch):
     assert torch.isfinite(lc).all()
     assert torch.equal(la, lc[:512]) and torch.equal(ha, hc[:512])
     assert torch.equal(lb, lc) and torch.equal(hb, hc)
+
+
+def test_repeated_forward_is_bit_identical():
+    """race screen for the counted-vmcnt / one-barrier pipelines (4-wave GEMM, conv+x_proj, scan): the same batch run
+    six times at the l32 width must give the same bits every time."""
+    cfg = make_config("l32", n_layer=2)
+    m = build(cfg, synthetic_state_dict(cfg, seed=9), torch.bfloat16)
+    ids = rand_ids(192, 512, 5, mask=255).to(DEV)
+    ref = None
+    for _ in range(6):
+        out = m(input_ids=ids, output_hidden_states=True, positions=[255, 3, 508])
+        cur = (out.logits.clone(), out.hidden_states[-1].clone())
+        if ref is None:
+            ref = cur
+        else:
+            assert torch.equal(cur[0], ref[0]) and torch.equal(cur[1], ref[1])
