@@ -173,18 +173,18 @@ __global__ __launch_bounds__(CX_THREADS, 2) void convx_kernel(const T* __restric
     const uint32_t cw_src = (uint32_t)((wave % CW_PIECES) * 1024 + lane * 16);
     const int cw_dst = (wave % CW_PIECES) * 1024;
 
-    auto stage_raw = [&](int kt) {
-        char* base = smem + (kt % CX_NRAW) * CX_RAW_BYTES;
+    auto stage_raw = [&](int kt, int par) __attribute__((always_inline)) {          // par = kt & 1, a compile-time constant at every call site
+        char* base = smem + par * CX_RAW_BYTES;
 #pragma unroll
         for (int i = 0; i < 3; ++i) cx_blds16(raw_base, raw_src[i], (uint32_t)kt * 1024u, base + raw_dst[i], raw_records);
     };
-    auto stage_w = [&](int kt) {
-        char* wb = smem + CX_OFF_W + (kt & 1) * 2 * CX_W_BYTES;
+    auto stage_w = [&](int kt, int par) __attribute__((always_inline)) {
+        char* wb = smem + CX_OFF_W + par * 2 * CX_W_BYTES;
 #pragma unroll
         for (int i = 0; i < 3; ++i) cx_blds16(w_dir[i] ? d1.Wx : d0.Wx, w_src[i], (uint32_t)kt * (uint32_t)CX_ROWB, wb + w_dst[i]);
     };
-    auto stage_taps = [&](int kt) {
-        cx_blds16(convw, cw_src, (uint32_t)kt * (uint32_t)CX_CW_BYTES, smem + CX_OFF_CW + (kt & 1) * CX_CW_BYTES + cw_dst);
+    auto stage_taps = [&](int kt, int par) __attribute__((always_inline)) {
+        cx_blds16(convw, cw_src, (uint32_t)kt * (uint32_t)CX_CW_BYTES, smem + CX_OFF_CW + par * CX_CW_BYTES + cw_dst);
     };
 
     // ---- a wave works on ONE direction in both passes: waves 0-3 causal, 4-7 anti-causal (wave-uniform) ---------
@@ -215,9 +215,9 @@ __global__ __launch_bounds__(CX_THREADS, 2) void convx_kernel(const T* __restric
     // and the MFMAs + xc copy-out of K-tile it-1 (matrix pipe + LDS, reads conv stage (it-1)&1) in the same barrier
     // interval, so the two pipes overlap instead of alternating.  DMAs issued at the start of iteration it: Wx(it),
     // taps(it+1), raw(it+1), each into the slot whose last reader finished in iteration it-1.
-    auto mfma_half = [&](int mt, int kk) {
-        const char* at = smem + CX_OFF_C + (mt & 1) * 2 * CX_TILE_BYTES + cdir * CX_TILE_BYTES;
-        const char* wb = smem + CX_OFF_W + (mt & 1) * 2 * CX_W_BYTES + cdir * CX_W_BYTES;
+    auto mfma_half = [&](int mpar, int kk) __attribute__((always_inline)) {          // mpar: parity of the K-tile being multiplied
+        const char* at = smem + CX_OFF_C + mpar * 2 * CX_TILE_BYTES + cdir * CX_TILE_BYTES;
+        const char* wb = smem + CX_OFF_W + mpar * 2 * CX_W_BYTES + cdir * CX_W_BYTES;
         u32x4 af[2], wfr[6];
 #pragma unroll
         for (int i = 0; i < 2; ++i) af[i] = *reinterpret_cast<const u32x4*>(at + (mq * 32 + i * 16) * CX_ROWB + frag_lo[kk]);
@@ -235,12 +235,12 @@ __global__ __launch_bounds__(CX_THREADS, 2) void convx_kernel(const T* __restric
     int c_lds[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) c_lds[i] = (cr0 + i * 8) * CX_ROWB + (((lane & 7) ^ cx_key(cr0 + i * 8)) << 4);
-    auto copy_out = [&](int mt) {
+    auto copy_out = [&](int mt, int mpar) __attribute__((always_inline)) {
 #pragma unroll
         for (int d = 0; d < 2; ++d) {
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                const u32x4 v = *reinterpret_cast<const u32x4*>(smem + CX_OFF_C + (mt & 1) * 2 * CX_TILE_BYTES + d * CX_TILE_BYTES +
+                const u32x4 v = *reinterpret_cast<const u32x4*>(smem + CX_OFF_C + mpar * 2 * CX_TILE_BYTES + d * CX_TILE_BYTES +
                                                                c_lds[i]);
                 if (t0 + cr0 + i * 8 < L) {
                     char* dst = reinterpret_cast<char*>(d ? xcr : xcf) + (xc_lo + (uint32_t)i * xc_blk + (uint32_t)mt * 1024u);
@@ -249,18 +249,18 @@ __global__ __launch_bounds__(CX_THREADS, 2) void convx_kernel(const T* __restric
             }
         }
     };
-    auto conv_pass = [&](int kt, auto rev_tag, bool with_mfma) {
+    auto conv_pass = [&](int kt, int par, auto rev_tag, bool with_mfma) __attribute__((always_inline)) {
         constexpr bool REVC = decltype(rev_tag)::value;       // static window indices (no dynamic register indexing)
-        const char* raw = smem + (kt % CX_NRAW) * CX_RAW_BYTES;
-        const float* cw = reinterpret_cast<const float*>(smem + CX_OFF_CW + (kt & 1) * CX_CW_BYTES) + (REVC ? 5 * KC : 0) + c8 * CPC;
-        if (with_mfma) mfma_half(kt - 1, 0);
-        char* ct = smem + CX_OFF_C + (kt & 1) * 2 * CX_TILE_BYTES + (REVC ? CX_TILE_BYTES : 0);
+        const char* raw = smem + par * CX_RAW_BYTES;
+        const float* cw = reinterpret_cast<const float*>(smem + CX_OFF_CW + par * CX_CW_BYTES) + (REVC ? 5 * KC : 0) + c8 * CPC;
+        if (with_mfma) mfma_half(1 - par, 0);
+        char* ct = smem + CX_OFF_C + par * 2 * CX_TILE_BYTES + (REVC ? CX_TILE_BYTES : 0);
         const f32x2_t nl2e = {-kLog2e, -kLog2e}, one = {1.0f, 1.0f};
         // The 16-byte chunk is convolved in two halves of HC channels (8-byte LDS accesses: same LDS cycles, half the live
         // registers: a spill here costs far more than its load - a scratch reload shares vmcnt with the LDS-DMAs in flight
         // and drains them).  Channel pairs go through the packed fp32 pipe: taps, bias and window as (e, e+1) pairs.
         constexpr int HC = CPC / 2;
-        auto conv_half = [&](int h) {
+        auto conv_half = [&](int h) __attribute__((always_inline)) {
             f32x2_t wt[4][HC / 2], bias[HC / 2];
 #pragma unroll
             for (int k = 0; k < 5; ++k)
@@ -303,31 +303,38 @@ __global__ __launch_bounds__(CX_THREADS, 2) void convx_kernel(const T* __restric
         };
         conv_half(0);
         __builtin_amdgcn_sched_barrier(0);
-        if (with_mfma) mfma_half(kt - 1, 1);
+        if (with_mfma) mfma_half(1 - par, 1);
         conv_half(1);
-        if (with_mfma) copy_out(kt - 1);
+        if (with_mfma) copy_out(kt - 1, 1 - par);
     };
 
     // prologue: taps(0), raw(0)
-    stage_taps(0);
-    stage_raw(0);
-    for (int it = 0; it <= nkt; ++it) {
+    stage_taps(0, 0);
+    stage_raw(0, 0);
+    // the loop is unrolled by two so that every LDS stage offset is a compile-time constant (addresses = a lane register
+    // + an immediate instead of per-access SALU/VALU address arithmetic; the kernel is instruction-issue bound)
+    auto iteration = [&](int it, auto par_tag) __attribute__((always_inline)) {
+        constexpr int P = decltype(par_tag)::value;               // it & 1
         // everything issued in the previous iteration (Wx(it-1), taps(it), raw(it)) must have landed; younger than those are
         // only that iteration's 4 xc stores (vmcnt retires in issue order, loads and stores alike)
         if (full_tile && it >= 2) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        if (it < nkt) stage_w(it);
-        if (it + 1 < nkt) { stage_taps(it + 1); stage_raw(it + 1); }
+        if (it < nkt) stage_w(it, P);
+        if (it + 1 < nkt) { stage_taps(it + 1, 1 - P); stage_raw(it + 1, 1 - P); }
         if (it < nkt) {
-            if (cdir) { if (it > 0) conv_pass(it, std::true_type{}, true); else conv_pass(it, std::true_type{}, false); }
-            else { if (it > 0) conv_pass(it, std::false_type{}, true); else conv_pass(it, std::false_type{}, false); }
+            if (cdir) conv_pass(it, P, std::true_type{}, it > 0);
+            else conv_pass(it, P, std::false_type{}, it > 0);
         } else {
-            mfma_half(it - 1, 0);
-            mfma_half(it - 1, 1);
-            copy_out(it - 1);
+            mfma_half(1 - P, 0);
+            mfma_half(1 - P, 1);
+            copy_out(it - 1, 1 - P);
         }
+    };
+    for (int it = 0; it <= nkt; it += 2) {
+        iteration(it, std::integral_constant<int, 0>{});
+        if (it + 1 <= nkt) iteration(it + 1, std::integral_constant<int, 1>{});
     }
 
     // ---- epilogue: lane (li = row, lg): fragment j -> columns j*16 + lg*4 .. +3 --------------------------------
