@@ -164,3 +164,31 @@ def test_plantcad2_sv_effect_and_motif_tasks_through_hip(golden_dir, tmp_path):
     a = pe.motif_acc(d2, m, tok, DEV, mask_idx=(30, 31, 32), motif_len=3, batch_size=4)
     b = pe.motif_acc(d2, om, tok, "cpu", mask_idx=(30, 31, 32), motif_len=3, batch_size=4)
     assert a == b
+
+
+def test_cli_end_to_end_from_snapshot_on_gpu(golden_dir, tmp_path):
+    """the reference's command line on the GPU, nothing mocked: a snapshot directory (config.json + model.safetensors under
+    the reference's key names) -> `zero_shot.main` (-input-table, -device cuda:0) -> TSV; scores against the oracle run on the
+    same checkpoint.  Also the embedding script's extract step on the model `load_model_and_tokenizer` returns."""
+    import oracle.caduceus_oracle as O
+    from plantcaduceus_amd.checkpoint import make_synthetic_checkpoint
+    d = str(tmp_path / "snap")
+    cfg, sd = make_synthetic_checkpoint(d, "x", seed=13, stress=False, d_model=128, n_layer=2)
+    src = pd.read_csv(os.path.join(golden_dir, "example_snp.tsv"), delimiter="\t").iloc[:24]
+    inp, out = tmp_path / "in.tsv", tmp_path / "out.tsv"
+    src.to_csv(inp, sep="\t", index=False)
+    zero_shot.main(["-input-table", str(inp), "-output", str(out), "-model", d, "-device", DEV, "-batchSize", "7"])
+    res = pd.read_csv(out, delimiter="\t")
+    ok = (src["ref"].isin(list("ACGT")) & src["alt"].isin(list("ACGT"))).to_numpy()
+    assert len(res) == int(ok.sum())
+    om = O.OracleForMaskedLM(O.params_from_state_dict(sd, cfg))
+    tok = CaduceusTokenizer()
+    ids = torch.from_numpy(zero_shot.tokenize_masked(src["sequences"].tolist(), tok, 255).astype(np.int64))
+    p = torch.softmax(om(input_ids=ids).logits[:, 255, 3:7].float(), -1).numpy()
+    want = np.array([np.log(p[i, "ACGT".index(a)] / p[i, "ACGT".index(r)])
+                     for i, (r, a) in enumerate(zip(src["ref"], src["alt"])) if ok[i]])
+    # the dtype policy picks bf16 on this GPU (get_optimal_dtype): bf16 tolerance on a log-ratio of probabilities
+    np.testing.assert_allclose(res["zeroShotScore"].to_numpy(), want, rtol=0, atol=5e-2)
+    model, tok2 = zero_shot.load_model_and_tokenizer(d, DEV)
+    emb = embeddings.extract_embeddings(model, src["sequences"].tolist()[:5], DEV, 255, tokenizer=tok2, batch_size=4)
+    assert emb.shape == (5, cfg.d_model) and np.isfinite(emb).all()
