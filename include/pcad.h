@@ -153,6 +153,23 @@ int pcad_causal_conv1d_silu(const void* x, int64_t ldx, const float* w_fwd, cons
                             const float* w_rev, const float* b_rev, void* y_fwd, void* y_rev,
                             int S, int L, int E, int dtype, pcad_stream stream);
 
+/* The form the engine runs for the head of mamba_inner_fn — causal_conv1d_fn(x, w, b, "silu") of BOTH directions fused with
+ * BOTH `x_dbl = x_proj(conv_out)` GEMMs, x read once (one kernel instead of causal_conv1d_fwd x2 + cuBLAS x2):
+ *   x        [rows8, E] dtype in the BLOCKED layout: byte offset of (row r, byte cb of the row) =
+ *            (((r >> 3) * (E*esz/128) + (cb >> 7)) << 10) + ((r & 7) << 7) + (cb & 127); rows8 = S*L rounded up to 8;
+ *            E*esz a multiple of 128 bytes; (S*L + 16) * E * esz < 2^32
+ *   w_*, b_* fp32 [E, 4] / [E] conv taps and bias per direction (fwd: causal, rev: anti-causal on the same rows)
+ *   Wx_*     [96, E] dtype: x_proj.weight packed as rows [0, R) = dt rows, zero rows [R, 64), rows [64, 80) = B, [80, 96) = C
+ *            (dt_rank R <= 64)
+ *   scratch  device buffer of pcad_conv_xproj_scratch_bytes(E, dtype) bytes (packed taps; written by this call)
+ *   xc_*     [rows8, E] dtype, blocked: silu(conv) per direction
+ *   dtl_*    [S*L, 64] dtype: x_dbl[:, :R] zero-padded to 64;   bc_* fp32 [S*L, 32] = B_t | C_t rounded to dtype */
+size_t pcad_conv_xproj_scratch_bytes(int E, int dtype);
+int pcad_conv_xproj_bidir(const void* x, const float* w_fwd, const float* b_fwd, const float* w_rev, const float* b_rev,
+                          const void* Wx_fwd, const void* Wx_rev, void* scratch,
+                          void* xc_fwd, void* dtl_fwd, float* bc_fwd, void* xc_rev, void* dtl_rev, float* bc_rev,
+                          int S, int L, int E, int dtype, pcad_stream stream);
+
 /* selective_scan_fn(u, delta, A, B, C, D, z, delta_bias, delta_softplus=True), token-major:
  *   u, delta [S, L, E] dtype; z [S, L, ldz>=E] dtype or NULL; bc fp32 [S*L, 32] = B_t (16) | C_t (16) per token;
  *   A fp32 [E, 16] (negative real, NOT pre-scaled); Dskip, delta_bias fp32 [E];

@@ -14,8 +14,8 @@
  *
  * Parallelisation: the 2B-strand batch walks the stack layer by layer and every operator is an OpenMP
  * parallel loop (GEMM: weight-panel x row-block tiles; conv/norm: token rows; scan: strand x 16-channel
- * blocks), so even a small sample uses all host cores.  Plain blocked loops the compiler vectorises; no
- * BLAS, no intrinsics: this is a scalar-source port.
+ * blocks), so even a small sample uses all host cores.  Plain blocked loops the compiler vectorises, no
+ * intrinsics: a scalar-source port.  The projections can be routed to the host BLAS instead (oracle_set_gemm).
  */
 #include <math.h>
 #include <stdint.h>
@@ -46,6 +46,9 @@ typedef struct {
     int32_t d_model, n_layer, d_inner, dt_rank;
     float eps;
     int32_t emulate_bf16;   /* round to bf16 at the reference's tensor boundaries (model run with torch_dtype=bfloat16) */
+    int32_t ref_order;      /* 1: the reference's order of the tied out_proj — out_proj(y_fwd) and out_proj(y_rev) each
+                               computed and rounded, then summed and rounded (BiMambaWrapper "add");  0: the engine's fold
+                               out_proj(y_fwd + y_rev).  Identical in exact arithmetic. */
     int32_t complement[8];
     const float* emb;     /* [8, D] (tied LM head) */
     const float* norm_f;  /* [D] */
@@ -162,7 +165,14 @@ static void linear_micro(const float* A, int lda, const float* W, int K, float* 
         }
 }
 
+/* Optional host-BLAS hook for the four projections (oracle/c_oracle.py installs a numpy/OpenBLAS sgemm): the same
+ * forward with library GEMMs, so the reported CPU baseline is not limited by this file's plain-C GEMM loops. */
+typedef void (*oracle_gemm_fn)(const float* A, int lda, const float* W, int K, float* C, int ldc, int M, int N);
+static oracle_gemm_fn g_gemm = 0;
+void oracle_set_gemm(oracle_gemm_fn fn) { g_gemm = fn; }
+
 static void linear_nt(const float* A, int lda, const float* W, int K, float* C, int ldc, int M, int N) {
+    if (g_gemm) { g_gemm(A, lda, W, K, C, ldc, M, N); return; }
     /* one work item = MB rows x NB weight rows: the item's A block (MB*K floats) and weight panel (NB*K floats)
      * both stay in a core's L2 while its 4x4 micro-tiles are walked, so each is fetched once per item */
     enum { MB = 64, NB = 64 };
@@ -220,7 +230,7 @@ static void conv_silu(const float* xz, const float* cw, const float* cb, float* 
 /* selective scan of one direction, accumulated into y (gated by silu(z)); channel blocks of VL lanes,
  * sequential in t; parallel over (strand, channel block) */
 static void scan_dir(const float* xc, const float* delta, const float* dbl, const float* xz, const float* A,
-                     const float* dt_b, const float* Dskip, float* y, int S, int L, int E, int R, int d, int rb) {
+                     const float* dt_b, const float* Dskip, float* y, int S, int L, int E, int R, int d, int rb, int acc) {
     const int XP = R + 2 * NST;
 #pragma omp parallel for collapse(2) schedule(static)
     for (int s = 0; s < S; ++s)
@@ -253,7 +263,8 @@ static void scan_dir(const float* xc, const float* delta, const float* dbl, cons
                 for (int l = 0; l < VL; ++l) {
                     const int c = c0 + l;
                     const float g = yv[l] * silu_f(xz[t * 2 * E + E + c]);      /* each direction rounded, then summed */
-                    y[t * E + c] = rb ? rbf(y[t * E + c] + rbf(g)) : y[t * E + c] + g;
+                    if (acc) y[t * E + c] = rb ? rbf(y[t * E + c] + rbf(g)) : y[t * E + c] + g;
+                    else y[t * E + c] = rb ? rbf(g) : g;
                 }
             }
         }
@@ -269,7 +280,7 @@ int oracle_forward(const oracle_model* m, const int32_t* ids, int B, int L, floa
     const size_t rows = (size_t)S * L;
     /* the whole 2B-strand batch walks the stack layer by layer (as the HIP engine does); every operator is
      * OpenMP-parallel inside, so a small sample still uses all cores */
-    const size_t nfl = rows * ((size_t)3 * D + 2 * E + E + XP + E + E) + (size_t)E * NST;
+    const size_t nfl = rows * ((size_t)3 * D + 2 * E + E + XP + E + E + (m->ref_order ? D : 0)) + (size_t)E * NST;
     float* buf = (float*)malloc(sizeof(float) * nfl);
     int32_t* tok = (int32_t*)malloc(sizeof(int32_t) * rows);
     if (!buf || !tok) { free(buf); free(tok); return -1; }
@@ -282,6 +293,7 @@ int oracle_forward(const oracle_model* m, const int32_t* ids, int B, int L, floa
     float* delta = dbl + rows * XP;
     float* y = delta + rows * E;
     float* A = y + rows * E;
+    float* h2 = A + (size_t)E * NST;   /* ref_order only: out_proj of the reverse direction */
 
     for (int s = 0; s < S; ++s)
         for (int t = 0; t < L; ++t)
@@ -307,9 +319,19 @@ int oracle_forward(const oracle_model* m, const int32_t* ids, int B, int L, floa
             round_rows(delta, rows * E, rb);
 #pragma omp parallel for schedule(static)
             for (int i = 0; i < E * NST; ++i) A[i] = -expf(ly->A_log[d][i]);
-            scan_dir(xc, delta, dbl, xz, A, ly->dt_b[d], ly->Dskip[d], y, S, L, E, R, d, rb);
+            scan_dir(xc, delta, dbl, xz, A, ly->dt_b[d], ly->Dskip[d], y, S, L, E, R, d, rb, !m->ref_order);
+            if (m->ref_order) {      /* each Mamba call ends in its own (tied) out_proj, output stored in the model dtype */
+                float* o = d == 0 ? h : h2;
+                linear_nt(y, E, ly->out_proj, E, o, D, (int)rows, D);
+                round_rows(o, rows * D, rb);
+            }
         }
-        linear_nt(y, E, ly->out_proj, E, h, D, (int)rows, D);        /* tied out_proj folded, as the engine does */
+        if (m->ref_order) {          /* BiMambaWrapper "add": out_fwd + out_rev */
+#pragma omp parallel for schedule(static)
+            for (int64_t i = 0; i < (int64_t)(rows * D); ++i) h[i] += h2[i];
+        } else {
+            linear_nt(y, E, ly->out_proj, E, h, D, (int)rows, D);    /* tied out_proj folded, as the engine does */
+        }
         round_rows(h, rows * D, rb);
     }
     float* Hall = u;   /* final normalised hidden [S, L, D] */

@@ -40,7 +40,7 @@ class OracleLayer(C.Structure):
 
 class OracleModel(C.Structure):
     _fields_ = [("d_model", C.c_int32), ("n_layer", C.c_int32), ("d_inner", C.c_int32), ("dt_rank", C.c_int32),
-                ("eps", C.c_float), ("emulate_bf16", C.c_int32), ("complement", C.c_int32 * 8), ("emb", FP), ("norm_f", FP),
+                ("eps", C.c_float), ("emulate_bf16", C.c_int32), ("ref_order", C.c_int32), ("complement", C.c_int32 * 8), ("emb", FP), ("norm_f", FP),
                 ("layers", C.POINTER(OracleLayer))]
 
 
@@ -57,7 +57,21 @@ def _lib():
     lib.oracle_forward.restype = C.c_int
     lib.oracle_forward.argtypes = [C.POINTER(OracleModel), C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
     lib.oracle_num_threads.restype = C.c_int
+    lib.oracle_set_gemm.restype = None
+    lib.oracle_set_gemm.argtypes = [C.c_void_p]
     return lib
+
+
+GEMM_FN = C.CFUNCTYPE(None, FP, C.c_int, FP, C.c_int, FP, C.c_int, C.c_int, C.c_int)
+
+
+@GEMM_FN
+def _blas_gemm(A, lda, W, K, Cp, ldc, M, N):
+    """C[M, N] = A[M, :K] . W[N, K]^T through numpy (the host's BLAS sgemm, all cores)."""
+    a = np.ctypeslib.as_array(A, shape=(M, lda))[:, :K]
+    w = np.ctypeslib.as_array(W, shape=(N, K))
+    c = np.ctypeslib.as_array(Cp, shape=(M, ldc))[:, :N]
+    np.matmul(a, w.T, out=c)
 
 
 class COracle:
@@ -65,11 +79,15 @@ class COracle:
     emulating from_pretrained(torch_dtype=...); arithmetic is always fp32).  emulate_bf16=True additionally rounds
     to bf16 at the tensor boundaries where the reference's bf16 model stores a bf16 tensor (u, xz, conv out, x_dbl,
     delta, each direction's gated scan output and their sum, out_proj out, hidden, logits) — the engine's order,
-    i.e. caduceus_oracle.forward_strands(rnd=round_bf16, tie_fold=True)."""
+    i.e. caduceus_oracle.forward_strands(rnd=round_bf16, tie_fold=True).  ref_order=True keeps the reference's order of
+    the tied out_proj instead (each direction projected and rounded, then summed: forward_strands(tie_fold=False)); in
+    both orders each direction's scan output is gated by SiLU(z) and rounded separately, as the reference's two
+    selective_scan_fn calls do."""
 
-    def __init__(self, state_dict, config, dtype=None, emulate_bf16=False):
+    def __init__(self, state_dict, config, dtype=None, emulate_bf16=False, ref_order=False, blas=False):
         import torch
         self.lib = _lib()
+        self.blas = bool(blas)     # the four projections through the host BLAS (numpy) instead of the plain-C GEMM
         self.config = config
         self._keep = []
 
@@ -100,7 +118,7 @@ class COracle:
                 ly.Dskip[d] = arr(mp + "D")
         self.model = OracleModel(
             d_model=config.d_model, n_layer=config.n_layer, d_inner=config.d_inner, dt_rank=config.dt_rank,
-            eps=config.norm_epsilon, emulate_bf16=int(bool(emulate_bf16)), complement=(C.c_int32 * 8)(*config.complement_list()[:8]),
+            eps=config.norm_epsilon, emulate_bf16=int(bool(emulate_bf16)), ref_order=int(bool(ref_order)), complement=(C.c_int32 * 8)(*config.complement_list()[:8]),
             emb=arr(pre + "embeddings.word_embeddings.embedding.weight"), norm_f=arr(pre + "norm_f.weight"),
             layers=self.layers)
 
@@ -113,9 +131,13 @@ class COracle:
         B, L = ids.shape
         logits = np.empty((B, L, 8), dtype=np.float32) if want_logits else None
         hidden = np.empty((B, L, 2 * self.config.d_model), dtype=np.float32) if want_hidden else None
-        rc = self.lib.oracle_forward(C.byref(self.model), ids.ctypes.data, B, L,
-                                     logits.ctypes.data if want_logits else None,
-                                     hidden.ctypes.data if want_hidden else None)
+        self.lib.oracle_set_gemm(C.cast(_blas_gemm, C.c_void_p) if self.blas else None)
+        try:
+            rc = self.lib.oracle_forward(C.byref(self.model), ids.ctypes.data, B, L,
+                                         logits.ctypes.data if want_logits else None,
+                                         hidden.ctypes.data if want_hidden else None)
+        finally:
+            self.lib.oracle_set_gemm(None)
         if rc != 0:
             raise MemoryError("oracle_forward failed")
         return logits, hidden

@@ -603,6 +603,32 @@ int pcad_causal_conv1d_silu(const void* x, int64_t ldx, const float* w_fwd, cons
     return PCAD_OK;
 }
 
+size_t pcad_conv_xproj_scratch_bytes(int E, int dtype) {
+    if (E <= 0 || (dtype != PCAD_F32 && dtype != PCAD_BF16) || (E * (dtype == PCAD_BF16 ? 2 : 4)) % 128) return 0;
+    return convx_packed_bytes(E, dtype);
+}
+
+int pcad_conv_xproj_bidir(const void* x, const float* w_fwd, const float* b_fwd, const float* w_rev, const float* b_rev,
+                          const void* Wx_fwd, const void* Wx_rev, void* scratch, void* xc_fwd, void* dtl_fwd,
+                          float* bc_fwd, void* xc_rev, void* dtl_rev, float* bc_rev, int S, int L, int E, int dtype,
+                          pcad_stream stream) {
+    if (!x || !w_fwd || !b_fwd || !w_rev || !b_rev || !Wx_fwd || !Wx_rev || !scratch || !xc_fwd || !dtl_fwd || !bc_fwd ||
+        !xc_rev || !dtl_rev || !bc_rev)
+        return fail(PCAD_ERR_INVALID, "pcad_conv_xproj_bidir: null argument");
+    if (dtype != PCAD_F32 && dtype != PCAD_BF16) return fail(PCAD_ERR_INVALID, "pcad_conv_xproj_bidir: bad dtype");
+    const int64_t esz = dtype == PCAD_BF16 ? 2 : 4;
+    if (S < 0 || L < 0 || E <= 0 || (E * esz) % 128)
+        return fail(PCAD_ERR_INVALID, "pcad_conv_xproj_bidir: E * elem must be a multiple of 128 bytes");
+    if (((int64_t)S * L + 16) * E * esz >= ((int64_t)1 << 32))
+        return fail(PCAD_ERR_INVALID, "pcad_conv_xproj_bidir: (S*L + 16) * E * elem must be < 2^32 (32-bit in-tensor offsets)");
+    if (S == 0 || L == 0) return PCAD_OK;
+    hipStream_t s = (hipStream_t)stream;
+    HIP_TRY(launch_pack_convw(w_fwd, b_fwd, w_rev, b_rev, (float*)scratch, E, dtype, s));
+    HIP_TRY(launch_convx(x, (const float*)scratch, Wx_fwd, xc_fwd, dtl_fwd, bc_fwd, Wx_rev, xc_rev, dtl_rev, bc_rev, S, L, E,
+                         dtype, s));
+    return PCAD_OK;
+}
+
 static int scan_args_ok(const void* u, const float* bc, const float* A, const float* Dskip, const float* delta_bias,
                         void* y, int S, int L, int E) {
     if (!u || !bc || !A || !Dskip || !delta_bias || !y) return fail(PCAD_ERR_INVALID, "pcad_selective_scan: null argument");

@@ -65,6 +65,62 @@ def causal_conv1d_bidir(x_tm, w_fwd, b_fwd, w_rev, b_rev):
     return yf, yr
 
 
+def to_blocked(x_rows: torch.Tensor) -> torch.Tensor:
+    """[rows, E] -> the engine's blocked layout [rows8/8, E*esz/128, 8, 128/esz] (include/pcad.h), rows zero-padded to 8."""
+    rows, E = x_rows.shape
+    per = 128 // x_rows.element_size()
+    if E % per:
+        raise ValueError("E * elem must be a multiple of 128 bytes")
+    rows8 = (rows + 7) // 8 * 8
+    buf = torch.zeros((rows8, E), dtype=x_rows.dtype, device=x_rows.device)
+    buf[:rows] = x_rows
+    return buf.view(rows8 // 8, 8, E // per, per).permute(0, 2, 1, 3).contiguous()
+
+
+def from_blocked(xb: torch.Tensor, rows: int) -> torch.Tensor:
+    nb, pieces, _, per = xb.shape
+    return xb.permute(0, 2, 1, 3).reshape(nb * 8, pieces * per)[:rows].contiguous()
+
+
+def conv_xproj_bidir(x_tm, w_fwd, b_fwd, w_rev, b_rev, x_proj_fwd, x_proj_rev):
+    """The engine's fused head of mamba_inner_fn, both directions from one read of x:
+        xc_d    = causal_conv1d_fn(x, w_d, b_d, "silu")        (d = rev: anti-causal on the same rows)
+        x_dbl_d = F.linear(xc_d, x_proj_d)                     (stored in the model dtype)
+    x_tm [S, L, E]; w_* [E, 4]; b_* [E]; x_proj_* [R + 32, E] with R <= 64.
+    Returns (xc_fwd, xc_rev [S, L, E], x_dbl_fwd, x_dbl_rev [S, L, R + 32]) in x's dtype."""
+    _require_gpu(x_tm, "x")
+    lib = load_library()
+    S, L, E = x_tm.shape
+    dt, dev = x_tm.dtype, x_tm.device
+    R = x_proj_fwd.shape[0] - 32
+    if not 0 < R <= 64:
+        raise ValueError("dt_rank must be in [1, 64] for the fused kernel")
+    rows = S * L
+    xb = to_blocked(x_tm.reshape(rows, E))
+
+    def pack_wx(w):
+        p = torch.zeros((96, E), dtype=dt, device=dev)
+        p[:R] = w[:R].to(dt)
+        p[64:] = w[R:].to(dt)
+        return p
+    wx = [pack_wx(x_proj_fwd), pack_wx(x_proj_rev)]
+    taps = [t.float().contiguous() for t in (w_fwd.reshape(E, -1), b_fwd, w_rev.reshape(E, -1), b_rev)]
+    scratch = torch.empty(lib.pcad_conv_xproj_scratch_bytes(E, _DT[dt]) + 256, dtype=torch.uint8, device=dev)
+    xc = [torch.zeros_like(xb) for _ in range(2)]
+    dtl = [torch.empty((rows, 64), dtype=dt, device=dev) for _ in range(2)]
+    bc = [torch.empty((rows, 32), dtype=torch.float32, device=dev) for _ in range(2)]
+    with torch.cuda.device(dev):
+        _check(lib.pcad_conv_xproj_bidir(xb.data_ptr(), taps[0].data_ptr(), taps[1].data_ptr(), taps[2].data_ptr(),
+                                         taps[3].data_ptr(), wx[0].data_ptr(), wx[1].data_ptr(),
+                                         (scratch.data_ptr() + 255) // 256 * 256,
+                                         xc[0].data_ptr(), dtl[0].data_ptr(), bc[0].data_ptr(),
+                                         xc[1].data_ptr(), dtl[1].data_ptr(), bc[1].data_ptr(),
+                                         S, L, E, _DT[dt], _stream_ptr()), "pcad_conv_xproj_bidir")
+    outs = [from_blocked(c, rows).view(S, L, E) for c in xc]
+    dbl = [torch.cat([dtl[d][:, :R], bc[d].to(dt)], dim=1).view(S, L, R + 32) for d in range(2)]
+    return outs[0], outs[1], dbl[0], dbl[1]
+
+
 def causal_conv1d_fn(x, weight, bias=None, activation=None):
     """x (B, E, L), weight (E, W=4), bias (E), activation must be "silu"."""
     if activation not in ("silu", "swish"):

@@ -1,0 +1,95 @@
+"""-m gpu: parity at the FULL depth of the BASELINE models (PlantCaduceus_l20 = 20 layers x 384, l32 = 32 layers x 1024),
+HIP path (through the HF surface / C ABI) against the C oracle port on the same seeded inputs.
+
+  fp32 model  north_star's tolerance as written: logits and hidden <= 1e-4 of the tensor max, exact 4-way argmax of the
+              a/c/g/t call on every window, over all 512 positions.
+  bf16 model  (what the reference's dtype policy selects on this GPU) against the oracle in its bf16-emulating mode in
+              BOTH operation orders — the reference's (each direction's tied out_proj computed and rounded, then summed:
+              `ref_order=True`) and the engine's (out_proj of the sum) — and against the fp32 oracle.  Tolerance on the
+              probabilities 1e-2 (32 layers of bf16 rounding-order noise; measured ~4e-3); the argmax must be exact
+              wherever the oracle's top-2 margin exceeds twice that tolerance, at least half of the windows must be that
+              confident (non-vacuous), and the fraction of ALL windows whose call equals the fp32 oracle's is printed and
+              bounded below.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle.c_oracle import COracle
+from plantcaduceus_amd.checkpoint import make_config, synthetic_state_dict
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+P = 255
+
+
+def hip_model(cfg, sd, dtype):
+    from plantcaduceus_amd.modeling_caduceus import CaduceusForMaskedLM
+    m = CaduceusForMaskedLM(cfg)
+    m.load_state_dict(sd, strict=False)
+    m.tie_weights()
+    return m.to(dtype).to(DEV)
+
+
+def windows(n, seed):
+    ids = np.random.default_rng(seed).integers(3, 7, size=(n, 512)).astype(np.int32)
+    ids[:, P] = 1
+    ids[0, 7] = 2            # an N -> [UNK]
+    return ids
+
+
+def softmax4(z):
+    p = np.exp(z - z.max(1, keepdims=True))
+    return p / p.sum(1, keepdims=True)
+
+
+@pytest.mark.parametrize("size,n", [("l20", 16), ("l32", 16)])
+def test_full_depth_fp32(size, n):
+    cfg = make_config(size)
+    sd = synthetic_state_dict(cfg, seed=21, stress=True)      # distinct fwd/rev parameters, non-unit norm weights / D
+    ids = windows(n, 5)
+    lg_ref, hid_ref = COracle(sd, cfg, blas=True).forward(ids, want_hidden=True)
+    m = hip_model(cfg, sd, torch.float32)
+    out = m(input_ids=torch.from_numpy(ids).to(DEV), output_hidden_states=True)
+    lg = out.logits.cpu().numpy()
+    hid = out.hidden_states[-1].cpu().numpy()
+    e_l = np.abs(lg - lg_ref).max() / np.abs(lg_ref).max()
+    e_h = np.abs(hid - hid_ref).max() / np.abs(hid_ref).max()
+    print(f"{size} fp32 full depth: logits rel err {e_l:.2e}, hidden rel err {e_h:.2e}")
+    assert e_l < 1e-4 and e_h < 1e-4
+    assert (lg[:, P, 3:7].argmax(-1) == lg_ref[:, P, 3:7].argmax(-1)).all()
+    # and the call at EVERY position whose oracle margin is above fp32 summation-order noise
+    z = np.sort(lg_ref[..., 3:7], -1)
+    sure = (z[..., -1] - z[..., -2]) > 1e-4 * np.abs(lg_ref).max()
+    assert sure.mean() > 0.99
+    assert (lg[..., 3:7].argmax(-1)[sure] == lg_ref[..., 3:7].argmax(-1)[sure]).all()
+
+
+@pytest.mark.parametrize("size,n", [("l20", 32), ("l32", 16)])
+def test_full_depth_bf16_both_orders(size, n):
+    cfg = make_config(size)
+    sd = synthetic_state_dict(cfg, seed=1234, stress=False)   # BASELINE configs 2/3's checkpoint
+    ids = windows(n, 0)
+    m = hip_model(cfg, sd, torch.bfloat16)
+    lg = m(input_ids=torch.from_numpy(ids).to(DEV), positions=[P]).logits[:, 0].cpu().numpy()
+    p_hip = softmax4(lg[:, 3:7])
+
+    def oracle(**kw):
+        return softmax4(COracle(sd, cfg, blas=True, **kw).forward(ids)[0][:, P, 3:7])
+    p_ref = oracle(dtype=torch.bfloat16, emulate_bf16=True, ref_order=True)     # the reference's order
+    p_eng = oracle(dtype=torch.bfloat16, emulate_bf16=True, ref_order=False)    # the engine's order
+    p_f32 = oracle()
+    d_ref, d_eng, d_f32 = (np.abs(p_hip - q).max() for q in (p_ref, p_eng, p_f32))
+    d_orders = np.abs(p_ref - p_eng).max()
+    agree = {k: float((p_hip.argmax(1) == q.argmax(1)).mean()) for k, q in (("ref", p_ref), ("eng", p_eng), ("f32", p_f32))}
+    print(f"{size} bf16 x{n}: max|dp| vs ref-order emulation {d_ref:.2e}, vs engine-order {d_eng:.2e}, vs fp32 {d_f32:.2e}; "
+          f"the two emulations differ by {d_orders:.2e}; argmax agreement {agree}")
+    TOL = 1e-2
+    assert d_ref < TOL and d_eng < TOL
+    assert d_f32 < 2 * TOL
+    for q in (p_ref, p_eng, p_f32):
+        top2 = np.sort(q, 1)[:, -2:]
+        conf = (top2[:, 1] - top2[:, 0]) > 2 * TOL
+        assert conf.sum() >= n // 2, "vacuous argmax check: too few confident windows"
+        assert (p_hip.argmax(1)[conf] == q.argmax(1)[conf]).all()
+    assert agree["f32"] >= 0.85 and agree["ref"] >= 0.85

@@ -79,17 +79,19 @@ def test_config3_l32_bf16_example_snps(golden_dir):
     # reference's tensor boundaries, fp32 arithmetic in between; 32 layers deep.  Tolerance on probabilities: a few
     # bf16 ulps of accumulated rounding-order noise; argmax where the oracle's margin exceeds it.
     from oracle.c_oracle import COracle
-    n = 4
+    n = 16
     ids = tok.encode_batch(seqs[:n], mask_index=255)
-    lg, _ = COracle(sd, cfg, dtype=torch.bfloat16, emulate_bf16=True).forward(ids)
+    lg, _ = COracle(sd, cfg, dtype=torch.bfloat16, emulate_bf16=True, ref_order=True, blas=True).forward(ids)
     z = lg[:, 255, 3:7]
     ref = np.exp(z - z.max(1, keepdims=True))
     ref /= ref.sum(1, keepdims=True)
     print("config3: max |p_hip - p_oracle(bf16-emulating)| =", np.abs(probs[:n] - ref).max())
     assert np.abs(probs[:n] - ref).max() < 1e-2
     top2 = np.sort(ref, 1)[:, -2:]
-    conf = (top2[:, 1] - top2[:, 0]) > 6e-2
+    conf = (top2[:, 1] - top2[:, 0]) > 2e-2          # twice the probability tolerance
+    assert conf.sum() >= n // 2, "vacuous argmax check"
     assert (probs[:n].argmax(1)[conf] == ref.argmax(1)[conf]).all()
+    print("argmax agreement on all %d sampled rows: %.3f" % (n, (probs[:n].argmax(1) == ref.argmax(1)).mean()))
 
 
 def test_config2_l20_bf16_batch1024():
@@ -111,16 +113,18 @@ def test_config2_l20_bf16_batch1024():
     rc = comp[ids[:, ::-1]]
     probs_rc = zero_shot.extract_logits(m, np.ascontiguousarray(rc), DEV, 511 - 255, tok, batch_size=1024)[:, ::-1]
     assert np.abs(probs_rc - probs).max() < 2e-2
-    n = 8
-    lg, _ = COracle(sd, cfg, dtype=torch.bfloat16, emulate_bf16=True).forward(ids[:n])
+    n = 32
+    lg, _ = COracle(sd, cfg, dtype=torch.bfloat16, emulate_bf16=True, ref_order=True, blas=True).forward(ids[:n])
     z = lg[:, 255, 3:7]
     ref = np.exp(z - z.max(1, keepdims=True))
     ref /= ref.sum(1, keepdims=True)
     print("config2: max |p_hip - p_oracle(bf16-emulating)| =", np.abs(probs[:n] - ref).max())
     assert np.abs(probs[:n] - ref).max() < 1e-2
     top2 = np.sort(ref, 1)[:, -2:]
-    conf = (top2[:, 1] - top2[:, 0]) > 6e-2
+    conf = (top2[:, 1] - top2[:, 0]) > 2e-2          # twice the probability tolerance
+    assert conf.sum() >= n // 2, "vacuous argmax check"
     assert (probs[:n].argmax(1)[conf] == ref.argmax(1)[conf]).all()
+    print("argmax agreement on all %d sampled rows: %.3f" % (n, (probs[:n].argmax(1) == ref.argmax(1)).mean()))
 
 
 def test_plantcad2_helpers_through_hip(golden_dir):

@@ -69,6 +69,37 @@ def test_causal_conv1d_fp32(ops, L):
     assert relerr(yr.transpose(1, 2), ref_rev) < 1e-5
 
 
+@pytest.mark.parametrize("S,L,E,R,dtype", [(3, 24, 128, 8, torch.float32), (2, 512, 768, 24, torch.float32),
+                                           (2, 203, 256, 16, torch.float32), (1, 1, 128, 8, torch.float32),
+                                           (2, 5, 128, 8, torch.float32), (4, 512, 2048, 64, torch.bfloat16),
+                                           (3, 77, 768, 24, torch.bfloat16), (2, 133, 1536, 48, torch.float32)])
+def test_conv_xproj_fused(ops, S, L, E, R, dtype):
+    """pcad_conv_xproj_bidir — the kernel the engine actually runs for conv1d+SiLU and x_proj (convx.hip): both directions
+    against causal_conv1d_fn + einsum of the oracle (mamba_inner's head).  fp32: 1e-5 (conv) / 3e-5 (x_dbl, K = E sums);
+    bf16: one bf16 ulp on xc, x_dbl vs the oracle fed the kernel's own bf16 xc (isolates the GEMM) 2^-7."""
+    g = torch.Generator().manual_seed(S * 1000 + L)
+    x = torch.randn(S, L, E, generator=g)
+    wf, wr = (torch.randn(E, 4, generator=g) * 0.5 for _ in range(2))
+    bf, br = (torch.randn(E, generator=g) * 0.5 for _ in range(2))
+    xpf, xpr = (torch.randn(R + 32, E, generator=g) * E ** -0.5 for _ in range(2))
+    if dtype == torch.bfloat16:
+        x, xpf, xpr = (O.round_bf16(t) for t in (x, xpf, xpr))
+    rnd = O.round_bf16 if dtype == torch.bfloat16 else O._ident
+    xcf_ref = O.causal_conv1d_fn(x.transpose(1, 2), wf, bf, activation="silu", rnd=rnd).transpose(1, 2)
+    xcr_ref = O.causal_conv1d_fn(x.transpose(1, 2).flip(-1), wr, br, activation="silu", rnd=rnd).flip(-1).transpose(1, 2)
+    xcf, xcr, dblf, dblr = ops.conv_xproj_bidir(x.to(dtype).to(DEV), wf.to(DEV), bf.to(DEV), wr.to(DEV), br.to(DEV),
+                                                xpf.to(dtype).to(DEV), xpr.to(dtype).to(DEV))
+    assert xcf.dtype == dtype and dblf.shape == (S, L, R + 32)
+    tol_c = 1e-5 if dtype == torch.float32 else 2 ** -7
+    assert relerr(xcf, xcf_ref) < tol_c and relerr(xcr, xcr_ref) < tol_c
+    for xc, dbl, w in ((xcf, dblf, xpf), (xcr, dblr, xpr)):
+        ref = rnd(torch.einsum("sle,re->slr", xc.float().cpu(), w))          # the GEMM on the kernel's own conv output
+        assert relerr(dbl, ref) < (3e-5 if dtype == torch.float32 else 2 ** -7)
+    if dtype == torch.float32:                                               # end to end against the oracle's conv output
+        assert relerr(dblf, torch.einsum("sle,re->slr", xcf_ref, xpf)) < 3e-5
+        assert relerr(dblr, torch.einsum("sle,re->slr", xcr_ref, xpr)) < 3e-5
+
+
 def _scan_inputs(seed, Bsz, E, L, N=16):
     g = torch.Generator().manual_seed(seed)
     u = torch.randn(Bsz, E, L, generator=g)

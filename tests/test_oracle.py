@@ -126,3 +126,37 @@ def test_c_port_bf16_emulation_matches_torch_emulation():
     assert np.abs(lg - ref["logits"].numpy()).max() / np.abs(lg).max() < 2 ** -6
     assert np.abs(hid - ref["hidden"].numpy()).max() / np.abs(hid).max() < 2 ** -6
     assert np.array_equal(lg, lg.astype(np.float32)) and np.all(lg == torch.from_numpy(lg).bfloat16().float().numpy())
+
+
+def test_c_port_reference_order_matches_torch_oracle():
+    """ref_order=True (each direction's tied out_proj computed and rounded, then summed: the reference's BiMambaWrapper
+    order) equals forward_strands(tie_fold=False): fp32 to rounding noise, bf16-emulating to a bf16 ulp; and in fp32 the
+    two orders agree with each other (identical in exact arithmetic)."""
+    from oracle.c_oracle import COracle
+    cfg = make_config("x", d_model=128, n_layer=3)
+    sd = synthetic_state_dict(cfg, seed=3)
+    ids = np.random.default_rng(4).integers(3, 7, size=(3, 40)).astype(np.int64)
+    ids[:, 20] = 1
+    ref = O.forward_strands(torch.from_numpy(ids), O.params_from_state_dict(sd, cfg), tie_fold=False)
+    lg, hid = COracle(sd, cfg, ref_order=True).forward(ids, want_hidden=True)
+    assert np.abs(lg - ref["logits"].numpy()).max() / np.abs(lg).max() < 1e-5
+    assert np.abs(hid - ref["hidden"].numpy()).max() / np.abs(hid).max() < 1e-5
+    lg0, _ = COracle(sd, cfg).forward(ids)
+    assert np.abs(lg - lg0).max() / np.abs(lg).max() < 1e-5
+    refb = O.forward_strands(torch.from_numpy(ids), O.params_from_state_dict(sd, cfg, dtype=torch.bfloat16),
+                             rnd=O.round_bf16, tie_fold=False)
+    lgb, hidb = COracle(sd, cfg, dtype=torch.bfloat16, emulate_bf16=True, ref_order=True).forward(ids, want_hidden=True)
+    assert np.abs(lgb - refb["logits"].numpy()).max() / np.abs(lgb).max() < 2 ** -6
+    assert np.abs(hidb - refb["hidden"].numpy()).max() / np.abs(hidb).max() < 2 ** -6
+
+
+def test_c_port_blas_gemm_hook_matches_plain():
+    """blas=True routes the four projections to the host BLAS (numpy sgemm); same forward, summation-order noise only."""
+    from oracle.c_oracle import COracle
+    cfg = make_config("x", d_model=128, n_layer=2)
+    sd = synthetic_state_dict(cfg, seed=3)
+    ids = np.random.default_rng(4).integers(3, 7, size=(3, 40)).astype(np.int64)
+    lg0, h0 = COracle(sd, cfg).forward(ids, want_hidden=True)
+    lg1, h1 = COracle(sd, cfg, blas=True).forward(ids, want_hidden=True)
+    assert np.abs(lg1 - lg0).max() / np.abs(lg0).max() < 1e-5
+    assert np.abs(h1 - h0).max() / np.abs(h0).max() < 1e-5
