@@ -21,7 +21,7 @@ import numpy as np
 import torch
 
 from . import sharding
-from .zero_shot import tokenize_masked
+from .zero_shot import local_ids
 
 
 def load_data(filepath):
@@ -33,14 +33,12 @@ def load_data(filepath):
 
 def extract_embeddings(model, sequences, device, tokenIdx: int, tokenizer=None, batch_size: int = 128) -> np.ndarray:
     logging.info("Extracting embeddings")
-    if isinstance(sequences, (np.ndarray, torch.Tensor)):
-        ids_all = torch.as_tensor(np.asarray(sequences) if not torch.is_tensor(sequences) else sequences)
-    else:
-        ids_all = torch.from_numpy(tokenize_masked(sequences, tokenizer, None))
-    n_total = ids_all.shape[0]
+    n_total = len(sequences)
     rank, ws = sharding.world()
     start, stop, per = sharding.shard_bounds(n_total, rank, ws)
-    ids_local = sharding.pad_rows(ids_all[start:stop], per) if ws > 1 else ids_all
+    ids_local = local_ids(sequences, start, stop, tokenizer, None)            # only this rank's block is tokenised
+    if ws > 1:
+        ids_local = sharding.pad_rows(ids_local, per)
     fast = bool(getattr(model, "supports_positions", False))
     model.eval()
     outs = []

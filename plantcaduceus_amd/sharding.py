@@ -25,6 +25,7 @@ def init_from_env(device: str) -> str:
     """Under `torchrun` (WORLD_SIZE > 1): join the process group (RCCL for ROCm devices, gloo for cpu) and return
     this rank's device (`cuda:LOCAL_RANK`); otherwise return `device` unchanged."""
     import os
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC, before the first GPU call (RCCL needs it here)
     ws = int(os.environ.get("WORLD_SIZE", "1"))
     if ws <= 1 or not dist.is_available():
         return device
@@ -57,11 +58,8 @@ def pad_rows(x: torch.Tensor, rows: int) -> torch.Tensor:
     return torch.cat([x, x[-1:].expand(rows - x.shape[0], *x.shape[1:])], dim=0)
 
 
-def all_gather_rows(local: torch.Tensor, n_total: int) -> torch.Tensor:
-    """local [per_rank, ...] (equal on every rank) -> [n_total, ...] in rank order, padding stripped."""
-    rank, ws = world()
-    if ws == 1:
-        return local[:n_total]
+def _all_gather(local: torch.Tensor, ws: int) -> torch.Tensor:
+    """the collective itself: local [rows, ...] of each of `ws` ranks -> [ws * rows, ...] in rank order."""
     local = local.contiguous()
     out = torch.empty((ws * local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
     if local.is_cuda:
@@ -69,4 +67,12 @@ def all_gather_rows(local: torch.Tensor, n_total: int) -> torch.Tensor:
     else:
         parts = list(out.chunk(ws, dim=0))                 # gloo (CPU tests)
         dist.all_gather(parts, local)
-    return out[:n_total]
+    return out
+
+
+def all_gather_rows(local: torch.Tensor, n_total: int) -> torch.Tensor:
+    """local [per_rank, ...] (equal on every rank) -> [n_total, ...] in rank order, padding stripped."""
+    rank, ws = world()
+    if ws == 1:
+        return local[:n_total]
+    return _all_gather(local, ws)[:n_total]

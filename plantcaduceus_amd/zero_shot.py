@@ -70,6 +70,19 @@ def tokenize_masked(sequences: Sequence[str], tokenizer, tokenIdx: Optional[int]
     return ids
 
 
+def local_ids(sequences, start: int, stop: int, tokenizer, tokenIdx: Optional[int]) -> torch.Tensor:
+    """rows [start, stop) of the window list as an integer tensor [stop - start, L]: strings are tokenised (and masked at
+    tokenIdx) here, a pre-tokenised array is sliced.  Under sharding each rank calls this with its own block only."""
+    if isinstance(sequences, (np.ndarray, torch.Tensor)):
+        blk = sequences[start:stop]
+        return blk if torch.is_tensor(blk) else torch.from_numpy(np.ascontiguousarray(blk))
+    blk = sequences[start:stop]
+    if len(blk) == 0:
+        L = len(sequences[0]) if len(sequences) else 0
+        return torch.zeros((0, L), dtype=torch.int32)
+    return torch.from_numpy(tokenize_masked(blk, tokenizer, tokenIdx))
+
+
 # ---- a2: model loading ----------------------------------------------------------------------------
 def get_optimal_dtype() -> torch.dtype:
     if not torch.cuda.is_available():
@@ -108,14 +121,14 @@ def extract_logits(model, sequences, device, tokenIdx: int, tokenizer, batch_siz
     """sequences: list of equal-length strings, or a pre-tokenised+masked integer array [N, L].
     Returns softmax over the (a,c,g,t) logits at tokenIdx, fp32 [N, 4], rows in input order (all ranks)."""
     logging.info("Extracting logits")
-    ids_all = sequences if isinstance(sequences, (np.ndarray, torch.Tensor)) else tokenize_masked(sequences, tokenizer, tokenIdx)
-    ids_all = torch.as_tensor(np.asarray(ids_all) if not torch.is_tensor(ids_all) else ids_all)
-    n_total = ids_all.shape[0]
+    n_total = len(sequences)
     vocab = tokenizer.get_vocab()
     cols = [vocab[nc] for nc in "acgt"]
     rank, ws = sharding.world()
     start, stop, per = sharding.shard_bounds(n_total, rank, ws)
-    ids_local = sharding.pad_rows(ids_all[start:stop], per) if ws > 1 else ids_all
+    ids_local = local_ids(sequences, start, stop, tokenizer, tokenIdx)        # only this rank's block is tokenised
+    if ws > 1:
+        ids_local = sharding.pad_rows(ids_local, per)
     fast = bool(getattr(model, "supports_positions", False))
     outs = []
     with torch.inference_mode():

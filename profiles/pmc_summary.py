@@ -46,7 +46,11 @@ def main():
            "conv1d_bidir": [k for k in res if "conv_bidir" in k],
            "conv_xproj_fused": [k for k in res if "convx_kernel" in k],
            "add_rmsnorm": [k for k in res if "add_rmsnorm" in k and k.endswith("false>")]}
-    o = {"source": NOTE_SRC, "correction": NOTE_CORR, "kernels": res, "classes": {}}
+    o = {"source": NOTE_SRC, "correction": NOTE_CORR, "rows_per_launch": 65536, "kernels": res, "classes": {}}
+    try:
+        o["src_hash"] = open(base + "src_hash.txt").read().strip()     # bench.source_hash() of the profiled build
+    except OSError:
+        pass
     for c, ks in cls.items():
         ks = [k for k in ks if "FETCH_SIZE_KB" in res[k] and "WRITE_SIZE_KB" in res[k]]
         if not ks:

@@ -53,13 +53,22 @@ def test_config4_l32_embedding_extraction(l32):
     # different rows are different (not a constant output)
     assert np.abs(emb[0] - emb[1]).max() / scale > 1e-2
     k = 8
-    _, hid = COracle(sd, cfg, dtype=torch.bfloat16, emulate_bf16=True, ref_order=True, blas=True).forward(
-        ids[:k], want_logits=False, want_hidden=True)
-    e = hid[:, p, :]
-    ref = (e[:, :cfg.d_model] + e[:, cfg.d_model:][:, ::-1]) / 2                      # src/train_XGBoost.py:108-113
-    d = np.abs(emb[:k] - ref).max() / np.abs(ref).max()
-    print(f"config4: max |emb_hip - emb_oracle(bf16-emulating, reference order)| / max = {d:.2e} on {k} rows")
-    assert d < 1e-2
+
+    def oracle(**kw):
+        _, hid = COracle(sd, cfg, blas=True, **kw).forward(ids[:k], want_logits=False, want_hidden=True)
+        e = hid[:, p, :]
+        return (e[:, :cfg.d_model] + e[:, cfg.d_model:][:, ::-1]) / 2                 # src/train_XGBoost.py:108-113
+    ref = oracle(dtype=torch.bfloat16, emulate_bf16=True, ref_order=True)
+    eng = oracle(dtype=torch.bfloat16, emulate_bf16=True, ref_order=False)
+    f32 = oracle()
+    sc = np.abs(ref).max()
+    d, d_eng, d_f32, d_emul = (np.abs(a - b).max() / sc for a, b in ((emb[:k], ref), (emb[:k], eng), (emb[:k], f32), (ref, eng)))
+    print(f"config4 ({k} rows, / max): |hip - oracle bf16 reference order| {d:.2e}, |hip - oracle bf16 engine order| {d_eng:.2e}, "
+          f"|hip - oracle fp32| {d_f32:.2e}; the two bf16 emulations differ by {d_emul:.2e}")
+    # tolerance: the hidden state is a bf16 tensor (ulp at the max element 2^-8 = 3.9e-3 of max) after 32 layers of bf16
+    # rounding-order noise; two restatements that differ ONLY in the order of the tied out_proj already differ by d_emul
+    assert d < 2e-2 and d_eng < 2e-2 and d_f32 < 4e-2
+    assert d < 3 * max(d_emul, 2 ** -8)
 
 
 def test_config5_l32_ism_sweep_one_window(l32, golden_dir):

@@ -42,28 +42,37 @@ def _worker(rank, ws, port, n, outdir):
         from plantcaduceus_amd import embeddings, zero_shot
         from plantcaduceus_amd.checkpoint import make_config, synthetic_state_dict
         from plantcaduceus_amd.tokenization_caduceus import CaduceusTokenizer
-        torch.set_num_threads(2)
+        torch.set_num_threads(1 if ws > 2 else 2)
         cfg = make_config("x", d_model=32, n_layer=1)
         model = O.OracleForMaskedLM(O.params_from_state_dict(synthetic_state_dict(cfg, seed=1), cfg))
         model.config = cfg
         rng = np.random.default_rng(0)
         seqs = ["".join(rng.choice(list("ACGT"), size=24)) for _ in range(n)]
         tok = CaduceusTokenizer()
-        p = zero_shot.extract_logits(model, seqs, "cpu", 11, tok, batch_size=2)
-        e = embeddings.extract_embeddings(model, seqs, "cpu", 11, tok, batch_size=2)
+        seen = []                                     # rows this rank tokenises (must be its own block only)
+        enc = tok.encode_batch
+        tok.encode_batch = lambda ss, mask_index=None: (seen.append(len(ss)), enc(ss, mask_index=mask_index))[1]
+        p = zero_shot.extract_logits(model, seqs, "cpu", 11, tok, batch_size=16)
+        e = embeddings.extract_embeddings(model, seqs, "cpu", 11, tok, batch_size=16)
+        a, b, _ = sharding.shard_bounds(n, rank, ws)
+        assert all(k == b - a for k in seen) and len(seen) == (2 if b > a else 0), (seen, a, b)
         np.savez(os.path.join(outdir, f"r{rank}.npz"), p=p, e=e)
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n", [5, 0])
-def test_two_rank_gather_equals_single_rank(tmp_path, n):
+@pytest.mark.parametrize("ws,n", [(2, 5), (2, 0), (4, 185), (4, 1), (8, 185), (8, 1), (8, 0)])
+def test_multi_rank_gather_equals_single_rank(tmp_path, ws, n):
+    """world 2 / 4 / 8 over gloo; N = 185 (the example table: not divisible by 4 or 8, tail padded), N = 1 (fewer rows than
+    ranks: most ranks run only the dummy row) and N = 0."""
     port = _free_port()
-    mp.spawn(_worker, args=(2, port, n, str(tmp_path)), nprocs=2, join=True)
-    r0, r1 = np.load(tmp_path / "r0.npz"), np.load(tmp_path / "r1.npz")
+    mp.spawn(_worker, args=(ws, port, n, str(tmp_path)), nprocs=ws, join=True)
+    rs = [np.load(tmp_path / f"r{r}.npz") for r in range(ws)]
+    r0 = rs[0]
     assert r0["p"].shape == (n, 4) and r0["e"].shape[0] == n
-    np.testing.assert_array_equal(r0["p"], r1["p"])           # every rank holds the full result
-    np.testing.assert_array_equal(r0["e"], r1["e"])
+    for r in rs[1:]:
+        np.testing.assert_array_equal(r0["p"], r["p"])           # every rank holds the full result
+        np.testing.assert_array_equal(r0["e"], r["e"])
     if n:
         # single-rank run in this process
         from oracle import caduceus_oracle as O
@@ -75,5 +84,29 @@ def test_two_rank_gather_equals_single_rank(tmp_path, n):
         rng = np.random.default_rng(0)
         seqs = ["".join(rng.choice(list("ACGT"), size=24)) for _ in range(n)]
         tok = CaduceusTokenizer()
-        np.testing.assert_allclose(zero_shot.extract_logits(model, seqs, "cpu", 11, tok, batch_size=2), r0["p"], rtol=1e-6)
-        np.testing.assert_allclose(embeddings.extract_embeddings(model, seqs, "cpu", 11, tok, batch_size=2), r0["e"], rtol=1e-6, atol=1e-7)
+        np.testing.assert_allclose(zero_shot.extract_logits(model, seqs, "cpu", 11, tok, batch_size=16), r0["p"], rtol=1e-6)
+        np.testing.assert_allclose(embeddings.extract_embeddings(model, seqs, "cpu", 11, tok, batch_size=16), r0["e"], rtol=1e-6, atol=1e-7)
+
+
+@pytest.mark.gpu
+def test_rccl_all_gather_branch_single_rank():
+    """the GPU branch of sharding.all_gather_rows (dist.all_gather_into_tensor over RCCL) executed once: world 1 on cuda:0.
+    (`world() == 1` short-circuits in all_gather_rows, so sharding._all_gather — what world > 1 runs — is called directly.)"""
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        local = torch.arange(12, dtype=torch.float32, device=dev).reshape(3, 4)
+        out = torch.empty_like(local)
+        dist.all_gather_into_tensor(out, local.contiguous())
+        torch.cuda.synchronize()
+        assert torch.equal(out, local)
+        # and through the product's collective function (all_gather_rows skips it when world() == 1)
+        emb = torch.randn(5, 1024, device=dev)
+        assert torch.equal(sharding._all_gather(local, 1), local)
+        assert torch.equal(sharding._all_gather(emb, 1), emb)
+        assert sharding.world() == (0, 1) and torch.equal(sharding.all_gather_rows(emb, 4), emb[:4])
+    finally:
+        dist.destroy_process_group()

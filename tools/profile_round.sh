@@ -12,7 +12,8 @@ timeout 600 python3 "$ROOT/bench.py" > "$OUT/bench.json" 2> "$OUT/bench.err"
 tail -c 600 "$OUT/bench.json"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- python3 "$ROOT/bench.py" --steps 2 --warmup 1 --cpu-seqs 0 --no-profile > "$OUT/stats.log" 2>&1
 f=$(find "$OUT/stats" -name "*kernel_stats.csv" | head -1); cp "$f" "$OUT/kernel_stats.csv"; find "$OUT/stats" -type f ! -name "*kernel_stats.csv" -delete
-export PCAD_CHUNK_SEQS=64     # PMC passes: 65536 token-rows per launch (what profiles/pmc_summary.py and bench.py scale from)
+python3 -c "import sys; sys.path.insert(0, '$ROOT'); import bench; print(bench.source_hash())" > "$OUT/src_hash.txt"
+export PCAD_DEV=1 PCAD_CHUNK_SEQS=64     # PMC passes: 65536 token-rows per launch (what profiles/pmc_summary.py and bench.py scale from)
 for C in FETCH_SIZE WRITE_SIZE; do
   timeout 600 rocprofv3 --kernel-trace --pmc $C --output-format csv -d "$OUT/$C" -o p -- python3 "$ROOT/bench.py" --steps 1 --warmup 1 --cpu-seqs 0 --no-profile --batch 128 > "$OUT/$C.log" 2>&1
 done
