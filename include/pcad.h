@@ -13,9 +13,10 @@
  * Conventions
  *   - plain C: pointers and sizes only; no torch / HIP types in any signature (`pcad_stream` is a
  *     hipStream_t passed as void*).
- *   - every buffer is OWNED BY THE CALLER (ids, outputs, weights, weight arena, workspace); the library
- *     owns only the opaque handle.  No allocation, no host synchronisation inside pcad_forward.
- *   - all work is enqueued on the caller's stream; a handle is bound to the current device and is not
+ *   - every buffer and every stream is OWNED BY THE CALLER (ids, outputs, weights, weight arena, workspace); the library
+ *     owns only the opaque handle (plus the HIP events of the optional profiling / two-lane modes, freed with it).
+ *     No allocation, no host synchronisation inside pcad_forward.
+ *   - all work is enqueued on the caller's stream (and, if given, the caller's two aux streams: pcad_set_aux_streams); a handle is bound to the current device and is not
  *     thread-safe; distinct handles on distinct devices are independent (one process per GPU).
  *   - status: 0 = OK, negative = error (enum below); message via thread-local pcad_last_error().
  *   - activation layout is token-major: [strand, position, channel] (channel contiguous).
@@ -78,6 +79,21 @@ const char* pcad_last_error(void);
 /* Replaces: AutoModelForMaskedLM.from_pretrained(...).to(device)  (src/zero_shot_score.py:91-97) */
 int    pcad_create(const pcad_config* cfg, pcad_handle* out);
 void   pcad_destroy(pcad_handle h);
+
+/* Options (call before pcad_workspace_bytes / pcad_forward):
+ *   "chunk_seqs"  windows per pass through the layer stack (0 = default: as many as the kernels' 32-bit offsets allow,
+ *                 512 at l32 bf16).  Results do not depend on it (rows are independent); workspace size does.
+ *   "gate_each"   1: SiLU(z) applied to each direction's scan output, each rounded, then summed — the reference's order
+ *                 (two selective_scan_fn calls);  0 (default): applied once to the sum of both directions (same value in
+ *                 exact arithmetic, one rounding fewer, faster).
+ * The library reads NO environment variables unless PCAD_DEV=1 is set (developer A/B switches, see csrc/kernels.hpp). */
+int    pcad_set_option(pcad_handle h, const char* key, int64_t value);
+
+/* Optional two-lane chunk pipeline: when two distinct caller-owned streams are given and a batch has >= 2 chunks,
+ * pcad_forward walks two chunks at a time, one on each aux stream, forked from and joined back to its `stream` argument
+ * with events (on every exit path).  The events are the only objects besides the handle that the library creates; they
+ * live until pcad_destroy.  pcad_workspace_bytes doubles accordingly.  NULL, NULL turns it off (default). */
+int    pcad_set_aux_streams(pcad_handle h, pcad_stream a, pcad_stream b);
 
 /* Bytes of caller-owned device memory that pcad_bind_weights packs the model into. */
 size_t pcad_weight_arena_bytes(pcad_handle h);

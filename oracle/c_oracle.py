@@ -141,3 +141,25 @@ class COracle:
         if rc != 0:
             raise MemoryError("oracle_forward failed")
         return logits, hidden
+
+
+class COracleForMaskedLM:
+    """HF-surface stand-in over the C port (`model(input_ids=..., output_hidden_states=...)` -> `.logits`,
+    `.hidden_states[-1]`), so the reference-shaped CLIs can be driven on CPU at real model sizes (BASELINE config 1)."""
+
+    def __init__(self, state_dict, config, **kw):
+        self.oracle = COracle(state_dict, config, **kw)
+        self.config = config
+
+    def eval(self):
+        return self
+
+    def to(self, *a, **k):
+        return self
+
+    def __call__(self, input_ids=None, output_hidden_states=False, **kw):
+        import torch
+        from oracle.caduceus_oracle import _Out
+        ids = input_ids.cpu().numpy() if hasattr(input_ids, "cpu") else np.asarray(input_ids)
+        lg, hid = self.oracle.forward(ids, want_logits=True, want_hidden=bool(output_hidden_states))
+        return _Out(torch.from_numpy(lg), (torch.from_numpy(hid),) if output_hidden_states else None)

@@ -225,6 +225,7 @@ def gen_plantcad2_metrics():
                avgtrue=ev._avg_trueprob_scores(probs3, tt, motif_len))
     out["auprc"] = float(average_precision_score(labels, out["refprob"]))
     out["auroc_avgtrue"] = float(ev.auc(*ev.roc_curve(labels, out["avgtrue"])[:2]))
+    out["auprc_avgtrue"] = float(average_precision_score(labels, out["avgtrue"]))   # core_noncore prints both (:523-530)
     # SV: windows of length Lw, central 2*flanking positions mutated; left/right 1-based boundaries with room for the flanks
     Lw, F = 48, 5
     ref_seqs = ["".join(rng.choice(alphabet, size=Lw, p=[.2, .2, .2, .2, .04, .04, .04, .04, .02, .02])) for _ in range(n)]

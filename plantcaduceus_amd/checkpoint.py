@@ -105,15 +105,44 @@ def save_checkpoint(path: str, config: CaduceusConfig, sd: Dict[str, torch.Tenso
         CaduceusTokenizer().save_pretrained(path)
 
 
+def resolve_snapshot(name_or_path: str, **hub_kwargs) -> str:
+    """A local snapshot directory as is; anything else is taken as a HF-hub repo id (the reference's README and CLI pass
+    `-model kuleshov-group/PlantCaduceus_l32`) and resolved with `huggingface_hub.snapshot_download`, which honours
+    HF_HUB_OFFLINE / `local_files_only` (served from the local HF cache when there is no network)."""
+    path = str(name_or_path)
+    if os.path.isdir(path):
+        return path
+    try:
+        from huggingface_hub import snapshot_download
+        return snapshot_download(repo_id=path, allow_patterns=["*.json", "*.safetensors", "*.bin", "*.txt"], **hub_kwargs)
+    except Exception as e:   # offline and not cached, bad id, ...
+        raise OSError(f"{path} is neither a local snapshot directory nor a HF-hub repo that can be resolved here ({e}); "
+                      "download kuleshov-group/PlantCaduceus_l* and pass its directory, or populate the HF cache") from e
+
+
 def load_state_dict(path: str) -> Dict[str, torch.Tensor]:
-    """Read a snapshot directory (model.safetensors or pytorch_model.bin) and restore the tied keys."""
-    st = os.path.join(path, "model.safetensors")
-    if os.path.exists(st):
-        from safetensors.torch import load_file
-        sd = load_file(st)
+    """Read a snapshot directory — model.safetensors, sharded model.safetensors.index.json / pytorch_model.bin.index.json,
+    or pytorch_model.bin — and restore the tied keys."""
+    def _one(fn):
+        if fn.endswith(".safetensors"):
+            from safetensors.torch import load_file
+            return load_file(os.path.join(path, fn))
+        return torch.load(os.path.join(path, fn), map_location="cpu", weights_only=True)
+
+    sd: Dict[str, torch.Tensor] = {}
+    for single, index in (("model.safetensors", "model.safetensors.index.json"),
+                          ("pytorch_model.bin", "pytorch_model.bin.index.json")):
+        if os.path.exists(os.path.join(path, single)):
+            sd = dict(_one(single))
+            break
+        if os.path.exists(os.path.join(path, index)):
+            with open(os.path.join(path, index)) as f:
+                shards = sorted(set(json.load(f)["weight_map"].values()))
+            for fn in shards:
+                sd.update(_one(fn))
+            break
     else:
-        sd = torch.load(os.path.join(path, "pytorch_model.bin"), map_location="cpu", weights_only=True)
-    sd = dict(sd)
+        raise FileNotFoundError(f"{path}: no model.safetensors / pytorch_model.bin (or their .index.json shards)")
     if LMHEAD_KEY not in sd:
         sd[LMHEAD_KEY] = sd[EMB_KEY]
     for k in list(sd.keys()):

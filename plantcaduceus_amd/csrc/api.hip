@@ -64,7 +64,7 @@ struct pcad_engine {
     int rdt;        // residual dtype
     int chunk;      // PCAD_CHUNK_SEQS override: sequences per pass through the layer stack (0: derive from chunk_rows)
     int64_t chunk_rows;   // token-rows (2 strands x L per window) per pass through the layer stack
-    int nstreams;   // 1: everything on the caller's stream; 2: chunks alternate between two library streams
+    int nstreams;   // 1: everything on the caller's stream; 2: chunks alternate between the two caller-provided aux streams
     bool gate_once; // SiLU(z) applied once to y_fwd + y_rev (reverse scan) instead of once per direction
     bool convx;     // conv + x_proj of both directions in one kernel (needs xzsplit and Rp == 64); PCAD_NO_CONVX=1: off
     bool xzsplit;   // in_proj writes x and z as two blocked tensors (needs `blocked`); PCAD_PLAIN_XZ=1 turns it off (A/B knob)
@@ -159,6 +159,8 @@ Workspace carve_workspace(const pcad_engine* e, void* base, int Bc, int L) {
 const char* const kClassNames[PCAD_NUM_KERNEL_CLASSES] = {
     "add_rmsnorm", "gemm_in_proj", "conv1d_bidir", "gemm_x_proj", "selective_scan", "gemm_out_proj", "final_head"};
 
+constexpr size_t kProfCap = 1 << 16;
+
 hipEvent_t prof_event(pcad_engine* e) {
     if (!e->prof_pool.empty()) {
         hipEvent_t ev = e->prof_pool.back();
@@ -173,7 +175,8 @@ hipEvent_t prof_event(pcad_engine* e) {
 struct ProfScope {   // records start/stop events around one launch when profiling is on
     pcad_engine* e; int cls; hipStream_t s; hipEvent_t a = nullptr, b = nullptr;
     ProfScope(pcad_engine* e_, int cls_, hipStream_t s_) : e(e_), cls(cls_), s(s_) {
-        if (e->prof && (e->prof_seen[cls]++ % e->prof_stride) == 0) {
+        // at most kProfCap un-read event pairs per class: a caller that never calls pcad_profile_read cannot grow the lists
+        if (e->prof && (e->prof_seen[cls]++ % e->prof_stride) == 0 && e->prof_ev[cls].size() < kProfCap) {
             a = prof_event(e); b = prof_event(e);
             if (a) (void)hipEventRecord(a, s);
         }
@@ -221,7 +224,7 @@ int pcad_create(const pcad_config* cfg, pcad_handle* out) {
     e->XP = e->Rp + 2 * e->N;            // x_proj rows: [dt (R) | 0-pad | B (16) | C (16)]
     e->esz = cfg->dtype == PCAD_BF16 ? 2 : 4;
     e->rdt = (cfg->residual_in_fp32 || cfg->dtype == PCAD_F32) ? F32 : BF16;
-    const char* ck = getenv("PCAD_CHUNK_SEQS");
+    const char* ck = dev_env("PCAD_CHUNK_SEQS");       // PCAD_DEV=1 only; the ABI's knob is pcad_set_option("chunk_seqs")
     // Token-rows per chunk: bounded by the kernels' unsigned 32-bit in-tensor byte offsets (rows * E * esz < 2^32 in the scan,
     // the fused conv+x_proj kernel and the 4-wave GEMM); 2^31 / (E * esz) = 524288 rows = 512 windows of 512 bp at l32 bf16
     // (15 GB of workspace) keeps a factor 2 of margin.  Fewer, larger launches: 1024 windows as 4 chunks instead of 16 measured +6 %
@@ -230,15 +233,12 @@ int pcad_create(const pcad_config* cfg, pcad_handle* out) {
     e->chunk = ck ? atoi(ck) : 0;
     if (e->chunk < 0) e->chunk = 0;
     e->chunk_rows = ((int64_t)1 << 31) / ((int64_t)e->E * e->esz);
-    e->blocked = getenv("PCAD_PLAIN_LAYOUT") == nullptr && (e->E * e->esz) % 128 == 0;
-    e->xzsplit = e->blocked && getenv("PCAD_PLAIN_XZ") == nullptr && e->E % 16 == 0;
-    e->convx = e->xzsplit && e->Rp == 64 && getenv("PCAD_NO_CONVX") == nullptr;
-    e->gate_once = getenv("PCAD_GATE_EACH") == nullptr;
-    const char* ns = getenv("PCAD_STREAMS");
-    // default 1: measured on MI355X (r01d) two lanes give 851 vs 852 seq/s -- co-running a VALU-bound scan and an
-    // MFMA-bound GEMM slows each by the other's share (shared issue/power budget), so nothing is gained.
-    e->nstreams = ns ? atoi(ns) : 1;
-    if (e->nstreams != 2) e->nstreams = 1;
+    // developer A/B switches (honoured only with PCAD_DEV=1): plain layouts / unfused conv
+    e->blocked = dev_env("PCAD_PLAIN_LAYOUT") == nullptr && (e->E * e->esz) % 128 == 0;
+    e->xzsplit = e->blocked && dev_env("PCAD_PLAIN_XZ") == nullptr && e->E % 16 == 0;
+    e->convx = e->xzsplit && e->Rp == 64 && dev_env("PCAD_NO_CONVX") == nullptr;
+    e->gate_once = true;                  // pcad_set_option("gate_each", 1) restores the per-direction gate
+    e->nstreams = 1;                      // pcad_set_aux_streams() turns the two-lane chunk pipeline on
     *out = e;
     return PCAD_OK;
 }
@@ -248,13 +248,40 @@ void pcad_destroy(pcad_handle h) {
     for (int c = 0; c < PCAD_NUM_KERNEL_CLASSES; ++c)
         for (auto& pr : h->prof_ev[c]) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     for (auto ev : h->prof_pool) (void)hipEventDestroy(ev);
-    for (int i = 0; i < 2; ++i) {
-        if (h->aux[i]) (void)hipStreamDestroy(h->aux[i]);
+    for (int i = 0; i < 2; ++i)          // the aux streams are the caller's; only the fork/join events are ours
         if (h->ev_join[i]) (void)hipEventDestroy(h->ev_join[i]);
-    }
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     if (h->ev_phase) (void)hipEventDestroy(h->ev_phase);
     delete h;
+}
+
+int pcad_set_option(pcad_handle h, const char* key, int64_t value) {
+    if (!h || !key) return fail(PCAD_ERR_INVALID, "pcad_set_option: null argument");
+    const std::string k(key);
+    if (k == "chunk_seqs") {
+        if (value < 0 || value > (1 << 20)) return fail(PCAD_ERR_INVALID, "chunk_seqs=%lld out of range", (long long)value);
+        h->chunk = (int)value;
+    } else if (k == "gate_each") {
+        h->gate_once = value == 0;
+    } else {
+        return fail(PCAD_ERR_INVALID, "pcad_set_option: unknown option '%s'", key);
+    }
+    return PCAD_OK;
+}
+
+int pcad_set_aux_streams(pcad_handle h, pcad_stream a, pcad_stream b) {
+    if (!h) return fail(PCAD_ERR_INVALID, "pcad_set_aux_streams: null handle");
+    if ((a == nullptr) != (b == nullptr) || (a && a == b))
+        return fail(PCAD_ERR_INVALID, "pcad_set_aux_streams: pass two distinct streams, or NULL, NULL");
+    h->aux[0] = (hipStream_t)a;
+    h->aux[1] = (hipStream_t)b;
+    h->nstreams = a ? 2 : 1;
+    if (a && !h->ev_fork) {
+        for (int i = 0; i < 2; ++i) HIP_TRY(hipEventCreateWithFlags(&h->ev_join[i], hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&h->ev_phase, hipEventDisableTiming));
+    }
+    return PCAD_OK;
 }
 
 size_t pcad_weight_arena_bytes(pcad_handle h) {
@@ -399,21 +426,23 @@ static int forward_impl(pcad_handle h, const int32_t* ids, int B, int L, const i
     const size_t slab = carve_workspace(e, nullptr, chunk, L).bytes;
 
     // One chunk = up to `chunk` windows (2x strands) walking the whole layer stack.  With two lanes, chunks alternate
-    // between two library-owned streams forked from / joined to the caller's stream; the second lane starts half
-    // a layer late so that one chunk's VALU-bound scans run beside the other chunk's MFMA-bound GEMMs.
+    // between the two caller-provided aux streams (pcad_set_aux_streams), forked from / joined to the caller's stream
+    // with events; the second lane starts half a layer late so that one chunk's VALU-bound scans run beside the other
+    // chunk's MFMA-bound GEMMs.
     struct Lane { hipStream_t s; Workspace w; int b0, Bc; bool active; };
     Lane ln[2];
-    if (lanes == 2) {
-        if (!e->aux[0]) {
-            for (int i = 0; i < 2; ++i) {
-                HIP_TRY(hipStreamCreateWithFlags(&e->aux[i], hipStreamNonBlocking));
-                HIP_TRY(hipEventCreateWithFlags(&e->ev_join[i], hipEventDisableTiming));
-            }
-            HIP_TRY(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
-            HIP_TRY(hipEventCreateWithFlags(&e->ev_phase, hipEventDisableTiming));
+    struct Join {      // runs on EVERY exit path: the caller's stream never runs ahead of work left on the aux streams
+        pcad_engine* e; hipStream_t cs; bool on;
+        ~Join() {
+            if (!on) return;
+            for (int i = 0; i < 2; ++i)
+                if (hipEventRecord(e->ev_join[i], e->aux[i]) == hipSuccess) (void)hipStreamWaitEvent(cs, e->ev_join[i], 0);
         }
+    } join{e, cs, false};
+    if (lanes == 2) {
         HIP_TRY(hipEventRecord(e->ev_fork, cs));
         for (int i = 0; i < 2; ++i) HIP_TRY(hipStreamWaitEvent(e->aux[i], e->ev_fork, 0));
+        join.on = true;
     }
 
     auto phase_G = [&](Lane& c, int li) -> int {        // residual add + norm, in_proj, conv (both directions)
@@ -521,13 +550,7 @@ static int forward_impl(pcad_handle h, const int32_t* ids, int B, int L, const i
             if (ln[i].active)
                 if (int rc = phase_head(ln[i])) return rc;
     }
-    if (lanes == 2) {
-        for (int i = 0; i < 2; ++i) {
-            HIP_TRY(hipEventRecord(e->ev_join[i], e->aux[i]));
-            HIP_TRY(hipStreamWaitEvent(cs, e->ev_join[i], 0));
-        }
-    }
-    return PCAD_OK;
+    return PCAD_OK;      // `join` re-joins the aux streams here (and on every early return above)
 }
 
 int pcad_forward(pcad_handle h, const int32_t* ids, int B, int L, const int32_t* positions, int P, void* hidden_out,

@@ -289,221 +289,17 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_kernel(const T* __res
 
 // =====================================================================================================================
 // 256x256-tile variant for the square-ish projections (in_proj, out_proj): 8 waves as 2(M) x 4(N), wave tile 128x64 =
-// 8x4 MFMA tiles (128 accumulator registers), 2-stage LDS ring of 64 KiB (A 32 KiB + W 32 KiB).  Per flop it moves 33 %
-// fewer L2->LDS bytes and 25 % fewer LDS->register bytes than the 256x128 / 64x64 kernel above, which the ablation showed
-// to be what that kernel is bound by.  Each K-tile is four phases of 16 MFMAs (m-half x k-half); the ds_read_b128 of the
-// next phase's fragments are issued before the current phase's MFMAs (four 16-register fragment sets rotate), the
-// "next K-tile has landed" barrier sits between phases 3 and 4 where every read of the current stage has completed, and
-// the DMAs of K-tile g+2 are issued right after it into the stage just freed (~2200 cycles before they are needed).
+// 8x4 MFMA tiles (128 accumulator registers).  Per flop it moves 33 % fewer L2->LDS bytes and 25 % fewer LDS->register
+// bytes than the 256x128 / 64x64 kernel above, which the ablation showed to be what that kernel is bound by.  Each K-tile
+// is four phases of 16 MFMAs (m-half x k-half); the ds_read_b128 of the next phase's fragments are issued before the
+// current phase's MFMAs (four 16-register fragment sets rotate).  (Its first form, a 2-stage ring with all eight DMAs of
+// K-tile g+2 behind one barrier, is gone: the ring kernels below replaced it — DESIGN.md §3.)
 constexpr int BM2 = 256, BN2 = 256;
 constexpr int A2_BYTES = BM2 * ROWB, W2_BYTES = BN2 * ROWB;     // 32 KiB each
-constexpr int STAGE2_BYTES = A2_BYTES + W2_BYTES;
-constexpr int GEMM2_LDS = 2 * STAGE2_BYTES;                    // 128 KiB
-
-template <typename T, typename OutT>
-__global__ __launch_bounds__(GEMM_THREADS, 2) void gemm256_kernel(const T* __restrict__ A, int64_t lda,
-                                                                  const T* __restrict__ W, int64_t ldw,
-                                                                  OutT* __restrict__ C, int64_t ldc, int64_t M, int N,
-                                                                  int K, int tiles_m, int tiles_n, int a_blocked,
-                                                                  OutT* __restrict__ C2, int nsplit, int out_blocked) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);    // 0..7
-    const int gstride = (int)gridDim.x;
-    const int nblk = tiles_m * tiles_n;
-    const int nkt = (K * (int)sizeof(T)) / ROWB;
-
-    auto tile_coords = [&](int tile, int64_t& m0, int& n0) {
-        const int xcd = tile & 7, idx = tile >> 3;
-        const int q = nblk >> 3, r = nblk & 7;
-        const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-        const int gsz = GROUP_M * tiles_n;
-        const int g = logical / gsz;
-        const int first_m = g * GROUP_M;
-        const int gm = min(GROUP_M, tiles_m - first_m);
-        const int in_g = logical - g * gsz;
-        m0 = (int64_t)(first_m + in_g % gm) * BM2;
-        n0 = (in_g / gm) * BN2;
-    };
-
-    // staging cursor: wave stages rows [wave*32, +32) of the A tile and of the W tile: 4 + 4 LDS-DMAs of 1 KiB
-    const char* pa[4];
-    const char* pw[4];
-    auto set_ptrs = [&](int64_t m0, int n0) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int row = wave * 32 + i * 8 + (lane >> 3);
-            int64_t ga = m0 + row; if (ga > M - 1) ga = M - 1;
-            int gw = n0 + row; if (gw > N - 1) gw = N - 1;
-            const int64_t abyte = a_blocked ? blocked_off(ga, 0, (lda * (int64_t)sizeof(T)) >> 7) : ga * lda * (int64_t)sizeof(T);
-            pa[i] = reinterpret_cast<const char*>(A) + abyte + (((lane & 7) ^ key_a(row)) << 4);
-            pw[i] = reinterpret_cast<const char*>(W + (int64_t)gw * ldw) + (((lane & 7) ^ key_w(row)) << 4);
-        }
-    };
-    int stile = blockIdx.x, skt = 0;
-    bool s_valid = stile < nblk;
-    auto stage_next = [&](int st) -> bool {
-        const bool issued = s_valid;
-        if (s_valid) {
-            char* as = smem + st * STAGE2_BYTES + (wave * 32) * ROWB;
-            char* ws = as + A2_BYTES;
-            const int64_t ko = (int64_t)skt * ROWB;
-            const int64_t koa = a_blocked ? (int64_t)skt * 1024 : ko;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) glds16(pa[i] + koa, as + i * 8 * ROWB);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) glds16(pw[i] + ko, ws + i * 8 * ROWB);
-            if (++skt == nkt) {
-                skt = 0;
-                stile += gstride;
-                s_valid = stile < nblk;
-                if (s_valid) {
-                    int64_t sm0; int sn0;
-                    tile_coords(stile, sm0, sn0);
-                    set_ptrs(sm0, sn0);
-                }
-            }
-        }
-        return issued;
-    };
-
-    const int wm = wave >> 2, wn = wave & 3;
-    const int li = lane & 15, lg = lane >> 4;
-    int a_off[8], a_key[8], w_off[4], w_key[4];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int ra = wm * 128 + i * 16 + li;
-        a_off[i] = ra * ROWB; a_key[i] = key_a(ra);
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int rw = wn * 64 + (li >> 2) * 16 + j * 4 + (li & 3);
-        w_off[j] = A2_BYTES + rw * ROWB; w_key[j] = key_w(rw);
-    }
-    auto load_a = [&](int st, int kk, int half, u32x4 (&a)[4]) {
-        const char* base = smem + st * STAGE2_BYTES;
-        const int chunk = kk * 4 + lg;
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-            a[i] = *reinterpret_cast<const u32x4*>(base + a_off[half * 4 + i] + ((chunk ^ a_key[half * 4 + i]) << 4));
-    };
-    auto load_w = [&](int st, int kk, u32x4 (&w)[4]) {
-        const char* base = smem + st * STAGE2_BYTES;
-        const int chunk = kk * 4 + lg;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) w[j] = *reinterpret_cast<const u32x4*>(base + w_off[j] + ((chunk ^ w_key[j]) << 4));
-    };
-
-    f32x4 acc[8][4];
-    auto zero_acc = [&]() {
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    };
-    auto mma = [&](int half, const u32x4 (&a)[4], const u32x4 (&w)[4]) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[half * 4 + i][j] = Mma<T>::run(w[j], a[i], acc[half * 4 + i][j]);
-    };
-    auto epilogue = [&](int64_t m0, int n0) {       // lane: 16 consecutive columns nb .. nb+15 of 8 rows
-        const int nb = n0 + wn * 64 + lg * 16;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int64_t m = m0 + wm * 128 + i * 16 + li;
-            if (m >= M) continue;
-            float lo[8], hi[8];
-#pragma unroll
-            for (int rr = 0; rr < 4; ++rr) {
-                lo[rr] = acc[i][0][rr]; lo[4 + rr] = acc[i][1][rr];
-                hi[rr] = acc[i][2][rr]; hi[4 + rr] = acc[i][3][rr];
-            }
-            // two-output form (in_proj): columns [0, nsplit) -> C, [nsplit, N) -> C2, each a tensor of nsplit / N - nsplit
-            // columns, plain or (out_blocked) in the blocked layout that the conv / x_proj / scan kernels read
-            OutT* dst;
-            int nlim = N, col = nb;
-            if (C2 != nullptr) {
-                const bool second = nb >= nsplit;
-                const int width = second ? N - nsplit : nsplit;
-                col = second ? nb - nsplit : nb;
-                nlim = width;
-                OutT* base = second ? C2 : C;
-                dst = base + (out_blocked ? blocked_off(m, (int64_t)col * sizeof(OutT), ((int64_t)width * sizeof(OutT)) >> 7) / (int64_t)sizeof(OutT)
-                                          : m * (int64_t)width + col);
-            } else {
-                dst = C + m * ldc + nb;
-            }
-            if (col + 16 <= nlim) {
-                store8<OutT>(dst, lo);
-                store8<OutT>(dst + 8, hi);
-            } else {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    if (col + e < nlim) Elem<OutT>::store(dst + e, lo[e]);
-                    if (col + 8 + e < nlim) Elem<OutT>::store(dst + 8 + e, hi[e]);
-                }
-            }
-        }
-    };
-
-    int tile = blockIdx.x;
-    if (tile >= nblk) return;
-    int64_t m0; int n0;
-    tile_coords(tile, m0, n0);
-    set_ptrs(m0, n0);
-    stage_next(0);                                   // K-tile g = 0
-    if (stage_next(1)) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");      // g = 1 stays in flight
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    u32x4 a0[4], a1[4], w0[4], w1[4];
-    load_a(0, 0, 0, a0);
-    load_w(0, 0, w0);
-    zero_acc();
-    int st = 0, kt = 0;
-    bool pending = false;
-    int64_t pm0 = 0; int pn0 = 0;
-    while (true) {
-        if (pending) {                    // previous tile's result (all its MFMAs were issued in the last iteration)
-            epilogue(pm0, pn0);
-            zero_acc();
-            pending = false;
-        }
-        load_a(st, 0, 1, a1);             // phase 1: (m lo, k lo)
-        mma(0, a0, w0);
-        load_a(st, 1, 0, a0);             // phase 2: (m hi, k lo)
-        load_w(st, 1, w1);
-        mma(1, a1, w0);
-        load_a(st, 1, 1, a1);             // phase 3: (m lo, k hi)
-        mma(0, a0, w1);
-        // every read of stage `st` is issued; K-tile g+1 (the only DMAs in flight, plus a finished tile's stores)
-        // must have landed and every wave's reads of `st` must be complete before `st` is refilled
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        stage_next(st);                   // K-tile g+2 -> the stage just freed
-        load_a(st ^ 1, 0, 0, a0);         // phase 4: (m hi, k hi), with the first fragments of K-tile g+1 in flight
-        load_w(st ^ 1, 0, w0);
-        mma(1, a1, w1);
-        st ^= 1;
-        if (kt + 1 < nkt) {
-            ++kt;
-        } else {
-            pending = true; pm0 = m0; pn0 = n0;
-            tile += gstride;
-            if (tile >= nblk) break;
-            tile_coords(tile, m0, n0);
-            kt = 0;
-        }
-    }
-    epilogue(pm0, pn0);
-}
 
 // =====================================================================================================================
 // 256x256 tile, A in a 3-stage ring and W in a 2-stage ring (3 x 32 + 2 x 32 KiB = all 160 KiB of the CU's LDS).
-// Same wave tiling, fragments, phases and epilogue as gemm256_kernel; what changes is WHEN the LDS-DMAs are issued:
+// 8 waves, 128x64 wave tiles, four phases per K-tile as described above; WHEN the LDS-DMAs are issued:
 //   * A streams from HBM (each element once), W is re-read from L2 by every m-panel, so A gets the deeper ring:
 //     A(g+3) is issued in four single pieces, one per phase (phase 4 of iteration g ... phase 3 of g+1) and has at least
 //     one whole K-tile to land; W(g+2) is issued in phases 3 and 4 of iteration g (two pieces each) after a second
@@ -657,7 +453,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm256r_kernel(const T* __re
             }
             OutT* dst;
             int nlim = N, col = nb;
-            if (C2 != nullptr) {                    // two-output form (in_proj), see gemm256_kernel
+            if (C2 != nullptr) {                    // two-output form (in_proj): columns >= nsplit go to C2
                 const bool second = nb >= nsplit;
                 const int width = second ? N - nsplit : nsplit;
                 col = second ? nb - nsplit : nb;
@@ -970,7 +766,7 @@ __global__ __launch_bounds__(GEMMQ_THREADS, 1) void gemm256q_kernel(const T* __r
             const int nbase = n0 + wn * 128 + jg * 64;                 // wave-uniform
             char* lane_dst;
             int64_t row_step;                                          // bytes between rows m and m + 16
-            if (C2 != nullptr) {                                       // two-output form (in_proj), see gemm256_kernel
+            if (C2 != nullptr) {                                       // two-output form (in_proj): columns >= nsplit go to C2
                 const bool second = nbase >= nsplit;
                 const int width = second ? N - nsplit : nsplit;
                 const int col = (second ? nbase - nsplit : nbase) + lg * 16;
@@ -1124,7 +920,7 @@ static hipError_t launch_gemm256_t(const void* A, int64_t lda, const void* W, in
                                    bool out_blocked = false) {
     const int tiles_m = (int)((M + BM2 - 1) / BM2), tiles_n = (N + BN2 - 1) / BN2;
     dim3 grid((unsigned)persistent_grid(tiles_m * tiles_n)), block(GEMM_THREADS);
-    static const bool quad = getenv("PCAD_GEMM_NOQUAD") == nullptr;   // developer knob: the 8-wave kernels for A/B runs
+    static const bool quad = dev_env("PCAD_GEMM_NOQUAD") == nullptr;   // PCAD_DEV=1 only: the 8-wave kernel for A/B runs
     const int64_t esz_ = (int64_t)sizeof(T);
     if (quad && M % BM2 == 0 && N % BN2 == 0 && (C2 == nullptr || nsplit % 64 == 0) && M * lda * esz_ < ((int64_t)1 << 32) - 65536 &&
         (int64_t)N * ldw * esz_ < ((int64_t)1 << 32) - 65536) {     // unsigned 32-bit buffer offsets
@@ -1139,26 +935,14 @@ static hipError_t launch_gemm256_t(const void* A, int64_t lda, const void* W, in
                            tiles_m, tiles_n, (int)a_blocked, (T*)C2, nsplit, (int)out_blocked);
         return hipGetLastError();
     }
-    static const bool ring = getenv("PCAD_GEMM_NORING") == nullptr;   // developer knob: the 2-stage kernel for A/B runs
-    if (ring) {
-        auto kr = gemm256r_kernel<T, T>;
-        static bool attr_r = false;
-        if (!attr_r) {
-            hipError_t e = hipFuncSetAttribute((const void*)kr, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM3_LDS);
-            if (e != hipSuccess) return e;
-            attr_r = true;
-        }
-        hipLaunchKernelGGL(kr, grid, block, GEMM3_LDS, s, (const T*)A, lda, (const T*)W, ldw, (T*)C, ldc, M, N, K, tiles_m,
-                           tiles_n, (int)a_blocked, (T*)C2, nsplit, (int)out_blocked);
-        return hipGetLastError();
+    auto kr = gemm256r_kernel<T, T>;
+    static bool attr_r = false;
+    if (!attr_r) {
+        hipError_t e = hipFuncSetAttribute((const void*)kr, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM3_LDS);
+        if (e != hipSuccess) return e;
+        attr_r = true;
     }
-    auto kfn = gemm256_kernel<T, T>;
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM2_LDS);
-        attr_done = true;
-    }
-    hipLaunchKernelGGL(kfn, grid, block, GEMM2_LDS, s, (const T*)A, lda, (const T*)W, ldw, (T*)C, ldc, M, N, K, tiles_m,
+    hipLaunchKernelGGL(kr, grid, block, GEMM3_LDS, s, (const T*)A, lda, (const T*)W, ldw, (T*)C, ldc, M, N, K, tiles_m,
                        tiles_n, (int)a_blocked, (T*)C2, nsplit, (int)out_blocked);
     return hipGetLastError();
 }
@@ -1185,7 +969,7 @@ hipError_t launch_gemm_nt(const void* A, int64_t lda, const void* W, int64_t ldw
     if ((lda * esz) % 16 || (ldw * esz) % 16 || ((uintptr_t)A) % 16 || ((uintptr_t)W) % 16)
         return hipErrorInvalidValue;
     if (a_blocked && (lda * esz) % 128) return hipErrorInvalidValue;
-    static const bool no256 = getenv("PCAD_GEMM_NO256") != nullptr;      // developer knob: force the 256x128 kernel
+    static const bool no256 = dev_env("PCAD_GEMM_NO256") != nullptr;      // PCAD_DEV=1 only: force the 256x128 kernel
     const bool big = !no256 && M >= 2048 && N >= 512 && N % 16 == 0 && out_dt == dt &&
                      (ldc * esz) % 16 == 0 && ((uintptr_t)C) % 16 == 0;
     if (big) {

@@ -2,10 +2,18 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 namespace pcad {
 
 enum DType { F32 = 0, BF16 = 1 };
+
+// Developer A/B switches are environment variables that are honoured ONLY when PCAD_DEV=1 is also set; a production
+// process never changes behaviour because of a stray variable.  (Numerics / sizing options of the ABI: pcad_set_option.)
+inline const char* dev_env(const char* name) {
+    static const bool dev = [] { const char* d = getenv("PCAD_DEV"); return d && d[0] == '1'; }();
+    return dev ? getenv(name) : nullptr;
+}
 
 struct Positions {            // by-value kernel argument: the positions evaluated by the head kernel
     int n;                    // 0 => all L positions

@@ -43,6 +43,8 @@ SIGNATURES = {
     "pcad_last_error": (C.c_char_p, []),
     "pcad_create": (C.c_int, [C.POINTER(PcadConfig), C.POINTER(C.c_void_p)]),
     "pcad_destroy": (None, [C.c_void_p]),
+    "pcad_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int64]),
+    "pcad_set_aux_streams": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "pcad_weight_arena_bytes": (C.c_size_t, [C.c_void_p]),
     "pcad_bind_weights": (C.c_int, [C.c_void_p, C.POINTER(PcadTensor), C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
     "pcad_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int, C.c_int]),
@@ -138,6 +140,13 @@ class Engine:
         self._h = C.c_void_p()
         _check(self.lib.pcad_create(C.byref(cfg), C.byref(self._h)), "pcad_create")
         self._ws: Optional[torch.Tensor] = None
+        self._aux = None
+        for key, val in (getattr(config, "engine_options", None) or {}).items():
+            if key == "two_lanes":
+                if val:
+                    self.set_two_lanes(True)
+            else:
+                self.set_option(key, int(val))
         with torch.cuda.device(self.device):
             nbytes = self.lib.pcad_weight_arena_bytes(self._h)
             self._arena = torch.empty(nbytes + 256, dtype=torch.uint8, device=self.device)
@@ -189,6 +198,10 @@ class Engine:
             raise RuntimeError(f"input_ids on {input_ids.device}, engine on {self.device}")
         ids = input_ids.to(torch.int32).contiguous()
         B, L = ids.shape
+        V = int(self.config.padded_vocab_size)
+        if B and bool(((ids < 0) | (ids >= V)).any()):
+            # the reference's nn.Embedding raises an index error; the kernels would alias the id to another row (ids & 7)
+            raise IndexError(f"input_ids contain token ids outside [0, {V}): check the tokenizer's vocabulary against the model")
         D = self.config.d_model
         per_seq = None
         if torch.is_tensor(positions):
@@ -221,6 +234,23 @@ class Engine:
             _check(self.lib.pcad_forward(self._h, ids.data_ptr(), B, L, pos_arr, P, hp, lp, ws, ws_bytes,
                                          _stream_ptr()), "pcad_forward")
         return logits, hidden
+
+    def set_option(self, key: str, value: int):
+        """`pcad_set_option`: "chunk_seqs" (windows per pass through the stack), "gate_each" (reference-order SiLU gate)."""
+        _check(self.lib.pcad_set_option(self._h, key.encode(), int(value)), "pcad_set_option")
+        self._ws = None
+
+    def set_two_lanes(self, on: bool):
+        """Two-lane chunk pipeline on two torch-owned streams (`pcad_set_aux_streams`)."""
+        if on:
+            with torch.cuda.device(self.device):
+                self._aux = (torch.cuda.Stream(self.device), torch.cuda.Stream(self.device))
+            _check(self.lib.pcad_set_aux_streams(self._h, self._aux[0].cuda_stream, self._aux[1].cuda_stream),
+                   "pcad_set_aux_streams")
+        else:
+            _check(self.lib.pcad_set_aux_streams(self._h, None, None), "pcad_set_aux_streams")
+            self._aux = None
+        self._ws = None
 
     def profile(self, on):
         """False/0: off; True/1: HIP events around every launch; N > 1: around every N-th launch of each kernel class."""

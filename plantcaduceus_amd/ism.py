@@ -10,6 +10,7 @@ the same output), and the position to read is passed per window (`pcad_forward_a
   sweep_window(model, seq, tokenizer, device)          every position of ONE window masked in turn -> probs [L, 4]
   sweep_region(model, chrom_seq, start, stop, ...)     reference semantics: a window centred (tokenIdx 255) on every
                                                       position of [start, stop) -> probs [n, 4]
+  sweep_region_to_vcf(model, fasta, chrom, start, ...) streaming form of the above: chunked, indexed FASTA, rows appended
   ism_scores(probs, ref_bases)                         -> [n, 4] log(p_alt / p_ref), 0 for alt == ref, NaN where the
                                                       reference base is not A/C/G/T
 """
@@ -68,6 +69,45 @@ def sweep_region(model, chrom_seq: str, start: int, stop: int, tokenizer, device
     logging.info(f"ISM sweep over {stop - start} positions")
     seqs = [window_for(chrom_seq, p, tokenIdx) for p in range(start, stop)]
     return extract_logits(model, seqs, device, tokenIdx, tokenizer, batch_size)
+
+
+def sweep_region_to_vcf(model, fasta, chrom: str, start: int, stop: int, tokenizer, device, out_path: str,
+                        tokenIdx: int = 255, batch_size: int = 128, chunk: int = 65536) -> int:
+    """Streaming ISM driver: positions [start, stop) of `chrom` (0-based) in chunks of `chunk` positions — windows are cut
+    from the indexed FASTA (`zero_shot.FastaIndex`), scored (one masked forward per position, all four probabilities), and
+    the chunk's rows appended to `out_path` in the layout `1_simulation.R:110-127` emits (one row per position x alt != ref,
+    score in INFO).  Nothing larger than one chunk is ever held.  Under torch.distributed every rank computes its block of
+    each chunk and rank 0 writes.  Returns the number of rows written."""
+    from .zero_shot import FastaIndex, window_from_index
+    fa = fasta if isinstance(fasta, FastaIndex) else FastaIndex(fasta)
+    rank, _ = sharding.world()
+    stop = min(stop, fa.length(chrom))
+    rows = 0
+    out = open(out_path, "w") if rank == 0 else None
+    try:
+        if out:
+            out.write("##fileformat=VCFv4.2\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\n")
+        for c0 in range(start, stop, chunk):
+            c1 = min(stop, c0 + chunk)
+            seqs = [window_from_index(fa, chrom, p, tokenIdx) for p in range(c0, c1)]
+            probs = extract_logits(model, seqs, device, tokenIdx, tokenizer, batch_size)
+            refs = list(fa.fetch(chrom, c0, c1).upper())          # the reference base of each position, from the FASTA itself
+            sc = ism_scores(probs, refs)
+            if out:
+                for i, r in enumerate(refs):
+                    if r not in NUCLEOTIDES:
+                        continue
+                    for k, a in enumerate(NUCLEOTIDES):
+                        if a != r:
+                            out.write(f"{chrom}\t{c0 + i + 1}\t.\t{r}\t{a}\t.\t.\tplantCAD_zero_shot={sc[i, k]}\n")
+                            rows += 1
+                out.flush()
+    finally:
+        if out:
+            out.close()
+        if fa is not fasta:
+            fa.close()
+    return rows
 
 
 def ism_scores(probs: np.ndarray, ref_bases: Sequence[str]) -> np.ndarray:

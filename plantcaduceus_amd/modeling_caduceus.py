@@ -23,7 +23,7 @@ from torch import nn
 from transformers import PreTrainedModel
 from transformers.modeling_outputs import BaseModelOutputWithNoAttention, MaskedLMOutput
 
-from .checkpoint import load_state_dict
+from .checkpoint import load_state_dict, resolve_snapshot
 from .configuration_caduceus import CaduceusConfig
 from .engine import Engine
 
@@ -114,10 +114,8 @@ class CaduceusPreTrainedModel(PreTrainedModel):
     @classmethod
     def from_pretrained(cls, pretrained_model_name_or_path, *model_args, config=None, torch_dtype=None, dtype=None,
                         device_map=None, trust_remote_code=None, **kwargs):
-        path = str(pretrained_model_name_or_path)
-        if not os.path.isdir(path):
-            raise OSError(f"{path} is not a local snapshot directory (the engine runs offline: download the "
-                          "kuleshov-group/PlantCaduceus_l* snapshot and pass its directory)")
+        hub_kw = {k: kwargs[k] for k in ("revision", "cache_dir", "local_files_only", "token") if k in kwargs}
+        path = resolve_snapshot(pretrained_model_name_or_path, **hub_kw)     # directory, or a hub id via the HF cache
         if config is None:
             with open(os.path.join(path, "config.json")) as f:
                 raw = json.load(f)

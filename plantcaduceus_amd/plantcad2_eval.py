@@ -17,7 +17,8 @@ the reference's metric lines.  Pinned by `tests/golden/harness_plantcad2_metrics
 from __future__ import annotations
 
 import json
-from typing import Dict, Optional, Sequence, Union
+import logging
+from typing import Dict, List, Optional, Sequence, Union
 
 import numpy as np
 import torch
@@ -240,16 +241,28 @@ def evo_cons(data, model=None, tokenizer=None, device="cuda:0", token_idx: int =
     return _emit({"AUROC": auroc(y, sc), "AUPRC": average_precision(y, sc)}, metrics_json, {"token_idx": token_idx})
 
 
+def _positions(mask_idx, motif_len: int) -> List[int]:
+    """The reference pairs the probabilities — which `_masked_probs` returns in ASCENDING position order (a masked_select
+    over the sequence, :129-140) — with the true bases taken in the order the user gave `mask_idx`
+    (`_compute_true_tokens_from_seq(df[seq], positions)`, :414 / :518).  The same pairing is kept here so results are
+    identical on every input; with an unsorted `mask_idx` that pairing is inconsistent (in the reference too): warn."""
+    positions = [int(x) for x in mask_idx]
+    assert len(positions) == motif_len, "mask_idx count must equal motif_len"
+    if positions != sorted(positions):
+        logging.warning("mask_idx %s is not ascending: probabilities come out in ascending position order but true bases are "
+                        "read in the given order (reference behaviour) - sort mask_idx", positions)
+    return positions
+
+
 def motif_acc(data, model=None, tokenizer=None, device="cuda:0", mask_idx: Sequence[int] = (255, 256, 257), motif_len: int = 3,
               batch_size: int = 128, seq_column: str = "sequence", save_logits=None, logits_path=None,
               metrics_json=None) -> Dict[str, float]:
     """:374-428 - multi-position masking; token and whole-motif accuracy."""
     df = _frame(data)
-    positions = [int(x) for x in mask_idx]
-    assert len(positions) == motif_len, "mask_idx count must equal motif_len"
+    positions = _positions(mask_idx, motif_len)
     probs = _probs_or_infer(df[seq_column], model, tokenizer, device, positions, batch_size, logits_path, save_logits)
     assert probs.shape[0] == len(df) * len(positions), f"Row mismatch: probs={probs.shape[0]} expected={len(df) * len(positions)}"
-    tt = true_tokens(df[seq_column], sorted(positions))
+    tt = true_tokens(df[seq_column], positions)
     return _emit({"token_accuracy": token_accuracy(probs, tt), "motif_accuracy": motif_accuracy(probs, tt, motif_len)},
                  metrics_json)
 
@@ -257,14 +270,15 @@ def motif_acc(data, model=None, tokenizer=None, device="cuda:0", mask_idx: Seque
 def core_noncore(data, model=None, tokenizer=None, device="cuda:0", mask_idx: Sequence[int] = (255, 256, 257),
                  motif_len: int = 3, batch_size: int = 128, seq_column: str = "sequence", label_column: str = "label",
                  save_logits=None, logits_path=None, metrics_json=None) -> Dict[str, float]:
-    """:478-530 - AUROC of the mean true-base probability over the masked positions against `label_column`."""
+    """:478-530 - AUROC and AUPRC of the mean true-base probability over the masked positions against `label_column`
+    (printed as `AUROC` / `AUPRC`, metrics_json keys `auroc` / `auprc`: :523-530)."""
     df = _frame(data)
-    positions = [int(x) for x in mask_idx]
-    assert len(positions) == motif_len, "mask_idx count must equal motif_len"
+    positions = _positions(mask_idx, motif_len)
     probs = _probs_or_infer(df[seq_column], model, tokenizer, device, positions, batch_size, logits_path, save_logits)
     assert probs.shape[0] == len(df) * len(positions)
-    sc = avg_trueprob_scores(probs, true_tokens(df[seq_column], sorted(positions)), motif_len)
-    return _emit({"AUROC": auroc(df[label_column].astype(int).to_numpy(), sc)}, metrics_json)
+    sc = avg_trueprob_scores(probs, true_tokens(df[seq_column], positions), motif_len)
+    y = df[label_column].astype(int).to_numpy()
+    return _emit({"AUROC": auroc(y, sc), "AUPRC": average_precision(y, sc)}, metrics_json)
 
 
 def sv_effect(data, model, tokenizer, device="cuda:0", batch_size: int = 64, flanking: int = 5, output=None,

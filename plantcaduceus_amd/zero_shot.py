@@ -9,7 +9,9 @@ function by function (same names, argument meaning, flags and output conventions
   extract_logits             :107-121  batched forward, logits[:, tokenIdx, ids(a,c,g,t)], softmax over 4 -> [N,4]
   zero_shot_score            :124-134  log(p[alt] / p[ref]), nucleotide order A,C,G,T
   zero_shot_score_vcf        :137-169  INFO/plantCAD_zero_shot = comma-joined per-ALT scores, "." for non-SNV
-  seq_from_vcf               :172-214  windows [pos-tokenIdx, pos+512-tokenIdx), upper-cased, N-padded
+  seq_from_vcf               :172-214  windows [pos-tokenIdx, pos+512-tokenIdx), upper-cased, N-padded; `windows_from_vcf`
+                                       is the de-duplicated form main() uses (one forward per distinct (chrom, pos));
+                                       FASTA through `FastaIndex` (.fai seek + slice, no whole-genome dict)
   main                       :217-259  TSV / BED / VCF outputs
 
 Differences, all on the host side: probabilities stay on the device until the end (one D2H copy per call
@@ -106,9 +108,25 @@ def load_model_and_tokenizer(model_dir: str, device: str):
     except Exception as e:   # same fallback as the reference (:90-94)
         logging.error(f"Failed to load model with {dtype}, falling back to float32. Error: {e}")
         model = CaduceusForMaskedLM.from_pretrained(model_dir, trust_remote_code=True, torch_dtype=torch.float32)
-    tokenizer = CaduceusTokenizer.from_pretrained(model_dir) if _has_vocab(model_dir) else CaduceusTokenizer()
+    from .checkpoint import resolve_snapshot
+    snap = resolve_snapshot(model_dir)
+    tokenizer = CaduceusTokenizer.from_pretrained(snap) if _has_vocab(snap) else CaduceusTokenizer()
+    check_vocab_matches_complement(tokenizer, model.config)
     model.to(device)
     return model, tokenizer
+
+
+def check_vocab_matches_complement(tokenizer, config):
+    """The RCPS wiring pairs token ids through config.complement_map; a tokenizer whose a/c/g/t ids do not follow it (a
+    snapshot with a different vocab.json than the model was trained with) would silently score the wrong bases."""
+    v = tokenizer.get_vocab()
+    comp = config.complement_list()
+    for x, y in (("a", "t"), ("c", "g")):
+        if x not in v or y not in v or max(v[x], v[y]) >= len(comp) or comp[v[x]] != v[y] or comp[v[y]] != v[x]:
+            raise ValueError(f"tokenizer vocabulary {dict((k, v.get(k)) for k in 'acgt')} is inconsistent with the model's "
+                             f"complement_map {comp}")
+    if tokenizer.mask_token_id is None or tokenizer.mask_token_id >= len(comp):
+        raise ValueError("tokenizer has no usable [MASK] id for this model")
 
 
 def _has_vocab(model_dir: str) -> bool:
@@ -160,7 +178,8 @@ def zero_shot_score(snpDF, logits) -> List[float]:
 
 # ---- a16: VCF + FASTA -> windows ----------------------------------------------------------------------
 def read_fasta(path: str) -> Dict[str, str]:
-    """name (first word of the header) -> sequence, case preserved."""
+    """name (first word of the header) -> sequence, case preserved.  Whole-file read: only used for gzip input
+    (not seekable); plain FASTA goes through `FastaIndex`."""
     opener = gzip.open if path.endswith(".gz") else open
     out: Dict[str, List[str]] = {}
     name = None
@@ -172,6 +191,92 @@ def read_fasta(path: str) -> Dict[str, str]:
             elif name is not None:
                 out[name].append(line.strip())
     return {k: "".join(v) for k, v in out.items()}
+
+
+class FastaIndex:
+    """Random access to a FASTA by (name, start, stop) through a samtools-style index — no whole-genome dict
+    (the reference loads every chromosome into memory with BioPython, src/zero_shot_score.py:176-180).
+
+    `<fasta>.fai` (name, length, offset, linebases, linewidth per line; what `samtools faidx` writes and
+    reference src/format_VCF.sh:23 creates) is used when present; otherwise the same five columns are built by one
+    streaming pass over the file (never holding more than a line).  `fetch` is a seek + read of the covering bytes with the
+    line terminators removed.  A .gz FASTA is not seekable: it is read whole (`read_fasta`)."""
+
+    def __init__(self, path: str):
+        self.path = path
+        self._mem: Optional[Dict[str, str]] = None
+        self.index: Dict[str, Tuple[int, int, int, int]] = {}       # name -> (length, offset, linebases, linewidth)
+        if path.endswith(".gz"):
+            self._mem = read_fasta(path)
+            self._fh = None
+            return
+        import os
+        fai = path + ".fai"
+        if os.path.exists(fai) and os.path.getmtime(fai) >= os.path.getmtime(path):
+            with open(fai) as f:
+                for line in f:
+                    c = line.rstrip("\n").split("\t")
+                    if len(c) >= 5:
+                        self.index[c[0]] = (int(c[1]), int(c[2]), int(c[3]), int(c[4]))
+        else:
+            self.index = self.build_index(path)
+        self._fh = open(path, "rb")
+
+    @staticmethod
+    def build_index(path: str) -> Dict[str, Tuple[int, int, int, int]]:
+        idx: Dict[str, Tuple[int, int, int, int]] = {}
+        name = None
+        length = offset = linebases = linewidth = 0
+        short_seen = False
+        pos = 0
+        with open(path, "rb") as f:
+            for raw in f:
+                if raw.startswith(b">"):
+                    if name is not None:
+                        idx[name] = (length, offset, linebases, linewidth)
+                    w = raw[1:].split()
+                    name = w[0].decode("latin-1") if w else ""
+                    length, offset, linebases, linewidth, short_seen = 0, pos + len(raw), 0, 0, False
+                elif name is not None:
+                    body = raw.rstrip(b"\r\n")
+                    if body or raw:
+                        if linebases == 0 and body:
+                            linebases, linewidth = len(body), len(raw)
+                        elif body:
+                            if short_seen or len(body) > linebases:
+                                raise ValueError(f"{path}: sequence {name} has lines of unequal length; cannot index")
+                            if len(body) < linebases:
+                                short_seen = True        # only the last line of a record may be short
+                        length += len(body)
+                pos += len(raw)
+        if name is not None:
+            idx[name] = (length, offset, linebases, linewidth)
+        return idx
+
+    def __contains__(self, name: str) -> bool:
+        return name in (self._mem if self._mem is not None else self.index)
+
+    def length(self, name: str) -> int:
+        return len(self._mem[name]) if self._mem is not None else self.index[name][0]
+
+    def fetch(self, name: str, start: int, stop: int) -> str:
+        """bases [start, stop) of `name`, clipped to [0, length), case preserved (Python slice semantics for start >= 0)."""
+        if self._mem is not None:
+            return self._mem[name][max(0, start):max(0, stop)]
+        length, offset, lb, lw = self.index[name]
+        start, stop = max(0, start), min(stop, length)
+        if stop <= start or lb == 0:
+            return ""
+        b0 = offset + (start // lb) * lw + start % lb
+        b1 = offset + ((stop - 1) // lb) * lw + (stop - 1) % lb + 1
+        self._fh.seek(b0)
+        raw = self._fh.read(b1 - b0)
+        return raw.replace(b"\n", b"").replace(b"\r", b"").decode("latin-1")
+
+    def close(self):
+        if self._fh is not None:
+            self._fh.close()
+            self._fh = None
 
 
 def iter_vcf(path: str):
@@ -201,26 +306,55 @@ def window_for(chrom_seq: str, pos0: int, tokenIdx: int, length: int = 512) -> s
     return chrom_seq[pos0 - tokenIdx:pos0 + add].upper().ljust(length, "N")
 
 
-def seq_from_vcf(args) -> Tuple[List[str], List[int]]:
+def window_from_index(fa: FastaIndex, chrom: str, pos0: int, tokenIdx: int, length: int = 512) -> str:
+    """`window_for` on an indexed FASTA: only the window's bytes are read."""
+    add = length - tokenIdx
+    if pos0 - tokenIdx < 0:
+        return fa.fetch(chrom, 0, pos0 + add).upper().rjust(length, "N")
+    return fa.fetch(chrom, pos0 - tokenIdx, pos0 + add).upper().ljust(length, "N")
+
+
+def windows_from_vcf(args) -> Tuple[List[str], List[int], List[int]]:
+    """-> (unique_windows, recordIndices, inverse).  One window per DISTINCT (chrom, pos) among the records with an SNV ALT
+    (the window depends on nothing else); `inverse[k]` is the window of the k-th scored record.  The reference makes one
+    window and one forward per record (src/zero_shot_score.py:189-201) — its in-silico-mutagenesis pipeline emits three
+    records per position (pipelines/in-silico-mutagenesis/1_simulation.R:85-100), i.e. three identical forwards."""
     logging.info(f"Reading input data from {args.inputVCF}")
-    fasta = read_fasta(args.inputFasta)
-    sequences, recordIndices = [], []
+    fa = FastaIndex(args.inputFasta)
+    uniq: List[str] = []
+    key_to_u: Dict[Tuple[str, int], int] = {}
+    recordIndices: List[int] = []
+    inverse: List[int] = []
     recordIdx = 0
-    for line, f in iter_vcf(args.inputVCF):
-        if f is None:
-            continue
-        alts = f[4].split(",")
-        if any(_is_snv(a) for a in alts):
-            chrom, pos0 = f[0], int(f[1]) - 1
-            if chrom not in fasta:
-                print("Error processing VCF at record " + str(recordIdx))
-                print("Check that VCF file is sorted and chromosome names match FASTA file.")
-                print(line)
-                sys.exit()
-            sequences.append(window_for(fasta[chrom], pos0, args.tokenIdx))
-            recordIndices.append(recordIdx)
-        recordIdx += 1
-    return sequences, recordIndices
+    try:
+        for line, f in iter_vcf(args.inputVCF):
+            if f is None:
+                continue
+            alts = f[4].split(",")
+            if any(_is_snv(a) for a in alts):
+                chrom, pos0 = f[0], int(f[1]) - 1
+                if chrom not in fa:
+                    print("Error processing VCF at record " + str(recordIdx))
+                    print("Check that VCF file is sorted and chromosome names match FASTA file.")
+                    print(line)
+                    sys.exit()
+                u = key_to_u.get((chrom, pos0))
+                if u is None:
+                    u = key_to_u[(chrom, pos0)] = len(uniq)
+                    uniq.append(window_from_index(fa, chrom, pos0, args.tokenIdx))
+                inverse.append(u)
+                recordIndices.append(recordIdx)
+            recordIdx += 1
+    finally:
+        fa.close()
+    logging.info(f"{len(recordIndices)} scored records -> {len(uniq)} distinct windows")
+    return uniq, recordIndices, inverse
+
+
+def seq_from_vcf(args) -> Tuple[List[str], List[int]]:
+    """The reference's return value (:172-214): one window per scored record, in record order."""
+    uniq, recordIndices, inverse = windows_from_vcf(args)
+    return [uniq[u] for u in inverse], recordIndices
 
 
 def zero_shot_score_vcf(args, recordIndices, logits):
@@ -265,9 +399,11 @@ def main(argv: Optional[Sequence[str]] = None):
         snpDF = snpDF[ok].copy()
         sequences = snpDF["sequences"].tolist()
     else:
-        sequences, recordIndices = seq_from_vcf(args)
+        sequences, recordIndices, inverse = windows_from_vcf(args)        # one forward per distinct (chrom, pos)
     model, tokenizer = load_model_and_tokenizer(args.model, args.device)
     logits = extract_logits(model, sequences, args.device, args.tokenIdx, tokenizer, args.batchSize)
+    if args.inputDF is None:
+        logits = logits[np.asarray(inverse, dtype=np.int64)] if len(inverse) else logits[:0]      # fan back out per record
     rank, _ = sharding.world()
     if rank != 0:
         return

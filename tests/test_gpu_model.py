@@ -10,8 +10,9 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
-def build(cfg, sd, dtype):
+def build(cfg, sd, dtype, **engine_options):
     from plantcaduceus_amd.modeling_caduceus import CaduceusForMaskedLM
+    cfg.engine_options = dict(engine_options)        # pcad_set_option / pcad_set_aux_streams at engine creation
     m = CaduceusForMaskedLM(cfg)
     m.load_state_dict(sd, strict=False)
     m.tie_weights()
@@ -94,20 +95,20 @@ def test_rc_equivariance_property_full_size():
     assert ((hb.flip(1, 2) - ha).abs().max() / ha.abs().max()).item() < 1e-4
 
 
-def test_batch_chunking_and_empty_and_all_hidden(monkeypatch):
+def test_batch_chunking_and_empty_and_all_hidden():
     cfg = make_config("x", d_model=64, n_layer=2)
     sd = synthetic_state_dict(cfg, seed=2)
     ids = rand_ids(7, 32, 21)
-    monkeypatch.setenv("PCAD_CHUNK_SEQS", "3")   # 7 sequences -> chunks 3,3,1
-    m = build(cfg, sd, torch.float32)
+    m = build(cfg, sd, torch.float32, chunk_seqs=3)                  # 7 sequences -> chunks 3,3,1
     lg = m(input_ids=ids.to(DEV)).logits.cpu()
-    monkeypatch.setenv("PCAD_STREAMS", "2")      # same chunks alternating between the two library streams
-    m1 = build(cfg, sd, torch.float32)
+    m1 = build(cfg, sd, torch.float32, chunk_seqs=3, two_lanes=True)  # same chunks alternating between two caller-owned aux streams
     assert torch.equal(lg, m1(input_ids=ids.to(DEV)).logits.cpu())
-    monkeypatch.setenv("PCAD_STREAMS", "1")
-    monkeypatch.setenv("PCAD_CHUNK_SEQS", "64")
-    m2 = build(cfg, sd, torch.float32)
+    m2 = build(cfg, sd, torch.float32, chunk_seqs=64)
     assert torch.equal(lg, m2(input_ids=ids.to(DEV)).logits.cpu())
+    # the reference-order gate (each direction gated and rounded) is the same function in fp32 up to rounding
+    m4 = build(cfg, sd, torch.float32, gate_each=1)
+    lg4 = m4(input_ids=ids.to(DEV)).logits.cpu()
+    assert ((lg4 - lg).abs().max() / lg.abs().max()).item() < 1e-5
     # ragged / empty
     assert m2(input_ids=ids[:0].to(DEV)).logits.shape == (0, 32, 8)
     # full hidden-state tuple vs literal-RCPS oracle
@@ -150,7 +151,7 @@ def test_long_window_8192():
     assert (lg[:, 0, 3:7].argmax(-1) == lg_ref[:, 4095, 3:7].argmax(-1)).all()
 
 
-def test_maximum_chunk_bit_identical_to_small_chunks(monkeypatch):
+def test_maximum_chunk_bit_identical_to_small_chunks():
     """maximum sizes: at the l32 width one default chunk is 512 windows = 524 288 token-rows, whose x / xc / y tensors are
     2 GiB each, so the kernels' unsigned 32-bit byte offsets run past 2^31.  Rows are independent, so the result must be
     bit-identical to the same batch walked in 64-window chunks."""
@@ -158,7 +159,6 @@ def test_maximum_chunk_bit_identical_to_small_chunks(monkeypatch):
     sd = synthetic_state_dict(cfg, seed=8)
     ids = rand_ids(520, 512, 77, mask=255)           # 520 -> chunks of 260 + 260 by default; rows of the 2nd half past 2^31 B / 2
     pos = [255, 0, 511]
-    monkeypatch.delenv("PCAD_CHUNK_SEQS", raising=False)
     big = build(cfg, sd, torch.bfloat16)
     a = big(input_ids=ids[:512].to(DEV), output_hidden_states=True, positions=pos)       # ONE chunk of 512 windows
     b = big(input_ids=ids.to(DEV), output_hidden_states=True, positions=pos)
@@ -166,8 +166,7 @@ def test_maximum_chunk_bit_identical_to_small_chunks(monkeypatch):
     lb, hb = b.logits.cpu(), b.hidden_states[-1].float().cpu()
     del big, a, b
     torch.cuda.empty_cache()
-    monkeypatch.setenv("PCAD_CHUNK_SEQS", "64")
-    small = build(cfg, sd, torch.bfloat16)
+    small = build(cfg, sd, torch.bfloat16, chunk_seqs=64)
     c = small(input_ids=ids.to(DEV), output_hidden_states=True, positions=pos)
     lc, hc = c.logits.cpu(), c.hidden_states[-1].float().cpu()
     assert torch.isfinite(lc).all()

@@ -196,7 +196,48 @@ def test_plantcad2_task_metrics_match_reference(golden_dir, tmp_path, capsys):
     assert json.load(open(tmp_path / "m.json"))["token_idx"] == ti
     m = pe.motif_acc(df, mask_idx=pos, motif_len=ml, logits_path=str(p3))
     assert m["motif_accuracy"] == pytest.approx(float(g["motif_acc"]), abs=1e-9)
-    m = pe.core_noncore(df, mask_idx=pos, motif_len=ml, logits_path=str(p3))
+    m = pe.core_noncore(df, mask_idx=pos, motif_len=ml, logits_path=str(p3), metrics_json=str(tmp_path / "c.json"))
     assert m["AUROC"] == pytest.approx(float(g["auroc_avgtrue"]), abs=1e-9)
+    assert m["AUPRC"] == pytest.approx(float(g["auprc_avgtrue"]), abs=1e-9)          # the reference reports both (:523-530)
+    assert set(json.load(open(tmp_path / "c.json"))) == {"auroc", "auprc"}
     out = capsys.readouterr().out
     assert "AUROC\t" in out and "token_accuracy\t" in out and "motif_accuracy\t" in out
+
+
+def test_config1_l20_64_windows_through_cli(tmp_path, monkeypatch):
+    """BASELINE config 1 at its stated size: PlantCaduceus_l20 (384-d, 20 layers) CPU forward on 64 synthetic
+    512-bp sequences (iid ACGT, default_rng(0)), ref/alt drawn with default_rng(1), mask index 255, synthetic checkpoint seed
+    1234, through the zero_shot_score-compatible CLI with -device cpu — plumbing, no GPU.  The model behind the HF surface is
+    the C oracle port (the product engine has no CPU path by design); scores are checked against probabilities computed
+    outside the CLI."""
+    from oracle.c_oracle import COracle, COracleForMaskedLM
+    rng = np.random.default_rng(0)
+    seqs = ["".join(rng.choice(list("ACGT"), size=512)) for _ in range(64)]
+    r1 = np.random.default_rng(1)
+    ref = [s[255] for s in seqs]
+    alt = [r1.choice([c for c in "ACGT" if c != r]) for r in ref]
+    inp, out = tmp_path / "in.tsv", tmp_path / "out.tsv"
+    pd.DataFrame({"chr": "chr1", "start": np.arange(64), "end": np.arange(64) + 512, "pos": np.arange(64) + 256, "ref": ref,
+                  "alt": alt, "sequences": seqs}).to_csv(inp, sep="\t", index=False)
+    cfg = make_config("l20")
+    assert (cfg.d_model, cfg.n_layer) == (384, 20)
+    sd = synthetic_state_dict(cfg, seed=1234, stress=False)
+    tok = CaduceusTokenizer()
+    model = COracleForMaskedLM(sd, cfg, blas=True)
+    monkeypatch.setattr(zero_shot, "load_model_and_tokenizer", lambda d, dev: (model, tok))
+    zero_shot.main(["-input-table", str(inp), "-output", str(out), "-model", "PlantCaduceus_l20", "-device", "cpu",
+                    "-batchSize", "32"])
+    res = pd.read_csv(out, delimiter="\t")
+    assert len(res) == 64 and np.isfinite(res["zeroShotScore"]).all()
+    k = 16                                                               # rows re-computed outside the CLI
+    ids = tok.encode_batch(seqs[:k], mask_index=255)
+    lg, _ = COracle(sd, cfg, blas=True).forward(ids)
+    z = lg[:, 255, 3:7].astype(np.float64)
+    p = np.exp(z - z.max(1, keepdims=True))
+    p /= p.sum(1, keepdims=True)
+    want = np.log(p[np.arange(k), ["ACGT".index(a) for a in alt[:k]]] / p[np.arange(k), ["ACGT".index(r) for r in ref[:k]]])
+    np.testing.assert_allclose(res["zeroShotScore"].to_numpy()[:k], want, rtol=1e-4, atol=1e-5)
+    assert np.abs(want).max() > 1e-2                                     # a real signal, not a constant
+    # the BLAS-backed and the plain-C GEMM forms of the port agree at full depth
+    lg2, _ = COracle(sd, cfg).forward(ids[:2])
+    assert np.abs(lg2 - lg[:2]).max() / np.abs(lg[:2]).max() < 1e-4

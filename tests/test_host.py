@@ -103,3 +103,45 @@ def test_engine_requires_gpu_and_library():
     cfg = make_config("x", d_model=64, n_layer=1)
     with pytest.raises(RuntimeError, match="ROCm device"):
         engine.Engine(cfg, synthetic_state_dict(cfg), torch.float32, torch.device("cpu"))
+
+
+def test_hub_id_resolution_and_sharded_checkpoint(tmp_path, monkeypatch):
+    """-model may be a hub id (reference README / CLI): resolved through huggingface_hub (offline here: a clear OSError);
+    sharded *.safetensors.index.json snapshots load like single-file ones."""
+    import json
+    import torch
+    from safetensors.torch import save_file
+    from plantcaduceus_amd import checkpoint as ck
+    with pytest.raises(OSError, match="neither a local snapshot directory nor a HF-hub repo"):
+        ck.resolve_snapshot("kuleshov-group/PlantCaduceus_l32")
+    d = str(tmp_path / "snap")
+    cfg, sd = ck.make_synthetic_checkpoint(d, "x", seed=3, d_model=64, n_layer=2)
+    assert ck.resolve_snapshot(d) == d
+    full = ck.load_state_dict(d)
+    # re-write as two shards + index
+    os.remove(os.path.join(d, "model.safetensors"))
+    keys = sorted(k for k in full if k != ck.LMHEAD_KEY and ".mamba_rev.in_proj." not in k and ".mamba_rev.out_proj." not in k)
+    half = len(keys) // 2
+    wm = {}
+    for i, part in enumerate((keys[:half], keys[half:])):
+        fn = f"model-0000{i + 1}-of-00002.safetensors"
+        save_file({k: full[k].contiguous().clone() for k in part}, os.path.join(d, fn))
+        wm.update({k: fn for k in part})
+    json.dump({"metadata": {}, "weight_map": wm}, open(os.path.join(d, "model.safetensors.index.json"), "w"))
+    sharded = ck.load_state_dict(d)
+    assert set(sharded) == set(full) and all(torch.equal(sharded[k], full[k]) for k in full)
+    # a hub id that IS in the (mocked) cache resolves to its directory
+    import huggingface_hub
+    monkeypatch.setattr(huggingface_hub, "snapshot_download", lambda repo_id, **kw: d)
+    assert ck.resolve_snapshot("kuleshov-group/PlantCaduceus_l20") == d
+
+
+def test_tokenizer_vocab_must_match_complement_map():
+    from plantcaduceus_amd import zero_shot
+    from plantcaduceus_amd.checkpoint import make_config
+    from plantcaduceus_amd.tokenization_caduceus import CaduceusTokenizer
+    cfg = make_config("x", d_model=64, n_layer=1)
+    zero_shot.check_vocab_matches_complement(CaduceusTokenizer(), cfg)
+    bad = CaduceusTokenizer(vocab={"[PAD]": 0, "[MASK]": 1, "[UNK]": 2, "a": 3, "c": 4, "t": 5, "g": 6})
+    with pytest.raises(ValueError, match="inconsistent"):
+        zero_shot.check_vocab_matches_complement(bad, cfg)

@@ -1,0 +1,189 @@
+"""Host side of the -input-vcf path: indexed FASTA reads, (chrom, pos) de-duplication, streaming ISM
+writer.  CPU tests with the oracle stand-in as the model; one -m gpu run of the command line."""
+import gzip
+import os
+import types
+
+import numpy as np
+import pandas as pd
+import pytest
+import torch
+
+from oracle import caduceus_oracle as O
+from plantcaduceus_amd import ism, zero_shot
+from plantcaduceus_amd.checkpoint import make_config, make_synthetic_checkpoint, synthetic_state_dict
+from plantcaduceus_amd.tokenization_caduceus import CaduceusTokenizer
+
+
+def _genome(seed=0):
+    rng = np.random.default_rng(seed)
+    mk = lambda n: "".join(rng.choice(list("ACGTacgtN"), size=n, p=[.2, .2, .2, .2, .04, .04, .04, .04, .04]))
+    return {"chr1": mk(1500), "chr2": mk(61), "scaf_3": mk(700), "empty": ""}
+
+
+def _write_fasta(path, genome, width=60, crlf=False):
+    nl = "\r\n" if crlf else "\n"
+    with open(path, "w", newline="") as f:
+        for name, seq in genome.items():
+            f.write(f">{name} description words{nl}")
+            for i in range(0, len(seq), width):
+                f.write(seq[i:i + width] + nl)
+
+
+@pytest.mark.parametrize("width,crlf", [(60, False), (61, False), (7, True)])
+def test_fasta_index_fetch_equals_slicing(tmp_path, width, crlf):
+    g = _genome()
+    fa = tmp_path / "g.fa"
+    _write_fasta(fa, g, width, crlf)
+    fx = zero_shot.FastaIndex(str(fa))
+    rng = np.random.default_rng(1)
+    for name, seq in g.items():
+        assert name in fx and fx.length(name) == len(seq)
+        for _ in range(50):
+            a, b = sorted(rng.integers(-5, len(seq) + 20, size=2))
+            assert fx.fetch(name, int(a), int(b)) == seq[max(0, a):max(0, b)], (name, a, b)
+        assert fx.fetch(name, 0, len(seq)) == seq
+    assert "chrX" not in fx
+    # windows == the whole-string form on every position incl. both chromosome ends
+    for name in ("chr1", "chr2"):
+        for pos in list(range(0, 5)) + [len(g[name]) // 2] + list(range(len(g[name]) - 5, len(g[name]))):
+            for tidx in (255, 0, 511):
+                assert zero_shot.window_from_index(fx, name, pos, tidx) == zero_shot.window_for(g[name], pos, tidx)
+    fx.close()
+    # a samtools-style .fai next to the file is used as is
+    with open(str(fa) + ".fai", "w") as f:
+        for name, (length, off, lb, lw) in zero_shot.FastaIndex.build_index(str(fa)).items():
+            f.write(f"{name}\t{length}\t{off}\t{lb}\t{lw}\n")
+    fy = zero_shot.FastaIndex(str(fa))
+    assert fy.fetch("scaf_3", 100, 300) == g["scaf_3"][100:300]
+    fy.close()
+
+
+def test_fasta_index_gz_and_ragged(tmp_path):
+    g = _genome(3)
+    fa = tmp_path / "g.fa"
+    _write_fasta(fa, g)
+    with open(fa, "rb") as f, gzip.open(str(fa) + ".gz", "wb") as z:
+        z.write(f.read())
+    fz = zero_shot.FastaIndex(str(fa) + ".gz")
+    assert fz.fetch("chr1", 10, 700) == g["chr1"][10:700] and fz.length("chr2") == 61
+    bad = tmp_path / "bad.fa"
+    bad.write_text(">a\nACGT\nAC\nACGT\n")
+    with pytest.raises(ValueError, match="unequal"):
+        zero_shot.FastaIndex(str(bad))
+
+
+class _Counting:
+    """oracle stand-in that counts the windows it is asked to run"""
+
+    def __init__(self, model):
+        self.model, self.rows = model, 0
+
+    def __call__(self, input_ids=None, **kw):
+        self.rows += int(input_ids.shape[0])
+        return self.model(input_ids=input_ids, **kw)
+
+
+def _ism_vcf(path, genome, chrom, start, stop, extra=()):
+    """three rows per position like pipelines/in-silico-mutagenesis/1_simulation.R:85-100, plus `extra` records"""
+    rows = []
+    for p in range(start, stop):
+        r = genome[chrom][p].upper()
+        if r not in "ACGT":
+            continue
+        for a in "ACGT":
+            if a != r:
+                rows.append((chrom, p + 1, r, a))
+    rows += list(extra)
+    with open(path, "w") as f:
+        f.write("##fileformat=VCFv4.2\n##source=test\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\n")
+        for c, p, r, a in rows:
+            f.write(f"{c}\t{p}\t.\t{r}\t{a}\t.\tPASS\t.\n")
+    return rows
+
+
+def test_vcf_dedup_output_identical_to_per_record_path(tmp_path, monkeypatch):
+    g = _genome(5)
+    fa, vcf = tmp_path / "g.fa", tmp_path / "ism.vcf"
+    _write_fasta(fa, g)
+    extra = [("chr2", 5, g["chr2"][4].upper() if g["chr2"][4].upper() in "ACGT" else "A", "C,G"),     # multi-allelic
+             ("chr1", 700, "AT", "A"),                                   # ALT typed SNV by PyVCF (type is by ALT): scored, "."
+             ("chr2", 5, "A", "<DEL>"),                                                              # symbolic
+             ("chr1", 2, g["chr1"][1].upper(), "T")]
+    rows = _ism_vcf(vcf, g, "chr1", 690, 700, extra)
+    cfg = make_config("x", d_model=32, n_layer=1)
+    base = O.OracleForMaskedLM(O.params_from_state_dict(synthetic_state_dict(cfg, seed=3), cfg))
+    tok = CaduceusTokenizer()
+    args = types.SimpleNamespace(inputVCF=str(vcf), inputFasta=str(fa), tokenIdx=255)
+    uniq, ridx, inv = zero_shot.windows_from_vcf(args)
+    seqs, ridx2 = zero_shot.seq_from_vcf(args)
+    assert ridx == ridx2 and [uniq[u] for u in inv] == seqs
+    n_scored = len(rows) - 1                                             # only the symbolic ALT is not an SNV-typed record
+    assert len(seqs) == n_scored and len(uniq) < len(seqs) / 2.5          # ~3 records per position
+    assert len(set(uniq)) == len(uniq) or True                          # distinct positions may still share a sequence
+    # through main(): de-duplicated
+    cnt = _Counting(base)
+    monkeypatch.setattr(zero_shot, "load_model_and_tokenizer", lambda d, dev: (cnt, tok))
+    out1 = tmp_path / "o1.vcf"
+    zero_shot.main(["-input-vcf", str(vcf), "-input-fasta", str(fa), "-output", str(out1), "-model", "x", "-device", "cpu"])
+    assert cnt.rows == len(uniq)
+    # the reference's way: one forward per record
+    cnt2 = _Counting(base)
+    a2 = types.SimpleNamespace(inputVCF=str(vcf), inputFasta=str(fa), tokenIdx=255, output=str(tmp_path / "o2.vcf"))
+    probs = zero_shot.extract_logits(cnt2, seqs, "cpu", 255, tok, 128)
+    zero_shot.zero_shot_score_vcf(a2, ridx2, probs)
+    assert cnt2.rows == len(seqs)
+    assert open(out1, "rb").read() == open(a2.output, "rb").read()       # byte-identical output
+    body = [l for l in open(out1).read().splitlines() if not l.startswith("#")]
+    assert len(body) == n_scored and body[-1].split("\t")[7].startswith("plantCAD_zero_shot=")
+    multi = [l for l in body if l.split("\t")[4] == "C,G"][0].split("plantCAD_zero_shot=")[1]
+    assert len(multi.split(",")) == 2
+
+
+def test_streaming_region_sweep_equals_in_memory(tmp_path):
+    g = _genome(7)
+    fa = tmp_path / "g.fa"
+    _write_fasta(fa, g)
+    cfg = make_config("x", d_model=32, n_layer=1)
+    model = O.OracleForMaskedLM(O.params_from_state_dict(synthetic_state_dict(cfg, seed=3), cfg))
+    tok = CaduceusTokenizer()
+    a, b = 40, 61                                                        # runs into the end of chr2 (right N padding)
+    out = tmp_path / "s.vcf"
+    n = ism.sweep_region_to_vcf(model, str(fa), "chr2", a, 80, tok, "cpu", str(out), batch_size=8, chunk=6)
+    probs = ism.sweep_region(model, g["chr2"], a, b, tok, "cpu", batch_size=8)
+    refs = [c.upper() for c in g["chr2"][a:b]]
+    want = tmp_path / "w.vcf"
+    ism.write_ism_vcf(str(want), "chr2", a, refs, ism.ism_scores(probs, refs))
+    got_rows = [l.split("\t") for l in open(out).read().splitlines() if not l.startswith("#")]
+    want_rows = [l.split("\t") for l in open(want).read().splitlines() if not l.startswith("#")]
+    assert n == len(got_rows) == len(want_rows)
+    for x, y in zip(got_rows, want_rows):
+        assert x[:7] == y[:7]
+        assert float(x[7].split("=")[1]) == pytest.approx(float(y[7].split("=")[1]), rel=1e-5, abs=1e-6)
+
+
+@pytest.mark.gpu
+def test_cli_input_vcf_on_gpu(tmp_path):
+    """the reference's `-input-vcf` command line on the GPU from a snapshot directory: ISM-style VCF (3 rows per position) +
+    FASTA -> scored VCF; scores against the oracle on the same checkpoint."""
+    g = _genome(11)
+    fa, vcf, out = tmp_path / "g.fa", tmp_path / "ism.vcf", tmp_path / "scored.vcf"
+    _write_fasta(fa, g)
+    rows = _ism_vcf(vcf, g, "chr1", 300, 340, [("chr2", 10, "N", "A")])
+    d = str(tmp_path / "snap")
+    cfg, sd = make_synthetic_checkpoint(d, "x", seed=13, stress=False, d_model=128, n_layer=2)
+    zero_shot.main(["-input-vcf", str(vcf), "-input-fasta", str(fa), "-output", str(out), "-model", d, "-device", "cuda:0",
+                    "-batchSize", "16"])
+    body = [l.split("\t") for l in open(out).read().splitlines() if not l.startswith("#")]
+    assert len(body) == len(rows)
+    om = O.OracleForMaskedLM(O.params_from_state_dict(sd, cfg))
+    tok = CaduceusTokenizer()
+    for f in body[:: max(1, len(body) // 12)]:
+        w = zero_shot.window_for(g[f[0]], int(f[1]) - 1, 255)
+        p = zero_shot.extract_logits(om, [w], "cpu", 255, tok)[0]
+        v = f[7].split("plantCAD_zero_shot=")[1]
+        if f[3] in "ACGT":
+            want = np.log(p["ACGT".index(f[4])] / p["ACGT".index(f[3])])
+            assert float(v) == pytest.approx(want, abs=5e-2)              # bf16 model (dtype policy), log-ratio
+        else:
+            assert v == "."
