@@ -131,6 +131,19 @@ def test_no_cpu_fallback():
         m(input_ids=rand_ids(1, 16, 0))
 
 
+def test_out_of_vocabulary_ids_raise():
+    """the reference's nn.Embedding raises on an id outside the table; the engine must not alias it to another row."""
+    cfg = make_config("x", d_model=64, n_layer=1)
+    m = build(cfg, synthetic_state_dict(cfg, seed=2), torch.float32)
+    ids = rand_ids(2, 16, 0)
+    m(input_ids=ids.to(DEV))
+    for bad in (8, -1, 1000):
+        ids2 = ids.clone()
+        ids2[1, 3] = bad
+        with pytest.raises(IndexError, match="outside"):
+            m(input_ids=ids2.to(DEV))
+
+
 def test_long_window_8192():
     """PlantCAD2-sized context (reference docs/zero-shot-eval.md:31,42: 8 192-bp windows, token_idx 4095): the
     kernels are length-generic (time-sequential scan, sliding-window conv).  fp32, one l20-wide layer pair, against

@@ -71,3 +71,78 @@ def test_predict_cli_plumbing(tmp_path, monkeypatch, golden_dir):
                                                      "mytest_chunk_4_embeddings.npz", "mytest_predictions.tsv"]
     res2 = pd.read_csv(tmp_path / "out2" / "mytest_predictions.tsv", delimiter="\t")
     np.testing.assert_allclose(res2["prediction"].to_numpy(), want, rtol=1e-5)
+
+
+def _random_tree(rng, n_features, depth):
+    """random binary tree in XGBoost's JSON arrays (node 0 = root, children appended breadth-first)"""
+    left, right, feat, cond, dleft = [-1], [-1], [0], [float(rng.normal())], [0]
+    frontier = [(0, 0)]
+    while frontier:
+        node, d = frontier.pop(0)
+        if d < depth and rng.random() < 0.8:
+            l, r = len(left), len(left) + 1
+            for _ in range(2):
+                left.append(-1); right.append(-1); feat.append(0); cond.append(float(rng.normal() * 0.3)); dleft.append(0)
+            left[node], right[node] = l, r
+            feat[node], cond[node], dleft[node] = int(rng.integers(0, n_features)), float(rng.normal()), int(rng.integers(0, 2))
+            frontier += [(l, d + 1), (r, d + 1)]
+    return _tree(left, right, feat, cond, dleft)
+
+
+def test_xgb_evaluator_vs_scalar_walk_on_random_forests(tmp_path):
+    """the vectorised evaluator against a plain per-row recursive walk of the same JSON (x < threshold -> left, missing ->
+    default_left, leaf value in split_conditions, margins summed over trees + logit(base_score)) on 40 random trees with
+    missing values."""
+    rng = np.random.default_rng(5)
+    F = 24
+    trees = [_random_tree(rng, F, depth=int(rng.integers(1, 7))) for _ in range(40)]
+    path = tmp_path / "forest.json"
+    json.dump(_model_json(trees, F, base_score="3.1E-1"), open(path, "w"))
+    clf = xgb_predict.XGBJsonClassifier().load_model(str(path))
+    X = rng.normal(size=(300, F)).astype(np.float32)
+    X[rng.random(X.shape) < 0.1] = np.nan
+
+    def walk(t, x):
+        n = 0
+        while t["left_children"][n] != -1:
+            v = x[t["split_indices"][n]]
+            go_left = bool(t["default_left"][n]) if np.isnan(v) else bool(v < np.float32(t["split_conditions"][n]))
+            n = t["left_children"][n] if go_left else t["right_children"][n]
+        return np.float32(t["split_conditions"][n])
+    want = np.array([np.log(0.31 / 0.69) + sum(float(walk(t, x)) for t in trees) for x in X])
+    np.testing.assert_allclose(clf.margin(X), want, rtol=1e-5, atol=1e-6)
+    assert len({round(v, 3) for v in want}) > 100                      # the forest really separates rows
+
+
+import pytest  # noqa: E402
+
+
+@pytest.mark.gpu
+def test_predict_cli_on_gpu_from_snapshot(tmp_path, golden_dir):
+    """reference src/predict_XGBoost.py:28-67 end to end on the GPU, nothing mocked: snapshot directory -> embeddings through
+    the HIP path -> XGBoost-JSON classifier -> <prefix>_predictions.tsv; embeddings against the oracle on the same checkpoint,
+    predictions against the classifier applied to them."""
+    from plantcaduceus_amd.checkpoint import make_synthetic_checkpoint
+    d = str(tmp_path / "snap")
+    cfg, sd = make_synthetic_checkpoint(d, "x", seed=21, stress=False, d_model=128, n_layer=2)
+    src = pd.read_csv(os.path.join(golden_dir, "example_snp.tsv"), delimiter="\t").iloc[:20]
+    test = tmp_path / "gpu_test.tsv"
+    rng = np.random.default_rng(0)
+    pd.DataFrame({"sequences": src["sequences"], "label": rng.integers(0, 2, size=len(src))}).to_csv(test, sep="\t", index=False)
+    trees = [_random_tree(rng, cfg.d_model, 4) for _ in range(12)]
+    for t in trees:                                                      # thresholds on the scale of the embeddings
+        t["split_conditions"] = [c * 0.05 if l != -1 else c for c, l in zip(t["split_conditions"], t["left_children"])]
+    clf = tmp_path / "clf.json"
+    json.dump(_model_json(trees, cfg.d_model), open(clf, "w"))
+    out = tmp_path / "out"
+    xgb_predict.main(["-test", str(test), "-model", d, "-classifier", str(clf), "-output", str(out), "-device", "cuda:0",
+                      "-batchSize", "8"])
+    res = pd.read_csv(out / "gpu_test_predictions.tsv", delimiter="\t")
+    emb = np.load(out / "gpu_test_embeddings.npz")["test"]
+    assert emb.shape == (len(src), cfg.d_model) and list(res.columns) == ["label", "prediction"]
+    om = O.OracleForMaskedLM(O.params_from_state_dict(sd, cfg))
+    from plantcaduceus_amd import embeddings
+    ref = embeddings.extract_embeddings(om, src["sequences"].tolist(), "cpu", 255, CaduceusTokenizer(), batch_size=8)
+    assert np.abs(emb - ref).max() / np.abs(ref).max() < 2e-2          # bf16 model (dtype policy) vs fp32 oracle, 2 layers
+    want = xgb_predict.XGBJsonClassifier().load_model(str(clf)).predict_proba(emb)[:, 1]
+    np.testing.assert_allclose(res["prediction"].to_numpy(), want, rtol=1e-5)

@@ -46,6 +46,46 @@ __global__ __launch_bounds__(256, 1) void mfma_kernel(const u32x4* __restrict__ 
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 
+__device__ __forceinline__ float s_mul(float a, float b) { float r; asm volatile("v_mul_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float s_fma(float a, float b, float c) { float r; asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+__device__ __forceinline__ float s_exp(float a) { float r; asm volatile("v_exp_f32 %0, %1" : "=v"(r) : "v"(a)); return r; }
+
+// same recurrence with SCALAR fp32 instructions only (v_mul_f32 / v_fma_f32 / v_exp_f32 through inline asm, so the
+// compiler cannot re-pack them): MODE 1 full step, MODE 2 the 16 exps only, MODE 3 the 64 plain ops only
+template <int LDS_FLOATS, int MODE, int PRIO>
+__global__ __launch_bounds__(64, 4) void valu_scalar_kernel(const float* __restrict__ src, float* out, int steps) {
+    __shared__ float pad[LDS_FLOATS];
+    const int gid = blockIdx.x * 64 + threadIdx.x;
+    pad[threadIdx.x] = src[gid & 1023];
+    if (PRIO) __builtin_amdgcn_s_setprio(PRIO);
+    float a2[16], h[16];
+#pragma unroll
+    for (int n = 0; n < 16; ++n) { a2[n] = -0.01f * (n + 1) - 1e-4f * src[gid & 1023]; h[n] = 0.f; }
+    float y = 0.f;
+    float dv = 0.3f + 1e-3f * src[(gid + 5) & 1023];
+    for (int s = 0; s < steps; ++s) {
+        const float uv = 0.5f + 1e-4f * (float)(s & 7);
+        const float du = dv * uv;
+        float y0 = 0.f, y1 = 0.f;
+#pragma unroll
+        for (int n = 0; n < 16; n += 2) {
+            const float bb = 0.25f + 0.01f * n, cc = 0.75f - 0.01f * n;
+            float x0, x1;
+            if (MODE == 3) { x0 = a2[n]; x1 = a2[n + 1]; }
+            else { x0 = s_exp(MODE == 2 ? a2[n] + dv : s_mul(dv, a2[n])); x1 = s_exp(MODE == 2 ? a2[n + 1] + dv : s_mul(dv, a2[n + 1])); }
+            if (MODE == 2) { y0 += x0; y1 += x1; continue; }
+            if (MODE == 3) { x0 = s_mul(dv, x0); x1 = s_mul(dv, x1); }
+            h[n] = s_fma(x0, h[n], s_mul(du, bb));
+            h[n + 1] = s_fma(x1, h[n + 1], s_mul(du, cc));
+            y0 = s_fma(h[n], cc, y0);
+            y1 = s_fma(h[n + 1], bb, y1);
+        }
+        y += y0 + y1;
+        dv = 0.3f + 1e-6f * y;
+    }
+    out[gid] = y + pad[(threadIdx.x + 1) & 63];
+}
+
 template <int LDS_FLOATS>   // static LDS per 1-wave block sets the occupancy: 2560 floats (10 KiB) -> 16 blocks/CU = 4 waves/SIMD
 __global__ __launch_bounds__(64, 4) void valu_kernel(const float* __restrict__ src, float* out, int steps) {
     __shared__ float pad[LDS_FLOATS];
@@ -82,7 +122,7 @@ __global__ __launch_bounds__(64, 4) void valu_kernel(const float* __restrict__ s
 
 struct Timing { float ms_m, ms_v; double wall_ms; };
 
-template <int GAP, int LF>
+template <int GAP, int LF, int MODE = 0, int PRIO = 0>
 Timing run(bool do_m, bool do_v, int iters_m, int v_blocks, int v_steps, const u32x4* src, float* out_m, float* out_v,
            hipStream_t sm, hipStream_t sv) {
     hipEvent_t m0, m1, v0, v1;
@@ -90,7 +130,9 @@ Timing run(bool do_m, bool do_v, int iters_m, int v_blocks, int v_steps, const u
     CK(hipDeviceSynchronize());
     auto t0 = std::chrono::steady_clock::now();
     if (do_m) { CK(hipEventRecord(m0, sm)); hipLaunchKernelGGL(mfma_kernel<GAP>, dim3(256), dim3(256), 0, sm, src, out_m, iters_m); CK(hipEventRecord(m1, sm)); }
-    if (do_v) { CK(hipEventRecord(v0, sv)); hipLaunchKernelGGL(valu_kernel<LF>, dim3(v_blocks), dim3(64), 0, sv, (const float*)src, out_v, v_steps); CK(hipEventRecord(v1, sv)); }
+    if (do_v) { CK(hipEventRecord(v0, sv));
+        if (MODE == 0) hipLaunchKernelGGL(valu_kernel<LF>, dim3(v_blocks), dim3(64), 0, sv, (const float*)src, out_v, v_steps);
+        else hipLaunchKernelGGL((valu_scalar_kernel<LF, MODE, PRIO>), dim3(v_blocks), dim3(64), 0, sv, (const float*)src, out_v, v_steps); CK(hipEventRecord(v1, sv)); }
     CK(hipDeviceSynchronize());
     auto t1 = std::chrono::steady_clock::now();
     Timing t{0.f, 0.f, std::chrono::duration<double, std::milli>(t1 - t0).count()};
@@ -99,22 +141,22 @@ Timing run(bool do_m, bool do_v, int iters_m, int v_blocks, int v_steps, const u
     return t;
 }
 
-template <int GAP, int LF>
+template <int GAP, int LF, int MODE = 0, int PRIO = 0>
 void experiment(const char* name, const u32x4* src, float* out_m, float* out_v, hipStream_t sm, hipStream_t sv) {
     const int v_steps = 512;
     // V alone at 4 waves/SIMD: 16 rounds of 4096 blocks (like a 1024-strand scan launch at l32: 65536 blocks)
     const int v_blocks = 65536;
-    run<GAP, LF>(false, true, 0, v_blocks, v_steps, src, out_m, out_v, sm, sv);                    // warm
-    Timing tv = run<GAP, LF>(false, true, 0, v_blocks, v_steps, src, out_m, out_v, sm, sv);
+    run<GAP, LF, MODE, PRIO>(false, true, 0, v_blocks, v_steps, src, out_m, out_v, sm, sv);                    // warm
+    Timing tv = run<GAP, LF, MODE, PRIO>(false, true, 0, v_blocks, v_steps, src, out_m, out_v, sm, sv);
     // M alone, iterations sized to about the same duration
     int iters_m = 20000;
-    run<GAP, LF>(true, false, iters_m, 0, 0, src, out_m, out_v, sm, sv);
-    Timing tm = run<GAP, LF>(true, false, iters_m, 0, 0, src, out_m, out_v, sm, sv);
+    run<GAP, LF, MODE, PRIO>(true, false, iters_m, 0, 0, src, out_m, out_v, sm, sv);
+    Timing tm = run<GAP, LF, MODE, PRIO>(true, false, iters_m, 0, 0, src, out_m, out_v, sm, sv);
     iters_m = (int)(iters_m * tv.ms_v / tm.ms_m);
-    tm = run<GAP, LF>(true, false, iters_m, 0, 0, src, out_m, out_v, sm, sv);
+    tm = run<GAP, LF, MODE, PRIO>(true, false, iters_m, 0, 0, src, out_m, out_v, sm, sv);
     const double mfma_rate = 256.0 * 4 * (double)iters_m * 16 * 2 * 16 * 16 * 32 / (tm.ms_m * 1e-3) / 1e12;
-    Timing tb = run<GAP, LF>(true, true, iters_m, v_blocks, v_steps, src, out_m, out_v, sm, sv);
-    tb = run<GAP, LF>(true, true, iters_m, v_blocks, v_steps, src, out_m, out_v, sm, sv);
+    Timing tb = run<GAP, LF, MODE, PRIO>(true, true, iters_m, v_blocks, v_steps, src, out_m, out_v, sm, sv);
+    tb = run<GAP, LF, MODE, PRIO>(true, true, iters_m, v_blocks, v_steps, src, out_m, out_v, sm, sv);
     printf("%-22s  M alone %.2f ms (%.0f TF)   V alone %.2f ms   together: M %.2f ms, V %.2f ms, wall %.2f ms   serial sum %.2f ms  -> speedup %.2fx\n",
            name, tm.ms_m, mfma_rate, tv.ms_v, tb.ms_m, tb.ms_v, tb.wall_ms, tm.ms_m + tv.ms_v,
            (tm.ms_m + tv.ms_v) / (tb.ms_m > tb.ms_v ? tb.ms_m : tb.ms_v));
@@ -132,16 +174,27 @@ int main() {
     CK(hipMalloc(&out_m, 256 * 256 * 4)); CK(hipMalloc(&out_v, 65536 * 64 * 4));
     hipStream_t sm, sv;
     CK(hipStreamCreateWithFlags(&sm, hipStreamNonBlocking)); CK(hipStreamCreateWithFlags(&sv, hipStreamNonBlocking));
-    printf("V at 4 waves/SIMD (10 KiB LDS per block)\n");
+    printf("== V packed (v_pk_mul/v_pk_fma_f32 + v_exp_f32), 4 waves/SIMD\n");
     experiment<0, 2560>("MFMA back-to-back", src, out_m, out_v, sm, sv);
     experiment<2, 2560>("MFMA + 2 nop states", src, out_m, out_v, sm, sv);
     experiment<4, 2560>("MFMA + 4 nop states", src, out_m, out_v, sm, sv);
     experiment<8, 2560>("MFMA + 8 nop states", src, out_m, out_v, sm, sv);
-    printf("V at 2 waves/SIMD (20 KiB LDS per block)\n");
-    experiment<0, 5120>("MFMA back-to-back", src, out_m, out_v, sm, sv);
-    experiment<4, 5120>("MFMA + 4 nop states", src, out_m, out_v, sm, sv);
-    printf("V at 1 wave/SIMD (40 KiB LDS per block)\n");
-    experiment<0, 10240>("MFMA back-to-back", src, out_m, out_v, sm, sv);
-    experiment<4, 10240>("MFMA + 4 nop states", src, out_m, out_v, sm, sv);
+    printf("== V scalar (v_mul/v_fma_f32 + v_exp_f32), 4 waves/SIMD\n");
+    experiment<0, 2560, 1>("MFMA back-to-back", src, out_m, out_v, sm, sv);
+    experiment<2, 2560, 1>("MFMA + 2 nop states", src, out_m, out_v, sm, sv);
+    experiment<4, 2560, 1>("MFMA + 4 nop states", src, out_m, out_v, sm, sv);
+    experiment<8, 2560, 1>("MFMA + 8 nop states", src, out_m, out_v, sm, sv);
+    printf("== V scalar, s_setprio 3, 4 waves/SIMD\n");
+    experiment<0, 2560, 1, 3>("MFMA back-to-back", src, out_m, out_v, sm, sv);
+    experiment<4, 2560, 1, 3>("MFMA + 4 nop states", src, out_m, out_v, sm, sv);
+    printf("== V = 16 v_exp_f32 only, 4 waves/SIMD\n");
+    experiment<0, 2560, 2>("MFMA back-to-back", src, out_m, out_v, sm, sv);
+    experiment<4, 2560, 2>("MFMA + 4 nop states", src, out_m, out_v, sm, sv);
+    printf("== V = 64 scalar v_mul/v_fma only, 4 waves/SIMD\n");
+    experiment<0, 2560, 3>("MFMA back-to-back", src, out_m, out_v, sm, sv);
+    experiment<4, 2560, 3>("MFMA + 4 nop states", src, out_m, out_v, sm, sv);
+    printf("== V scalar, 2 waves/SIMD\n");
+    experiment<0, 5120, 1>("MFMA back-to-back", src, out_m, out_v, sm, sv);
+    experiment<4, 5120, 1>("MFMA + 4 nop states", src, out_m, out_v, sm, sv);
     return 0;
 }
