@@ -99,6 +99,34 @@ class _LMHead(nn.Module):
         self.lm_head = _Weight(cfg.padded_vocab_size, cfg.d_model)
 
 
+class LastHiddenOnly(tuple):
+    """`hidden_states` when only the last level was materialised (the default: the reference's callers read `[-1]` only and
+    all n_layer+1 levels at B=1024 / l32 are 71 GB).  Behaves like the HF tuple for what exists — `len()` is n_layer + 1,
+    `[-1]` / `[n_layer]` is the final hidden state — and raises, loudly, for any level that was not kept."""
+
+    def __new__(cls, last, n_levels: int):
+        self = super().__new__(cls, (last,))
+        self._n = int(n_levels)
+        return self
+
+    def __len__(self):
+        return self._n
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            raise IndexError("only hidden_states[-1] is materialised; set config.materialize_all_hidden_states = True for slices")
+        j = i + self._n if i < 0 else i
+        if j == self._n - 1:
+            return tuple.__getitem__(self, 0)
+        if 0 <= j < self._n:
+            raise IndexError(f"hidden_states[{i}] was not materialised (only [-1] is, by default); set "
+                             "config.materialize_all_hidden_states = True to get all n_layer + 1 levels")
+        raise IndexError("tuple index out of range")
+
+    def __iter__(self):
+        raise TypeError("only hidden_states[-1] is materialised; set config.materialize_all_hidden_states = True to iterate")
+
+
 # ---- HF models --------------------------------------------------------------------------------------
 class CaduceusPreTrainedModel(PreTrainedModel):
     config_class = CaduceusConfig
@@ -208,7 +236,7 @@ class Caduceus(CaduceusPreTrainedModel):
             hs = tuple(allh[i] for i in range(allh.shape[0])) + (last,)
         else:
             _, last = eng.forward(input_ids, positions=positions, want_hidden=True, want_logits=False)
-            hs = (last,) if output_hidden_states else None
+            hs = LastHiddenOnly(last, self.config.n_layer + 1) if output_hidden_states else None
         if return_dict is False:
             return (last, hs) if hs is not None else (last,)
         return BaseModelOutputWithNoAttention(last_hidden_state=last, hidden_states=hs)
@@ -218,7 +246,8 @@ class CaduceusForMaskedLM(CaduceusPreTrainedModel):
     """`AutoModelForMaskedLM` class: `.logits` fp32 [B, L, 8]; `.hidden_states[-1]` [B, L, 2*d_model].
 
     By default only `hidden_states[-1]` is materialised when `output_hidden_states=True` (the only entry
-    the reference's callers read; all 33 levels at B=1024/l32 would be 71 GB).  Set
+    the reference's callers read; all 33 levels at B=1024/l32 would be 71 GB): `hidden_states` is then a
+    `LastHiddenOnly` — `len()` n_layer + 1 and `[-1]` as in HF, any other level raises.  Set
     `config.materialize_all_hidden_states = True` for the full n_layer+1 tuple.
     Extra (non-HF) keyword `positions=[p, ...]` evaluates the head only at those positions
     (logits [B, P, 8]) — the engine's fast path for zero-shot scoring.
@@ -254,7 +283,7 @@ class CaduceusForMaskedLM(CaduceusPreTrainedModel):
             logits, last = eng.forward(input_ids, positions=positions, want_hidden=bool(output_hidden_states),
                                        want_logits=True)
             if output_hidden_states:
-                hs = (last,)
+                hs = LastHiddenOnly(last, self.config.n_layer + 1)
         if return_dict is False:
             return (logits, hs) if hs is not None else (logits,)
         return MaskedLMOutput(loss=None, logits=logits, hidden_states=hs)

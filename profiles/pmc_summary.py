@@ -31,6 +31,22 @@ def main():
         for k, v in df.groupby("k").Counter_Value.mean().items():
             if k.startswith("pcad::") and "pack" not in k:
                 res.setdefault(k, {})[c + "_KB"] = round(float(v), 1)
+    import os
+    for sub in ("RDREQ", "DRAM"):                      # optional passes: read requests by size, DRAM-side request counts
+        fn = base + f"{sub}/p_counter_collection.csv"
+        if not os.path.exists(fn):
+            continue
+        df = pd.read_csv(fn)
+        df["k"] = df.Kernel_Name.map(short)
+        p = df.pivot_table(index="k", columns="Counter_Name", values="Counter_Value", aggfunc="mean")
+        for k, row in p.iterrows():
+            if k in res:
+                res[k].update({c: float(row[c]) for c in p.columns})
+                if sub == "RDREQ":
+                    n32, n64, n128, tot = (row.get(c, 0.0) for c in ("TCC_EA0_RDREQ_32B_sum", "TCC_EA0_RDREQ_64B_sum",
+                                                                      "TCC_EA0_RDREQ_128B_sum", "TCC_EA0_RDREQ_sum"))
+                    res[k]["read_bytes_by_size"] = float(32 * n32 + 64 * n64 + 128 * n128)
+                    res[k]["read_bytes_if_rest_64B"] = float(32 * n32 + 128 * n128 + 64 * max(0.0, tot - n32 - n128))
     df = pd.read_csv(base + "SQ/p_counter_collection.csv")
     df["k"] = df.Kernel_Name.map(short)
     p = df.pivot_table(index="k", columns="Counter_Name", values="Counter_Value", aggfunc="mean")
@@ -57,7 +73,10 @@ def main():
             continue
         f = sum(res[k]["FETCH_SIZE_KB"] for k in ks) / len(ks)
         w = sum(res[k]["WRITE_SIZE_KB"] for k in ks) / len(ks)
-        o["classes"][c] = {"traffic_bytes_per_launch": round((2 * f + w) * 1024), "fetch_raw_bytes": round(f * 1024),
+        rb = [res[k]["read_bytes_by_size"] for k in ks if "read_bytes_by_size" in res[k]]
+        read_b = sum(rb) / len(rb) if rb else 2 * f * 1024        # size-resolved request counts when collected, else 2x FETCH_SIZE
+        o["classes"][c] = {"traffic_bytes_per_launch": round(read_b + w * 1024), "fetch_raw_bytes": round(f * 1024),
+                           "read_bytes": round(read_b), "read_bytes_source": "TCC_EA0_RDREQ_{32B,64B,128B}" if rb else "2 x FETCH_SIZE",
                            "write_bytes": round(w * 1024),
                            "valu_busy_frac": round(sum(res[k].get("valu_busy_frac", 0) for k in ks) / len(ks), 3),
                            "mfma_busy_frac": round(sum(res[k].get("mfma_busy_frac", 0) for k in ks) / len(ks), 3)}

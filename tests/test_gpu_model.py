@@ -44,6 +44,9 @@ def test_forward_fp32_matches_oracle(D, nl, B, L):
     assert ((lg - ref["logits"]).abs().max() / scale).item() < 1e-4
     hid = out.hidden_states[-1].cpu()
     assert hid.shape == (B, L, 2 * D)
+    assert len(out.hidden_states) == nl + 1                    # HF length; levels that were not kept raise
+    with pytest.raises(IndexError, match="materialize_all_hidden_states"):
+        out.hidden_states[0]
     assert ((hid - ref["hidden"]).abs().max() / ref["hidden"].abs().max()).item() < 1e-4
     p = L // 2 - 1
     assert torch.equal(lg[:, p, 3:7].argmax(-1), ref["logits"][:, p, 3:7].argmax(-1))

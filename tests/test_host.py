@@ -145,3 +145,20 @@ def test_tokenizer_vocab_must_match_complement_map():
     bad = CaduceusTokenizer(vocab={"[PAD]": 0, "[MASK]": 1, "[UNK]": 2, "a": 3, "c": 4, "t": 5, "g": 6})
     with pytest.raises(ValueError, match="inconsistent"):
         zero_shot.check_vocab_matches_complement(bad, cfg)
+
+
+def test_last_hidden_only_container_is_loud():
+    from transformers.modeling_outputs import MaskedLMOutput
+    from plantcaduceus_amd.modeling_caduceus import LastHiddenOnly
+    t = torch.arange(6.0).reshape(1, 3, 2)
+    hs = LastHiddenOnly(t, 21)
+    assert len(hs) == 21 and hs[-1] is t and hs[20] is t
+    for bad in (0, 1, -2, 19):
+        with pytest.raises(IndexError, match="materialize_all_hidden_states"):
+            hs[bad]
+    with pytest.raises(IndexError):
+        hs[21]
+    with pytest.raises(TypeError, match="materialize_all_hidden_states"):
+        list(hs)
+    out = MaskedLMOutput(loss=None, logits=t, hidden_states=hs)      # survives the HF output dataclass
+    assert out.hidden_states[-1] is t and len(out.hidden_states) == 21

@@ -120,6 +120,86 @@ __global__ __launch_bounds__(64, 4) void valu_kernel(const float* __restrict__ s
     out[gid] = y + pad[(threadIdx.x + 1) & 63];
 }
 
+// ONE kernel, wave-specialised: waves 0-3 of each 16-wave block (one per SIMD) run the MFMA loop, waves 4-15 (three per SIMD)
+// the scalar VALU recurrence.  A single dispatch, so rocprofv3 --pmc sees both pipes in the same pass:
+//   tools/coreside_microbench fused        (three dispatches per GAP: M only, V only, both)
+template <int GAP>
+__global__ __launch_bounds__(1024) void fused_kernel(const u32x4* __restrict__ src, float* out, int iters_m, int steps_v) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int gid = blockIdx.x * 1024 + threadIdx.x;
+    if (wave < 4) {
+        if (iters_m == 0) return;
+        u32x4 a[4], b[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { a[i] = src[(lane + 64 * i) & 1023]; b[i] = src[(lane * 3 + 64 * i + 7) & 1023]; }
+        f32x4 acc[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int it = 0; it < iters_m; ++it) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a[i & 3]),
+                                                               __builtin_bit_cast(bf16x8_t, b[i >> 2]), acc[i], 0, 0, 0);
+                if constexpr (GAP > 0) asm volatile("s_nop %0" ::"n"(GAP - 1));
+            }
+        }
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+        out[gid] = s;
+    } else {
+        if (steps_v == 0) return;
+        const float* fs = (const float*)src;
+        float a2[16], h[16];
+#pragma unroll
+        for (int n = 0; n < 16; ++n) { a2[n] = -0.01f * (n + 1) - 1e-4f * fs[gid & 1023]; h[n] = 0.f; }
+        float y = 0.f;
+        float dv = 0.3f + 1e-3f * fs[(gid + 5) & 1023];
+        for (int s = 0; s < steps_v; ++s) {
+            const float uv = 0.5f + 1e-4f * (float)(s & 7);
+            const float du = dv * uv;
+            float y0 = 0.f, y1 = 0.f;
+#pragma unroll
+            for (int n = 0; n < 16; n += 2) {
+                const float bb = 0.25f + 0.01f * n, cc = 0.75f - 0.01f * n;
+                const float x0 = s_exp(s_mul(dv, a2[n])), x1 = s_exp(s_mul(dv, a2[n + 1]));
+                h[n] = s_fma(x0, h[n], s_mul(du, bb));
+                h[n + 1] = s_fma(x1, h[n + 1], s_mul(du, cc));
+                y0 = s_fma(h[n], cc, y0);
+                y1 = s_fma(h[n + 1], bb, y1);
+            }
+            y += y0 + y1;
+            dv = 0.3f + 1e-6f * y;
+        }
+        out[gid] = y;
+    }
+}
+
+template <int GAP>
+void fused_experiment(const char* name, const u32x4* src, float* out) {
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    auto go = [&](int im, int sv) {
+        CK(hipDeviceSynchronize());
+        CK(hipEventRecord(e0, 0));
+        hipLaunchKernelGGL(fused_kernel<GAP>, dim3(256), dim3(1024), 0, 0, src, out, im, sv);
+        CK(hipEventRecord(e1, 0));
+        CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        return ms;
+    };
+    const int sv = 16384;                 // 3 V waves per SIMD x 16384 steps
+    go(1000, 100);
+    const float tv = go(0, sv);
+    int im = 20000;
+    float tm = go(im, 0);
+    im = (int)(im * tv / tm);
+    tm = go(im, 0);
+    const float tb = go(im, sv);
+    printf("fused %-20s  M only %.2f ms (%.0f TF)   V only %.2f ms   both in one dispatch %.2f ms   serial sum %.2f -> speedup %.2fx\n", name, tm,
+           256.0 * 4 * (double)im * 16 * 2 * 16 * 16 * 32 / (tm * 1e-3) / 1e12, tv, tb, tm + tv, (tm + tv) / tb);
+}
+
 struct Timing { float ms_m, ms_v; double wall_ms; };
 
 template <int GAP, int LF, int MODE = 0, int PRIO = 0>
@@ -162,7 +242,7 @@ void experiment(const char* name, const u32x4* src, float* out_m, float* out_v, 
            (tm.ms_m + tv.ms_v) / (tb.ms_m > tb.ms_v ? tb.ms_m : tb.ms_v));
 }
 
-int main() {
+int main(int argc, char** argv) {
     std::vector<unsigned> h(4096);
     srand(1);
     for (auto& v : h) {   // two random bf16 values in [-1, 1) per word
@@ -174,6 +254,15 @@ int main() {
     CK(hipMalloc(&out_m, 256 * 256 * 4)); CK(hipMalloc(&out_v, 65536 * 64 * 4));
     hipStream_t sm, sv;
     CK(hipStreamCreateWithFlags(&sm, hipStreamNonBlocking)); CK(hipStreamCreateWithFlags(&sv, hipStreamNonBlocking));
+    if (argc > 1 && !strcmp(argv[1], "fused")) {
+        float* out;
+        CK(hipMalloc(&out, 256 * 1024 * 4));
+        fused_experiment<0>("MFMA back-to-back", src, out);
+        fused_experiment<2>("MFMA + 2 nop states", src, out);
+        fused_experiment<4>("MFMA + 4 nop states", src, out);
+        fused_experiment<8>("MFMA + 8 nop states", src, out);
+        return 0;
+    }
     printf("== V packed (v_pk_mul/v_pk_fma_f32 + v_exp_f32), 4 waves/SIMD\n");
     experiment<0, 2560>("MFMA back-to-back", src, out_m, out_v, sm, sv);
     experiment<2, 2560>("MFMA + 2 nop states", src, out_m, out_v, sm, sv);
