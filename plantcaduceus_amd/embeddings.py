@@ -21,7 +21,7 @@ import numpy as np
 import torch
 
 from . import sharding
-from .zero_shot import local_ids
+from .zero_shot import effective_batch, local_ids
 
 
 def load_data(filepath):
@@ -40,6 +40,8 @@ def extract_embeddings(model, sequences, device, tokenIdx: int, tokenizer=None, 
     if ws > 1:
         ids_local = sharding.pad_rows(ids_local, per)
     fast = bool(getattr(model, "supports_positions", False))
+    if fast and ids_local.shape[0]:
+        batch_size = effective_batch(model, batch_size, ids_local.shape[1])
     model.eval()
     outs = []
     with torch.inference_mode():

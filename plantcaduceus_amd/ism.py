@@ -23,7 +23,7 @@ import numpy as np
 import torch
 
 from . import sharding
-from .zero_shot import NUCLEOTIDES, extract_logits, tokenize_masked, window_for
+from .zero_shot import NUCLEOTIDES, effective_batch, extract_logits, tokenize_masked, window_for
 
 
 def _acgt_cols(tokenizer):
@@ -45,6 +45,8 @@ def sweep_window(model, seq: str, tokenizer, device, positions: Optional[Sequenc
     start, stop, per = sharding.shard_bounds(n_total, rank, ws)
     pos_local = sharding.pad_rows(pos_all[start:stop], per) if ws > 1 else pos_all
     per_seq = bool(getattr(model, "supports_positions", False))
+    if per_seq:
+        batch_size = effective_batch(model, batch_size, L)
     outs = []
     with torch.inference_mode():
         for b0 in range(0, pos_local.shape[0], batch_size):

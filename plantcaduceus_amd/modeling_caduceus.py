@@ -185,6 +185,15 @@ class CaduceusPreTrainedModel(PreTrainedModel):
                 model.to(dev)
         return model
 
+    def preferred_batch_size(self, seqlen: int) -> int:
+        """Windows per forward call at which the engine's launches are largest: two full chunks of the layer-stack walk
+        (a chunk is 2^31 / (d_inner * elem) token-rows: 512 windows of 512 bp at l32 bf16, see csrc/api.hip).  Results do
+        not depend on the batch size (windows are independent), so host loops may batch up to this regardless of the
+        `-batchSize` they were given."""
+        p = self._backbone_owner().caduceus_param()
+        rows = (1 << 31) // (self.config.d_inner * p.element_size())
+        return max(1, 2 * (rows // (2 * max(1, int(seqlen)))))
+
     # -- engine plumbing ----------------------------------------------------------------------------
     def _backbone_owner(self):
         raise NotImplementedError

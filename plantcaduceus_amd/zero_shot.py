@@ -134,6 +134,18 @@ def _has_vocab(model_dir: str) -> bool:
     return os.path.exists(os.path.join(model_dir, "vocab.json"))
 
 
+def effective_batch(model, batch_size: int, seqlen: int) -> int:
+    """`-batchSize` is a lower bound here: windows are independent, so when the model advertises a larger preferred batch
+    (the HIP engine: two full chunks, 1024 windows at l32) the host loop uses it — fewer, larger launches, same results."""
+    pref = getattr(model, "preferred_batch_size", None)
+    if callable(pref):
+        try:
+            return max(int(batch_size), int(pref(seqlen)))
+        except Exception:
+            return int(batch_size)
+    return int(batch_size)
+
+
 # ---- a3: batched forward -> [N, 4] probabilities ------------------------------------------------------
 def extract_logits(model, sequences, device, tokenIdx: int, tokenizer, batch_size: int = 128) -> np.ndarray:
     """sequences: list of equal-length strings, or a pre-tokenised+masked integer array [N, L].
@@ -148,6 +160,8 @@ def extract_logits(model, sequences, device, tokenIdx: int, tokenizer, batch_siz
     if ws > 1:
         ids_local = sharding.pad_rows(ids_local, per)
     fast = bool(getattr(model, "supports_positions", False))
+    if fast and ids_local.shape[0]:
+        batch_size = effective_batch(model, batch_size, ids_local.shape[1])
     outs = []
     with torch.inference_mode():
         for b0 in range(0, ids_local.shape[0], batch_size):
