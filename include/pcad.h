@@ -86,6 +86,8 @@ void   pcad_destroy(pcad_handle h);
  *   "gate_each"   1: SiLU(z) applied to each direction's scan output, each rounded, then summed — the reference's order
  *                 (two selective_scan_fn calls);  0 (default): applied once to the sum of both directions (same value in
  *                 exact arithmetic, one rounding fewer, faster).
+ *   "poison_workspace"  1: debug aid — the workspace is filled with 0xFF bytes (NaN in every dtype) before each forward, so a
+ *                 read of anything this forward did not write shows up as NaN outputs (tests/test_gpu_model.py).
  * The library reads NO environment variables unless PCAD_DEV=1 is set (developer A/B switches, see csrc/kernels.hpp). */
 int    pcad_set_option(pcad_handle h, const char* key, int64_t value);
 

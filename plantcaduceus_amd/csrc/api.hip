@@ -69,6 +69,7 @@ struct pcad_engine {
     bool convx;     // conv + x_proj of both directions in one kernel (needs xzsplit and Rp == 64); PCAD_NO_CONVX=1: off
     bool xzsplit;   // in_proj writes x and z as two blocked tensors (needs `blocked`); PCAD_PLAIN_XZ=1 turns it off (A/B knob)
     bool blocked;   // xc and y in the blocked layout (common.hpp::blocked_off); PCAD_PLAIN_LAYOUT=1 turns it off (A/B knob)
+    bool poison = false;   // pcad_set_option("poison_workspace", 1): debug — fill the workspace with 0xFF (NaN patterns) before every forward
     bool bound = false;
     hipStream_t aux[2] = {nullptr, nullptr};
     hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr}, ev_phase = nullptr;
@@ -263,6 +264,8 @@ int pcad_set_option(pcad_handle h, const char* key, int64_t value) {
         h->chunk = (int)value;
     } else if (k == "gate_each") {
         h->gate_once = value == 0;
+    } else if (k == "poison_workspace") {
+        h->poison = value != 0;
     } else {
         return fail(PCAD_ERR_INVALID, "pcad_set_option: unknown option '%s'", key);
     }
@@ -431,6 +434,10 @@ static int forward_impl(pcad_handle h, const int32_t* ids, int B, int L, const i
     // chunk's MFMA-bound GEMMs.
     struct Lane { hipStream_t s; Workspace w; int b0, Bc; bool active; };
     Lane ln[2];
+    // debug aid (race / uninitialised-read screen): every byte of the workspace starts as 0xFF, so a kernel that consumes a
+    // value no kernel of THIS forward produced turns the outputs into NaN instead of silently reusing the previous call's data
+    if (e->poison) HIP_TRY(hipMemsetAsync(workspace, 0xFF, need, cs));
+
     struct Join {      // runs on EVERY exit path: the caller's stream never runs ahead of work left on the aux streams
         pcad_engine* e; hipStream_t cs; bool on;
         ~Join() {

@@ -11,7 +11,7 @@ Only the head rows that are read are evaluated (`positions=`); tokenisation is t
 Task metrics and drivers on top of them (same file, `:181-320` and `ZeroShotEval` `:323-530`), vectorised numpy, no
 sklearn: `true_tokens`, `token_accuracy`, `motif_accuracy`, `refprob_scores`, `auroc`, `average_precision`,
 `avg_trueprob_scores`, `sv_llr_boundary`, and the four tasks `evo_cons`, `motif_acc`, `core_noncore`, `sv_effect`, which
-take a DataFrame (or a local .tsv/.csv/.parquet path - there is no network for HF `datasets` here) and print / return
+take a DataFrame, a local .tsv/.csv/.parquet path, or the reference's `(repo_id, task[, split])` (HF `datasets`: cache or network) and print / return
 the reference's metric lines.  Pinned by `tests/golden/harness_plantcad2_metrics.*` (outputs of the reference's functions).
 """
 from __future__ import annotations
@@ -199,10 +199,20 @@ def sv_llr_boundary(left, right, mut_seqs, ref_probs: np.ndarray, mut_probs: np.
 
 # ---------------------------------------------------------------------------------------------------------------------
 # task drivers (reference `ZeroShotEval` :323-530); `data`: DataFrame or path to a local .tsv / .csv / .parquet table
+def load_task(repo_id: str, task: str, split: str = "valid"):
+    """`load_dataset(repo_id, task)[split].to_pandas()` — how every sub-command of the reference gets its table (:344, :394,
+    :444, :498).  Needs the HF `datasets` cache or a network; the drivers below also take a DataFrame or a local file."""
+    from datasets import load_dataset
+    return load_dataset(repo_id, task)[split].to_pandas()
+
+
 def _frame(data):
+    """DataFrame | local table path | (repo_id, task[, split]) tuple as in the reference's CLI."""
     import pandas as pd
     if isinstance(data, pd.DataFrame):
         return data.reset_index(drop=True)
+    if isinstance(data, (tuple, list)) and 2 <= len(data) <= 3 and all(isinstance(x, str) for x in data):
+        return load_task(*data).reset_index(drop=True)
     path = str(data)
     if path.endswith(".parquet"):
         return pd.read_parquet(path)

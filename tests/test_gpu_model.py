@@ -134,6 +134,21 @@ def test_no_cpu_fallback():
         m(input_ids=rand_ids(1, 16, 0))
 
 
+@pytest.mark.parametrize("dtype,D,L,B", [(torch.float32, 128, 45, 3), (torch.bfloat16, 384, 203, 5), (torch.bfloat16, 1024, 512, 3),
+                                          (torch.float32, 64, 1, 2)])
+def test_poisoned_workspace_gives_identical_results(dtype, D, L, B):
+    """uninitialised-read screen: with every workspace byte pre-set to 0xFF (NaN) before each forward the outputs must be
+    bit-identical to the normal run, at ragged lengths (partial row blocks / tiles in every kernel) and in the two-lane mode."""
+    cfg = make_config("x", d_model=D, n_layer=2)
+    sd = synthetic_state_dict(cfg, seed=11)
+    ids = rand_ids(B, L, 3, mask=L // 2).to(DEV)
+    ref = build(cfg, sd, dtype)(input_ids=ids, output_hidden_states=True)
+    for opts in (dict(poison_workspace=1), dict(poison_workspace=1, chunk_seqs=2, two_lanes=True)):
+        out = build(cfg, sd, dtype, **opts)(input_ids=ids, output_hidden_states=True)
+        assert torch.isfinite(out.logits).all()
+        assert torch.equal(out.logits, ref.logits) and torch.equal(out.hidden_states[-1], ref.hidden_states[-1])
+
+
 def test_out_of_vocabulary_ids_raise():
     """the reference's nn.Embedding raises on an id outside the table; the engine must not alias it to another row."""
     cfg = make_config("x", d_model=64, n_layer=1)

@@ -241,3 +241,25 @@ def test_config1_l20_64_windows_through_cli(tmp_path, monkeypatch):
     # the BLAS-backed and the plain-C GEMM forms of the port agree at full depth
     lg2, _ = COracle(sd, cfg).forward(ids[:2])
     assert np.abs(lg2 - lg[:2]).max() / np.abs(lg[:2]).max() < 1e-4
+
+
+def test_plantcad2_task_table_sources(tmp_path, monkeypatch):
+    """the drivers take a DataFrame, a local table, or the reference's (repo_id, task, split) via HF datasets (:344)"""
+    import datasets
+    from plantcaduceus_amd import plantcad2_eval as pe
+    df = pd.DataFrame({"sequence": ["ACGT" * 4, "TTGA" * 4], "label": [0, 1]})
+    p = tmp_path / "t.tsv"
+    df.to_csv(p, sep="\t", index=False)
+    assert pe._frame(str(p)).equals(df) and pe._frame(df).equals(df)
+
+    class _DS(dict):
+        pass
+    calls = []
+
+    def fake_load(repo_id, task):
+        calls.append((repo_id, task))
+        return {"valid": types.SimpleNamespace(to_pandas=lambda: df.iloc[::-1])}
+    monkeypatch.setattr(datasets, "load_dataset", fake_load)
+    got = pe._frame(("kuleshov-group/cross-species-single-nucleotide-annotation", "conservation", "valid"))
+    assert calls == [("kuleshov-group/cross-species-single-nucleotide-annotation", "conservation")]
+    assert list(got["label"]) == [1, 0] and list(got.index) == [0, 1]
