@@ -61,6 +61,9 @@ def pad_rows(x: torch.Tensor, rows: int) -> torch.Tensor:
 def _all_gather(local: torch.Tensor, ws: int) -> torch.Tensor:
     """the collective itself: local [rows, ...] of each of `ws` ranks -> [ws * rows, ...] in rank order."""
     local = local.contiguous()
+    if local.is_cuda and dist.get_backend() != "nccl":
+        # device tensors on a gloo group (several ranks sharing one GPU in tests): stage through the host
+        return _all_gather(local.cpu(), ws).to(local.device)
     out = torch.empty((ws * local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
     if local.is_cuda:
         dist.all_gather_into_tensor(out, local)            # RCCL

@@ -110,3 +110,56 @@ def test_rccl_all_gather_branch_single_rank():
         assert sharding.world() == (0, 1) and torch.equal(sharding.all_gather_rows(emb, 4), emb[:4])
     finally:
         dist.destroy_process_group()
+
+
+def _gpu_worker(rank, ws, port, outdir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("gloo", rank=rank, world_size=ws)      # two ranks share the box's single GPU: RCCL refuses that
+    try:
+        import pandas as pd
+        from plantcaduceus_amd import embeddings, zero_shot
+        from plantcaduceus_amd.checkpoint import make_config, synthetic_state_dict
+        from plantcaduceus_amd.modeling_caduceus import CaduceusForMaskedLM
+        from plantcaduceus_amd.tokenization_caduceus import CaduceusTokenizer
+        cfg = make_config("x", d_model=128, n_layer=2)
+        m = CaduceusForMaskedLM(cfg)
+        m.load_state_dict(synthetic_state_dict(cfg, seed=5), strict=False)
+        m.tie_weights()
+        m = m.to("cuda:0")
+        df = pd.read_csv(os.path.join(os.path.dirname(__file__), "golden", "example_snp.tsv"), delimiter="\t")
+        df = df[df["ref"].isin(list("ACGT")) & df["alt"].isin(list("ACGT"))]
+        seqs = df["sequences"].tolist()                                # 185 rows: not divisible by 2
+        tok = CaduceusTokenizer()
+        p = zero_shot.extract_logits(m, seqs, "cuda:0", 255, tok, batch_size=64)
+        e = embeddings.extract_embeddings(m, seqs, "cuda:0", 255, tok, batch_size=64)
+        np.savez(os.path.join(outdir, f"g{rank}.npz"), p=p, e=e)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_two_processes_through_the_hip_engine_equal_single_process(tmp_path):
+    """the N > 1 product path end to end on the GPU box — two processes (one process per rank, both on the box's one GPU, gloo
+    rendezvous), each running ITS block of the 185 example windows through the HIP engine, one all-gather — equals the
+    single-process run bit for bit (windows are independent; rows come back in input order)."""
+    mp.spawn(_gpu_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    g0, g1 = np.load(tmp_path / "g0.npz"), np.load(tmp_path / "g1.npz")
+    assert g0["p"].shape == (185, 4) and g0["e"].shape == (185, 128)
+    np.testing.assert_array_equal(g0["p"], g1["p"])
+    np.testing.assert_array_equal(g0["e"], g1["e"])
+    import pandas as pd
+    from plantcaduceus_amd import embeddings, zero_shot
+    from plantcaduceus_amd.checkpoint import make_config, synthetic_state_dict
+    from plantcaduceus_amd.modeling_caduceus import CaduceusForMaskedLM
+    from plantcaduceus_amd.tokenization_caduceus import CaduceusTokenizer
+    cfg = make_config("x", d_model=128, n_layer=2)
+    m = CaduceusForMaskedLM(cfg)
+    m.load_state_dict(synthetic_state_dict(cfg, seed=5), strict=False)
+    m.tie_weights()
+    m = m.to("cuda:0")
+    df = pd.read_csv(os.path.join(os.path.dirname(__file__), "golden", "example_snp.tsv"), delimiter="\t")
+    df = df[df["ref"].isin(list("ACGT")) & df["alt"].isin(list("ACGT"))]
+    tok = CaduceusTokenizer()
+    np.testing.assert_array_equal(zero_shot.extract_logits(m, df["sequences"].tolist(), "cuda:0", 255, tok, batch_size=64), g0["p"])
+    np.testing.assert_array_equal(embeddings.extract_embeddings(m, df["sequences"].tolist(), "cuda:0", 255, tok, batch_size=64), g0["e"])
