@@ -55,6 +55,9 @@ def parse():
     ap.add_argument("--seqlen", type=int, default=512)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--cpu-seqs", type=int, default=-1, help="sample size for the CPU baseline (0 = skip)")
+    ap.add_argument("--two-lanes", action="store_true",
+                    help="pcad_set_aux_streams: chunks alternate between two caller-owned streams (measured: no gain, DESIGN.md §8)")
+    ap.add_argument("--chunk-seqs", type=int, default=0, help="pcad_set_option chunk_seqs (0 = engine default)")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--profile-stride", type=int, default=8,
                     help="HIP events around every N-th launch of each kernel class during the timed region")
@@ -146,6 +149,10 @@ def main():
     esz = 2 if args.dtype == "bf16" else 4
     sd = synthetic_state_dict(cfg, seed=1234, stress=False)
     eng = Engine(cfg, sd, tdt, device)
+    if args.chunk_seqs:
+        eng.set_option("chunk_seqs", args.chunk_seqs)
+    if args.two_lanes:
+        eng.set_two_lanes(True)
 
     B, L, p = args.batch, args.seqlen, 255 if args.seqlen > 255 else args.seqlen // 2
     D = cfg.d_model
@@ -237,7 +244,9 @@ def main():
                              "note": "per GPU; SURVEY.md §8(d) algorithmic flops (tie-folded) and bytes (GEMM-boundary fusion) "
                                      "per window x windows / timed wall clock"}
         chunk_max = max(1, (1 << 31) // (cfg.d_inner * esz) // (2 * L))                      # as api.hip
-        if os.environ.get("PCAD_DEV") == "1" and os.environ.get("PCAD_CHUNK_SEQS"):
+        if args.chunk_seqs:
+            chunk_max = args.chunk_seqs
+        elif os.environ.get("PCAD_DEV") == "1" and os.environ.get("PCAD_CHUNK_SEQS"):
             chunk_max = int(os.environ["PCAD_CHUNK_SEQS"])
         nchunks = -(-B // chunk_max)
         chunk = -(-B // nchunks)                                  # even split, as pcad_forward does

@@ -10,7 +10,10 @@ mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 timeout 600 python3 "$ROOT/bench.py" > "$OUT/bench.json" 2> "$OUT/bench.err"
 tail -c 600 "$OUT/bench.json"
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- python3 "$ROOT/bench.py" --steps 2 --warmup 1 --cpu-seqs 0 --no-profile > "$OUT/stats.log" 2>&1
+# kernel stats: the SAME process prints its own HIP-event roofline line (bench_under_rocprof.json), so the rocprofv3 average
+# duration of the dominant kernel and bench.py's `roofline.achieved` come from one run (a profiled run clocks ~3-6 % lower
+# than an un-profiled one: never compare across the two)
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- python3 "$ROOT/bench.py" --steps 3 --warmup 1 --cpu-seqs 0 > "$OUT/bench_under_rocprof.json" 2> "$OUT/stats.log"
 f=$(find "$OUT/stats" -name "*kernel_stats.csv" | head -1); cp "$f" "$OUT/kernel_stats.csv"; find "$OUT/stats" -type f ! -name "*kernel_stats.csv" -delete
 python3 -c "import sys; sys.path.insert(0, '$ROOT'); import bench; print(bench.source_hash())" > "$OUT/src_hash.txt"
 export PCAD_DEV=1 PCAD_CHUNK_SEQS=64     # PMC passes: 65536 token-rows per launch (what profiles/pmc_summary.py and bench.py scale from)
