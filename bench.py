@@ -59,8 +59,9 @@ def parse():
                     help="pcad_set_aux_streams: chunks alternate between two caller-owned streams (measured: no gain, DESIGN.md §8)")
     ap.add_argument("--chunk-seqs", type=int, default=0, help="pcad_set_option chunk_seqs (0 = engine default)")
     ap.add_argument("--no-profile", action="store_true")
-    ap.add_argument("--profile-stride", type=int, default=8,
-                    help="HIP events around every N-th launch of each kernel class during the timed region")
+    ap.add_argument("--profile-stride", type=int, default=7,
+                    help="HIP events around every N-th launch of each kernel class during the timed region (ODD: the scan class "
+                         "alternates forward / reverse launches, which differ by 14 %; an even stride samples one direction only)")
     return ap.parse_args()
 
 
