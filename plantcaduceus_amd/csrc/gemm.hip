@@ -845,257 +845,6 @@ __global__ __launch_bounds__(GEMMQ_THREADS, 1) void gemm256q_kernel(const T* __r
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // trailing (unused) DMAs must not outlive the block's LDS
 }
 
-// =====================================================================================================================
-// EXPERIMENT (PCAD_DEV=1 PCAD_GEMM_X32=1): the same 4-wave 256x256 kernel on v_mfma_f32_32x32x16_bf16 instead of 16x16x32.
-// Same ring (A x3, W x2), same barrier / counted-vmcnt protocol, same 16 ds_read_b128 + 8 LDS-DMA pieces per k-step, but 32
-// MFMAs of 32 cycles instead of 64 of 16 cycles per k-step: half the MFMA issue slots, and a non-MFMA instruction that blocks
-// its wave (an LDS-DMA piece costs 60-185 issue cycles) hides behind a 32-cycle MFMA instead of a 16-cycle one.
-//   wave tile 128x128 = 4 x 4 tiles of 32x32 (16 accumulator registers each = 256 AGPRs); operands swapped as above (W rows
-//   are the MFMA's M index), and MFMA row i of a 32-column tile reads W row 16*((i>>2)&1) + 4*(i>>3) + (i&3), so that lane
-//   (j = lane & 31, h = lane >> 5) ends up with the 16 consecutive output columns 16*h .. 16*h+15 of output row j in
-//   accumulator registers 0..15.  Fragment chunk of k-slice s (16 k-values): 2*s + h; one swizzle key (key_a) for both tiles.
-struct MmaAcc32 {
-    typedef float f32x16 __attribute__((ext_vector_type(16)));
-    static __device__ __forceinline__ void run(const u32x4& w, const u32x4& a, f32x16& c) {
-        asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(w), "v"(a));
-    }
-    static __device__ __forceinline__ void run0(const u32x4& w, const u32x4& a, f32x16& c) {
-        asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=a"(c) : "v"(w), "v"(a));
-    }
-};
-
-template <int VAR>
-__global__ __launch_bounds__(GEMMQ_THREADS, 1) void gemm256x_kernel(const bf16_t* __restrict__ A, int64_t lda,
-                                                                    const bf16_t* __restrict__ W, int64_t ldw,
-                                                                    bf16_t* __restrict__ C, int64_t ldc, int64_t M, int N,
-                                                                    int K, int tiles_m, int tiles_n, int a_blocked,
-                                                                    bf16_t* __restrict__ C2, int nsplit, int out_blocked) {
-    typedef bf16_t T;
-    typedef MmaAcc32::f32x16 f32x16;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);    // 0..3
-    const int gstride = (int)gridDim.x;
-    const int nblk = tiles_m * tiles_n;
-    const int nkt = (K * (int)sizeof(T)) / ROWB;
-    if ((int)blockIdx.x >= nblk) return;
-    const int my_tiles = (nblk - (int)blockIdx.x + gstride - 1) / gstride;
-    const int G = my_tiles * nkt;
-
-    auto tile_coords = [&](int tile, int64_t& m0, int& n0) {
-        const int xcd = tile & 7, idx = tile >> 3;
-        const int q = nblk >> 3, r = nblk & 7;
-        const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-        const int gsz = GROUP_M * tiles_n;
-        const int g = logical / gsz;
-        const int first_m = g * GROUP_M;
-        const int gm = min(GROUP_M, tiles_m - first_m);
-        const int in_g = logical - g * gsz;
-        m0 = (int64_t)(first_m + in_g % gm) * BM2;
-        n0 = (in_g / gm) * BN2;
-    };
-
-    const int64_t a_pieces = (lda * (int64_t)sizeof(T)) >> 7;
-    uint32_t a_lo[8], w_lo[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int row = wave * 64 + i * 8 + (lane >> 3);
-        const int64_t ab = a_blocked ? ((int64_t)(row >> 3) * a_pieces << 10) + ((row & 7) << 7) : (int64_t)row * lda * (int64_t)sizeof(T);
-        a_lo[i] = (uint32_t)(ab + (((lane & 7) ^ key_a(row)) << 4));
-        w_lo[i] = (uint32_t)((int64_t)row * ldw * (int64_t)sizeof(T) + (((lane & 7) ^ key_a(row)) << 4));
-    }
-    uint32_t a_base, w_base;
-    auto set_pa = [&](int64_t m0) {
-        a_base = (uint32_t)(a_blocked ? ((m0 >> 3) * a_pieces << 10) : m0 * lda * (int64_t)sizeof(T));
-    };
-    auto set_pw = [&](int n0) { w_base = (uint32_t)((int64_t)n0 * ldw * (int64_t)sizeof(T)); };
-    int a_tile = blockIdx.x, a_kt = 0, a_g = 0;
-    int w_tile = blockIdx.x, w_kt = 0, w_g = 0;
-    auto a_piece = [&](int sa, int p) {
-        const uint32_t soff = a_base + (uint32_t)a_kt * (a_blocked ? 1024u : (uint32_t)ROWB);
-        blds16(A, a_lo[p], soff, smem + sa * A2_BYTES + (wave * 64 + p * 8) * ROWB);
-    };
-    auto a_issue = [&](int sa) {
-#pragma unroll
-        for (int p = 0; p < 8; ++p) a_piece(sa, p);
-    };
-    auto w_piece = [&](int sw, int p) {
-        const uint32_t soff = w_base + (uint32_t)w_kt * (uint32_t)ROWB;
-        blds16(W, w_lo[p], soff, smem + GEMM3_OFF_W + sw * W2_BYTES + (wave * 64 + p * 8) * ROWB);
-    };
-    auto w_issue = [&](int sw) {
-#pragma unroll
-        for (int p = 0; p < 8; ++p) w_piece(sw, p);
-    };
-    auto a_advance = [&]() {
-        if (a_g + 1 < G) {
-            ++a_g;
-            if (++a_kt == nkt) {
-                a_kt = 0;
-                a_tile += gstride;
-                int64_t m0; int n0;
-                tile_coords(a_tile, m0, n0);
-                set_pa(m0);
-            }
-        }
-    };
-    auto w_advance = [&]() {
-        if (w_g + 1 < G) {
-            ++w_g;
-            if (++w_kt == nkt) {
-                w_kt = 0;
-                w_tile += gstride;
-                int64_t m0; int n0;
-                tile_coords(w_tile, m0, n0);
-                set_pw(n0);
-            }
-        }
-    };
-
-    const int wm = wave >> 1, wn = wave & 1;
-    const int lj = lane & 31, lh = lane >> 5;
-    const int wperm = 16 * ((lj >> 2) & 1) + 4 * (lj >> 3) + (lj & 3);      // W row (inside a 32-row tile) this lane supplies
-    int a_fo[4], w_fo[4];                              // fragment byte offsets for k-slice 0 (chunk lh); slice s: ^ (s << 5)
-#pragma unroll
-    for (int b = 0; b < 4; ++b) {
-        const int ra = wm * 128 + b * 32 + lj;
-        a_fo[b] = ra * ROWB + ((lh ^ key_a(ra)) << 4);
-        const int rw = wn * 128 + b * 32 + wperm;
-        w_fo[b] = GEMM3_OFF_W + rw * ROWB + ((lh ^ key_a(rw)) << 4);
-    }
-    // fragment sets of one k-step: index [b + 4 * sl], sl = k-slice inside the k-step (0, 1)
-    auto load_frags = [&](int sa, int sw, int kk, u32x4 (&a)[8], u32x4 (&w)[8]) {
-        const int ab = sa * A2_BYTES, wb = sw * W2_BYTES;
-#pragma unroll
-        for (int f = 0; f < 8; ++f) {
-            const int kx = (2 * kk + (f >> 2)) << 5;
-            w[f] = *reinterpret_cast<const u32x4*>(smem + ((wb + w_fo[f & 3]) ^ kx));
-        }
-#pragma unroll
-        for (int f = 0; f < 8; ++f) {
-            const int kx = (2 * kk + (f >> 2)) << 5;
-            a[f] = *reinterpret_cast<const u32x4*>(smem + ((ab + a_fo[f & 3]) ^ kx));
-        }
-    };
-
-    f32x16 acc[4][4];
-    // one k-step: 2 k-slices x 4 x 4 MFMAs (32 cycles each).  Behind MFMA t: an LDS-DMA piece when t % 4 == 1 (8 pieces), else
-    // the next fragment read of the NEXT k-step while any are left (16 reads: W first, then A) -> all issued by t = 22.
-    auto kstep = [&](const u32x4 (&ac)[8], const u32x4 (&wc)[8], u32x4 (&an)[8], u32x4 (&wnx)[8], int nsa, int nsw, int nkk,
-                     bool dma_a, int dma_stage, auto first_tag) {
-        constexpr bool FIRST = decltype(first_tag)::value;
-        const int abn = nsa * A2_BYTES, wbn = nsw * W2_BYTES;
-        auto rd = [&](int idx) {                       // idx 0..7: W' fragments, 8..15: A' fragments
-            const int f = idx & 7;
-            const int kx = (2 * nkk + (f >> 2)) << 5;
-            if (idx < 8) wnx[f] = *reinterpret_cast<const u32x4*>(smem + ((wbn + w_fo[f & 3]) ^ kx));
-            else an[f] = *reinterpret_cast<const u32x4*>(smem + ((abn + a_fo[f & 3]) ^ kx));
-        };
-        auto dma = [&](int p) { if (dma_a) a_piece(dma_stage, p); else w_piece(dma_stage, p); };
-#pragma unroll
-        for (int t = 0; t < 32; ++t) {
-            const int sl = t >> 4, mb = (t >> 2) & 3, nb = t & 3;
-            if (FIRST && sl == 0) MmaAcc32::run0(wc[nb + 4 * sl], ac[mb + 4 * sl], acc[mb][nb]);
-            else MmaAcc32::run(wc[nb + 4 * sl], ac[mb + 4 * sl], acc[mb][nb]);
-            if constexpr (VAR == 2) {                  // reads first (one per MFMA), then the DMA pieces behind every second MFMA
-                if (t < 16) rd(t);
-                else if ((t & 1) == 0) dma((t - 16) >> 1);
-            } else if constexpr (VAR == 3) {           // DMA pieces behind MFMA 3, 7, ...; reads in the other slots
-                if ((t & 3) == 3) dma(t >> 2);
-                else {
-                    const int ridx = t - (t >> 2);
-                    if (ridx < 16) rd(ridx);
-                }
-            } else {
-                if ((t & 3) == 1) dma(t >> 2);
-                else {
-                    const int ridx = t - ((t + 2) >> 2);   // t = 0,2,3,4,6,7,8,... -> 0,1,2,3,4,5,6,...
-                    if (ridx < 16) rd(ridx);
-                }
-            }
-            if constexpr (VAR != 4) __builtin_amdgcn_sched_barrier(0);
-        }
-    };
-    // lane (j = row inside a 32-row block, h): per (mb, nb) the 16 consecutive columns nb*32 + 16*h .. +15 of row mb*32 + j
-    auto epilogue = [&](int64_t m0, int n0) {
-#pragma unroll
-        for (int nb = 0; nb < 4; ++nb) {
-            const int ncol = n0 + wn * 128 + nb * 32;                   // wave-uniform; 32-column group lies in one output
-            char* base;
-            int64_t row_bytes;                                          // plain layout: bytes per row;  blocked: pieces per row
-            int col;
-            bool blockedl = false;
-            if (C2 != nullptr) {
-                const bool second = ncol >= nsplit;
-                const int width = second ? N - nsplit : nsplit;
-                col = (second ? ncol - nsplit : ncol) + lh * 16;
-                base = reinterpret_cast<char*>(second ? C2 : C);
-                blockedl = out_blocked != 0;
-                row_bytes = blockedl ? (((int64_t)width * sizeof(T)) >> 7) : (int64_t)width * sizeof(T);
-            } else {
-                col = ncol + lh * 16;
-                base = reinterpret_cast<char*>(C);
-                row_bytes = ldc * (int64_t)sizeof(T);
-            }
-#pragma unroll
-            for (int mb = 0; mb < 4; ++mb) {
-                const int64_t mrow = m0 + wm * 128 + mb * 32 + lj;
-                f32x16 t = acc[mb][nb];
-                asm volatile("" : "+v"(t));
-                float lo[8], hi[8];
-#pragma unroll
-                for (int e = 0; e < 8; ++e) { lo[e] = t[e]; hi[e] = t[8 + e]; }
-                T* dst = reinterpret_cast<T*>(blockedl ? base + blocked_off(mrow, (int64_t)col * sizeof(T), row_bytes)
-                                                       : base + mrow * row_bytes + (int64_t)col * sizeof(T));
-                store8<T>(dst, lo);
-                store8<T>(dst + 8, hi);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-    };
-
-    int tile = blockIdx.x;
-    int64_t m0; int n0;
-    tile_coords(tile, m0, n0);
-    set_pa(m0);
-    set_pw(n0);
-    a_issue(0); a_advance();
-    w_issue(0); w_advance();
-    a_issue(1); a_advance();
-    w_issue(1); w_advance();
-    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    u32x4 fa0[8], fw0[8], fa1[8], fw1[8];
-    load_frags(0, 0, 0, fa0, fw0);
-    int sa = 0, sw = 0, kt = 0;
-    while (true) {
-        const int sa_n = sa == 2 ? 0 : sa + 1;
-        const int sa_f = sa == 0 ? 2 : sa - 1;
-        if (kt == 0) kstep(fa0, fw0, fa1, fw1, sa, sw, 1, true, sa_f, std::true_type{});
-        else kstep(fa0, fw0, fa1, fw1, sa, sw, 1, true, sa_f, std::false_type{});
-        a_advance();
-        asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        kstep(fa1, fw1, fa0, fw0, sa_n, sw ^ 1, 0, false, sw, std::false_type{});
-        w_advance();
-        sa = sa_n;
-        sw ^= 1;
-        if (kt + 1 < nkt) {
-            ++kt;
-        } else {
-            epilogue(m0, n0);
-            tile += gstride;
-            if (tile >= nblk) break;
-            tile_coords(tile, m0, n0);
-            kt = 0;
-        }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-}
-
 // persistent launch: 1 resident block of 8 waves per CU (LDS-limited), a multiple of 8 so block b stays on XCD b & 7
 static int persistent_grid(int nblk) {
     static int cus = 0;
@@ -1175,17 +924,6 @@ static hipError_t launch_gemm256_t(const void* A, int64_t lda, const void* W, in
     const int64_t esz_ = (int64_t)sizeof(T);
     if (quad && M % BM2 == 0 && N % BN2 == 0 && (C2 == nullptr || nsplit % 64 == 0) && M * lda * esz_ < ((int64_t)1 << 32) - 65536 &&
         (int64_t)N * ldw * esz_ < ((int64_t)1 << 32) - 65536) {     // unsigned 32-bit buffer offsets
-        if constexpr (std::is_same<T, bf16_t>::value) {
-            static const int x32 = dev_env("PCAD_GEMM_X32") ? atoi(dev_env("PCAD_GEMM_X32")) : 0;   // PCAD_DEV=1 only: 32x32x16 experiment
-            if (x32) {
-                auto kx = x32 == 2 ? gemm256x_kernel<2> : x32 == 3 ? gemm256x_kernel<3> : x32 == 4 ? gemm256x_kernel<4> : gemm256x_kernel<1>;
-                hipError_t e = hipFuncSetAttribute((const void*)kx, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM3_LDS);
-                if (e != hipSuccess) return e;
-                hipLaunchKernelGGL(kx, grid, dim3(GEMMQ_THREADS), GEMM3_LDS, s, (const T*)A, lda, (const T*)W, ldw, (T*)C,
-                                   ldc, M, N, K, tiles_m, tiles_n, (int)a_blocked, (T*)C2, nsplit, (int)out_blocked);
-                return hipGetLastError();
-            }
-        }
         auto kq = gemm256q_kernel<T, T>;
         static bool attr_q = false;
         if (!attr_q) {
