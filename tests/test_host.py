@@ -162,3 +162,23 @@ def test_last_hidden_only_container_is_loud():
         list(hs)
     out = MaskedLMOutput(loss=None, logits=t, hidden_states=hs)      # survives the HF output dataclass
     assert out.hidden_states[-1] is t and len(out.hidden_states) == 21
+
+
+def test_bench_work_formulas_match_survey_8d():
+    """bench.py's algorithmic work = SURVEY.md §8(d): l32 4.552e11 flop and 1.368 GB per window, l20 4.127e10 / 0.324 GB;
+    the per-kernel §8(d) shares add up to the per-window byte formula."""
+    import bench
+    from plantcaduceus_amd.checkpoint import make_config
+    for size, fl, by in (("l32", 4.552e11, 1.368e9), ("l20", 4.127e10, 0.324e9)):
+        cfg = make_config(size)
+        f, b = bench.per_sequence_work(cfg, 512, 2)
+        assert abs(f / fl - 1) < 2e-3 and abs(b / by - 1) < 2e-3
+        rows = 2 * 512                                   # one window = 2 strands x 512 rows
+        w = bench.algorithmic_work(cfg, rows, 2)
+        per_layer = (w["add_rmsnorm"]["bytes_8d"] + w["gemm_in_proj"]["bytes_8d"] + w["conv_xproj_fused"]["bytes_8d"] +
+                     2 * w["selective_scan"]["bytes_8d"] + w["gemm_out_proj"]["bytes_8d"])
+        assert abs(per_layer * cfg.n_layer / b - 1) < 1e-9
+        fl_layer = (w["gemm_in_proj"]["flops"] + w["gemm_out_proj"]["flops"] + 2 * 2.0 * rows * cfg.d_inner * (cfg.dt_rank + 32)
+                    + 2 * 2.0 * rows * cfg.dt_rank * cfg.d_inner)
+        assert abs(fl_layer * cfg.n_layer / f - 1) < 1e-9
+    assert len(bench.source_hash()) == 16
