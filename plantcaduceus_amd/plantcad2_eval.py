@@ -311,3 +311,73 @@ def sv_effect(data, model, tokenizer, device="cuda:0", batch_size: int = 64, fla
         out["score"] = scores
         out.drop(columns=["Left5_Positions", "Right5_Positions"], errors="ignore").to_csv(output, sep="\t", index=False)
     return res
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# command line: the reference's `python src/zero-shot-eval.py <sub-command> --repo_id ... --task ... --model ...`
+# (Fire CLI, :533-534; flags as in docs/zero-shot-eval.md).  `--data <local table>` replaces --repo_id/--task when the
+# table is a file; everything else keeps the reference's names and defaults.
+def _load_model(model: str, device: str):
+    """`_load_model` (:42-72): bf16 on the GPU; tokenizer from the same snapshot."""
+    from .zero_shot import load_model_and_tokenizer
+    return load_model_and_tokenizer(model, device)
+
+
+def main(argv: Optional[Sequence[str]] = None):
+    import argparse
+    p = argparse.ArgumentParser(prog="plantcad2_eval", description="PlantCAD2 zero-shot evaluation tasks on the MI355X engine")
+    sub = p.add_subparsers(dest="cmd", required=True)
+
+    def common(q, batch_size):
+        for f in ("repo_id", "task"):
+            q.add_argument("--" + f, "--" + f.replace("_", "-"), dest=f, default=None)
+        q.add_argument("--data", default=None, help="local .tsv/.csv/.parquet table instead of --repo_id/--task")
+        q.add_argument("--split", default="valid")
+        q.add_argument("--model", default="kuleshov-group/PlantCAD2-Small-l24-d0768")
+        q.add_argument("--device", default="cuda:0")
+        q.add_argument("--batch_size", "--batch-size", dest="batch_size", type=int, default=batch_size)
+
+    def masked(q):
+        q.add_argument("--seq_column", "--seq-column", dest="seq_column", default="sequence")
+        for f in ("save_logits", "logits_path", "metrics_json"):
+            q.add_argument("--" + f, "--" + f.replace("_", "-"), dest=f, default=None)
+
+    def idx_list(v):
+        return [int(x) for x in str(v).strip("[]() ").replace(" ", "").split(",") if x != ""]
+
+    q = sub.add_parser("evo_cons"); common(q, 128); masked(q)
+    q.add_argument("--token_idx", "--token-idx", dest="token_idx", type=int, default=255)
+    for name in ("motif_acc", "core_noncore"):
+        q = sub.add_parser(name); common(q, 128); masked(q)
+        q.add_argument("--mask_idx", "--mask-idx", dest="mask_idx", type=idx_list, default=[255, 256, 257])
+        q.add_argument("--motif_len", "--motif-len", dest="motif_len", type=int, default=3)
+        if name == "core_noncore":
+            q.add_argument("--label_column", "--label-column", dest="label_column", default="label")
+    q = sub.add_parser("sv_effect"); common(q, 64)
+    q.add_argument("--flanking", type=int, default=5)
+    for f in ("output", "save_ref_logits", "save_mut_logits"):
+        q.add_argument("--" + f, "--" + f.replace("_", "-"), dest=f, default=None)
+    a = p.parse_args(argv)
+
+    logging.basicConfig(level=logging.INFO, format="%(asctime)s %(levelname)s %(message)s")
+    if a.data is None and not (a.repo_id and a.task):
+        p.error("give --data <table> or --repo_id and --task")
+    data = a.data if a.data is not None else (a.repo_id, a.task, a.split)
+    need_model = a.cmd == "sv_effect" or getattr(a, "logits_path", None) is None
+    model, tok = _load_model(a.model, a.device) if need_model else (None, None)
+    if a.cmd == "evo_cons":
+        return evo_cons(data, model, tok, a.device, token_idx=a.token_idx, batch_size=a.batch_size, seq_column=a.seq_column,
+                        save_logits=a.save_logits, logits_path=a.logits_path, metrics_json=a.metrics_json)
+    if a.cmd == "motif_acc":
+        return motif_acc(data, model, tok, a.device, mask_idx=a.mask_idx, motif_len=a.motif_len, batch_size=a.batch_size,
+                         seq_column=a.seq_column, save_logits=a.save_logits, logits_path=a.logits_path, metrics_json=a.metrics_json)
+    if a.cmd == "core_noncore":
+        return core_noncore(data, model, tok, a.device, mask_idx=a.mask_idx, motif_len=a.motif_len, batch_size=a.batch_size,
+                            seq_column=a.seq_column, label_column=a.label_column, save_logits=a.save_logits,
+                            logits_path=a.logits_path, metrics_json=a.metrics_json)
+    return sv_effect(data, model, tok, a.device, batch_size=a.batch_size, flanking=a.flanking, output=a.output,
+                     save_ref_logits=a.save_ref_logits, save_mut_logits=a.save_mut_logits)
+
+
+if __name__ == "__main__":
+    main()

@@ -263,3 +263,33 @@ def test_plantcad2_task_table_sources(tmp_path, monkeypatch):
     got = pe._frame(("kuleshov-group/cross-species-single-nucleotide-annotation", "conservation", "valid"))
     assert calls == [("kuleshov-group/cross-species-single-nucleotide-annotation", "conservation")]
     assert list(got["label"]) == [1, 0] and list(got.index) == [0, 1]
+
+
+def test_plantcad2_command_line(tmp_path, monkeypatch, capsys):
+    """`python -m plantcaduceus_amd.plantcad2_eval <sub-command> ...` with the reference's flag names (docs/zero-shot-eval.md):
+    same numbers as calling the drivers; `--logits_path` skips the model; the oracle stand-in as the loaded model otherwise."""
+    from plantcaduceus_amd import plantcad2_eval as pe
+    rng = np.random.default_rng(3)
+    n, L = 12, 40
+    seqs = ["".join(rng.choice(list("ACGT"), size=L)) for _ in range(n)]
+    tab = tmp_path / "task.tsv"
+    pd.DataFrame({"sequence": seqs, "label": rng.integers(0, 2, size=n)}).to_csv(tab, sep="\t", index=False)
+    cfg = make_config("x", d_model=32, n_layer=1)
+    model = O.OracleForMaskedLM(O.params_from_state_dict(synthetic_state_dict(cfg, seed=2), cfg))
+    tok = CaduceusTokenizer()
+    monkeypatch.setattr(pe, "_load_model", lambda m, d: (model, tok))
+    want = pe.evo_cons(str(tab), model, tok, "cpu", token_idx=19, batch_size=5)
+    got = pe.main(["evo_cons", "--data", str(tab), "--device", "cpu", "--token_idx", "19", "--batch_size", "5",
+                   "--save_logits", str(tmp_path / "p.tsv"), "--metrics_json", str(tmp_path / "m.json")])
+    assert got == want and set(json.load(open(tmp_path / "m.json"))) == {"auroc", "auprc", "token_idx"}
+    monkeypatch.setattr(pe, "_load_model", lambda m, d: (_ for _ in ()).throw(AssertionError("model loaded despite --logits_path")))
+    again = pe.main(["evo_cons", "--data", str(tab), "--token-idx", "19", "--logits-path", str(tmp_path / "p.tsv")])
+    assert again["AUROC"] == pytest.approx(want["AUROC"], abs=1e-6)
+    monkeypatch.setattr(pe, "_load_model", lambda m, d: (model, tok))
+    a = pe.main(["motif_acc", "--data", str(tab), "--device", "cpu", "--mask_idx", "18,19,20", "--motif_len", "3"])
+    assert a == pe.motif_acc(str(tab), model, tok, "cpu", mask_idx=(18, 19, 20), motif_len=3)
+    c = pe.main(["core_noncore", "--data", str(tab), "--device", "cpu", "--mask_idx", "[18,19,20]"])
+    assert set(c) == {"AUROC", "AUPRC"}
+    with pytest.raises(SystemExit):
+        pe.main(["evo_cons", "--device", "cpu"])
+    assert "AUROC\t" in capsys.readouterr().out
