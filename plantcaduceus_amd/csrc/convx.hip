@@ -364,271 +364,6 @@ __global__ __launch_bounds__(CX_THREADS, 2) void convx_kernel(const T* __restric
     }
 }
 
-// =====================================================================================================================
-// Wave-specialised form of the same kernel (round 2): waves 0-3 (one per SIMD) only CONVOLVE — both directions of K-tile it
-// into conv stage it & 1; waves 4-7 (one per SIMD) issue every LDS-DMA and run the MFMAs + the xc copy-out of K-tile it-1 from
-// conv stage (it-1) & 1.  Same LDS image, same single barrier per K-tile, same arithmetic (bit-identical outputs), but the VALU
-// stream of a SIMD now runs beside the MFMA / LDS / global-store stream of ANOTHER wave instead of alternating with it inside one
-// wave, and the conv waves never block on a DMA issue or a vmcnt.
-template <typename T, bool ZFILL>
-__global__ __launch_bounds__(CX_THREADS, 2) void convx2_kernel(const T* __restrict__ x, const float* __restrict__ convw,
-                                                               ConvxDir d0, ConvxDir d1, int S, int L, int E) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int CPC = Chunk<T>::CPC;
-    constexpr int KC = CX_ROWB / (int)sizeof(T);
-    constexpr int CW_PIECES = (2 * 5 * KC * 4 + 1023) / 1024;
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);    // 0..7
-    const bool gemm_role = wave >= 4;                             // wave-uniform
-    const int gw = wave & 3;                                      // index inside the role
-    const int tiles_per_strand = (L + CX_ROWS - 1) / CX_ROWS;
-    const int strand = blockIdx.x / tiles_per_strand;
-    const int t0 = (blockIdx.x - strand * tiles_per_strand) * CX_ROWS;
-    const int64_t row0 = (int64_t)strand * L;
-    const int nkt = E / KC;
-    const int64_t pieces = nkt;
-
-    // ---- staging, gemm waves only: per K-tile 5 raw groups (g, g+4, g+8, g+12 and, redundantly, 16) + 6 Wx groups + 1 taps piece
-    uint32_t raw_src[5];
-    int raw_dst[5];
-    const char* raw_base = reinterpret_cast<const char*>(x);
-    uint32_t raw_records = 0xfffffffcu;
-    if (ZFILL) {
-        raw_base += (row0 >> 3) * pieces * 1024;
-        raw_records = (uint32_t)((int64_t)(L >> 3) * pieces * 1024);
-    }
-#pragma unroll
-    for (int i = 0; i < 5; ++i) {
-        const int grp = i < 4 ? gw + 4 * i : 16;
-        const int q = grp * 8 + (lane >> 3);
-        if (ZFILL) {
-            const int t = t0 - 3 + q;
-            raw_src[i] = (uint32_t)((int64_t)(t >> 3) * pieces * 1024 + ((t & 7) << 7) + ((lane & 7) << 4));
-        } else {
-            const int t = min(max(t0 - 3 + q, 0), L - 1);
-            raw_src[i] = (uint32_t)(blocked_off(row0 + t, 0, pieces) + ((lane & 7) << 4));
-        }
-        raw_dst[i] = grp * 8 * CX_ROWB;
-    }
-    uint32_t w_src[6];
-    int w_dst[6], w_dir[6];
-#pragma unroll
-    for (int i = 0; i < 6; ++i) {
-        const int grp = gw * 6 + i;                                // 0..23
-        const int dir = grp / 12, g = grp - dir * 12;
-        const int r = g * 8 + (lane >> 3);
-        w_dir[i] = dir;
-        w_src[i] = (uint32_t)((int64_t)r * E * (int64_t)sizeof(T) + (((lane & 7) ^ cx_key(r)) << 4));
-        w_dst[i] = dir * CX_W_BYTES + g * 8 * CX_ROWB;
-    }
-    const uint32_t cw_src = (uint32_t)((gw % CW_PIECES) * 1024 + lane * 16);
-    const int cw_dst = (gw % CW_PIECES) * 1024;
-    auto stage_raw = [&](int kt, int par) __attribute__((always_inline)) {
-        char* base = smem + par * CX_RAW_BYTES;
-#pragma unroll
-        for (int i = 0; i < 5; ++i) cx_blds16(raw_base, raw_src[i], (uint32_t)kt * 1024u, base + raw_dst[i], raw_records);
-    };
-    auto stage_w = [&](int kt, int par) __attribute__((always_inline)) {
-        char* wb = smem + CX_OFF_W + par * 2 * CX_W_BYTES;
-#pragma unroll
-        for (int i = 0; i < 6; ++i) cx_blds16(w_dir[i] ? d1.Wx : d0.Wx, w_src[i], (uint32_t)kt * (uint32_t)CX_ROWB, wb + w_dst[i]);
-    };
-    auto stage_taps = [&](int kt, int par) __attribute__((always_inline)) {
-        cx_blds16(convw, cw_src, (uint32_t)kt * (uint32_t)CX_CW_BYTES, smem + CX_OFF_CW + par * CX_CW_BYTES + cw_dst);
-    };
-
-    // ---- conv waves: thread = (16-byte chunk c8, 4 consecutive rows g4) of the 128-row tile, both directions in turn --------
-    const int ct_id = tid & 255;
-    const int c8 = ct_id & 7;
-    const int g4 = (ct_id >> 3) * 4;
-    // Both directions from ONE 10-row window (raw rows g4 .. g4+9: the causal outputs use rows j .. j+3, the anti-causal ones
-    // rows j+3 .. j+6): 10 instead of 2 x 7 window reads and unpacks per half, and two independent dependency chains per output
-    // element (fwd, rev) for the single conv wave of a SIMD to interleave.
-    auto conv_both = [&](int par) __attribute__((always_inline)) {
-        const char* raw = smem + par * CX_RAW_BYTES;
-        const float* cw = reinterpret_cast<const float*>(smem + CX_OFF_CW + par * CX_CW_BYTES) + c8 * CPC;
-        char* ctf = smem + CX_OFF_C + par * 2 * CX_TILE_BYTES;
-        char* ctr = ctf + CX_TILE_BYTES;
-        const f32x2_t nl2e = {-kLog2e, -kLog2e}, one = {1.0f, 1.0f};
-        constexpr int HC = CPC / 2;
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            f32x2_t wt[2][4][HC / 2], bias[2][HC / 2];
-#pragma unroll
-            for (int d = 0; d < 2; ++d)
-#pragma unroll
-                for (int k = 0; k < 5; ++k)
-#pragma unroll
-                    for (int e = 0; e < HC; e += 2) {
-                        const f32x2_t v = *reinterpret_cast<const f32x2_t*>(cw + d * 5 * KC + k * KC + h * HC + e);
-                        if (k < 4) wt[d][k][e / 2] = v; else bias[d][e / 2] = v;
-                    }
-            f32x2_t win[10][HC / 2];
-#pragma unroll
-            for (int j = 0; j < 10; ++j) {
-                const int q = g4 + j;
-                const int t = t0 - 3 + q;
-                u32x2 r = *reinterpret_cast<const u32x2*>(raw + q * CX_ROWB + c8 * 16 + h * 8);
-                if (!ZFILL) {
-                    const unsigned keep = 0u - (unsigned)((unsigned)t < (unsigned)L);
-                    r &= u32x2{keep, keep};
-                }
-                float w1[HC];
-                Chunk<T>::unpack_half(r, w1);
-#pragma unroll
-                for (int e = 0; e < HC / 2; ++e) win[j][e] = f32x2_t{w1[2 * e], w1[2 * e + 1]};
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                float of[HC], orv[HC];
-#pragma unroll
-                for (int e = 0; e < HC / 2; ++e) {
-                    f32x2_t af = bias[0][e], ar = bias[1][e];
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        af = wt[0][k][e] * win[j + k][e] + af;              // x[t-3+k]
-                        ar = wt[1][k][e] * win[j + 6 - k][e] + ar;          // x[t+3-k]
-                    }
-                    const f32x2_t xf = af * nl2e, xr = ar * nl2e;
-                    const f32x2_t df = f32x2_t{fast_exp2(xf[0]), fast_exp2(xf[1])} + one;
-                    const f32x2_t dr = f32x2_t{fast_exp2(xr[0]), fast_exp2(xr[1])} + one;
-                    const f32x2_t sf = af * f32x2_t{fast_rcp(df[0]), fast_rcp(df[1])};
-                    const f32x2_t sr = ar * f32x2_t{fast_rcp(dr[0]), fast_rcp(dr[1])};
-                    of[2 * e] = sf[0]; of[2 * e + 1] = sf[1];
-                    orv[2 * e] = sr[0]; orv[2 * e + 1] = sr[1];
-                }
-                const int r = g4 + j;
-                const int off = r * CX_ROWB + ((c8 ^ cx_key(r)) << 4) + h * 8;
-                *reinterpret_cast<u32x2*>(ctf + off) = Chunk<T>::pack_half(of);
-                *reinterpret_cast<u32x2*>(ctr + off) = Chunk<T>::pack_half(orv);
-            }
-        }
-    };
-
-    // ---- gemm waves: 32 rows (mq) x 96 columns x both directions; copy-out of rows 32 mq .. 32 mq + 31 of cf and cr ---------
-    const int mq = gw;
-    const int li = lane & 15, lg = lane >> 4;
-    int frag_lo[2];
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) frag_lo[kk] = li * CX_ROWB + (((kk * 4 + lg) ^ cx_key(li)) << 4);
-    f32x4 acc[2][2][6];
-#pragma unroll
-    for (int d = 0; d < 2; ++d)
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 6; ++j) acc[d][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    T* xcf = (T*)d0.xc;
-    T* xcr = (T*)d1.xc;
-    const bool full_tile = t0 + CX_ROWS <= L;
-    auto mfma_tile = [&](int mpar, int d) __attribute__((always_inline)) {
-        const char* at = smem + CX_OFF_C + mpar * 2 * CX_TILE_BYTES + d * CX_TILE_BYTES;
-        const char* wb = smem + CX_OFF_W + mpar * 2 * CX_W_BYTES + d * CX_W_BYTES;
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            u32x4 af[2], wfr[6];
-#pragma unroll
-            for (int i = 0; i < 2; ++i) af[i] = *reinterpret_cast<const u32x4*>(at + (mq * 32 + i * 16) * CX_ROWB + frag_lo[kk]);
-#pragma unroll
-            for (int j = 0; j < 6; ++j) wfr[j] = *reinterpret_cast<const u32x4*>(wb + j * 16 * CX_ROWB + frag_lo[kk]);
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 6; ++j) acc[d][i][j] = CxMma<T>::run(wfr[j], af[i], acc[d][i][j]);
-        }
-    };
-    const int cr0 = mq * 32 + (lane >> 3);
-    const uint32_t xc_lo = (uint32_t)(blocked_off(row0 + t0 + cr0, 0, pieces) + ((lane & 7) << 4));
-    const uint32_t xc_blk = (uint32_t)(pieces << 10);
-    int c_lds[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) c_lds[i] = (cr0 + i * 8) * CX_ROWB + (((lane & 7) ^ cx_key(cr0 + i * 8)) << 4);
-    auto copy_out = [&](int mt, int mpar) __attribute__((always_inline)) {
-#pragma unroll
-        for (int d = 0; d < 2; ++d) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const u32x4 v = *reinterpret_cast<const u32x4*>(smem + CX_OFF_C + mpar * 2 * CX_TILE_BYTES + d * CX_TILE_BYTES +
-                                                               c_lds[i]);
-                if (t0 + cr0 + i * 8 < L) {
-                    char* dst = reinterpret_cast<char*>(d ? xcr : xcf) + (xc_lo + (uint32_t)i * xc_blk + (uint32_t)mt * 1024u);
-                    *reinterpret_cast<u32x4*>(dst) = v;
-                }
-            }
-        }
-    };
-
-    // The two roles run SEPARATE loops (the same number of s_barrier each: nkt + 1), so the register allocator sees the
-    // accumulators only in the gemm loop and the conv window / taps only in the conv loop (one merged loop body needed the sum of
-    // both and spilled).  Unrolled by two so that every LDS stage offset is a compile-time constant.
-    if (!gemm_role) {
-        auto conv_iter = [&](int it, auto par_tag) __attribute__((always_inline)) {
-            constexpr int P = decltype(par_tag)::value;
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-            if (it < nkt) conv_both(P);
-        };
-        for (int it = 0; it <= nkt; it += 2) {
-            conv_iter(it, std::integral_constant<int, 0>{});
-            if (it + 1 <= nkt) conv_iter(it + 1, std::integral_constant<int, 1>{});
-        }
-        return;
-    }
-    stage_taps(0, 0);
-    stage_raw(0, 0);
-    auto gemm_iter = [&](int it, auto par_tag) __attribute__((always_inline)) {
-        constexpr int P = decltype(par_tag)::value;               // it & 1
-        // the 12 DMAs of the previous iteration (Wx(it-1), taps(it), raw(it)) must have landed; younger than those are only
-        // that iteration's 8 xc stores
-        if (full_tile && it >= 2) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        if (it < nkt) stage_w(it, P);
-        if (it + 1 < nkt) { stage_taps(it + 1, 1 - P); stage_raw(it + 1, 1 - P); }
-        if (it > 0) {
-            mfma_tile(1 - P, 0);
-            mfma_tile(1 - P, 1);
-            copy_out(it - 1, 1 - P);
-        }
-    };
-    for (int it = 0; it <= nkt; it += 2) {
-        gemm_iter(it, std::integral_constant<int, 0>{});
-        if (it + 1 <= nkt) gemm_iter(it + 1, std::integral_constant<int, 1>{});
-    }
-
-    // ---- epilogue (gemm waves): lane (li = row, lg): fragment j -> columns j*16 + lg*4 .. +3 ---------------------------------
-#pragma unroll
-    for (int d = 0; d < 2; ++d) {
-        const ConvxDir dd = d ? d1 : d0;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int t = t0 + mq * 32 + i * 16 + li;
-            if (t >= L) continue;
-            const int64_t row = row0 + t;
-            T* dl = (T*)dd.dtl + row * 64;
-            float* bcr = dd.bc + row * 32;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                if constexpr (sizeof(T) == 2) {
-                    u32x2 v = {pack_bf16x2(acc[d][i][j][0], acc[d][i][j][1]), pack_bf16x2(acc[d][i][j][2], acc[d][i][j][3])};
-                    *reinterpret_cast<u32x2*>(dl + j * 16 + lg * 4) = v;
-                } else {
-                    *reinterpret_cast<f32x4*>(dl + j * 16 + lg * 4) = acc[d][i][j];
-                }
-            }
-#pragma unroll
-            for (int j = 4; j < 6; ++j) {
-                f32x4 v = {Elem<T>::round(acc[d][i][j][0]), Elem<T>::round(acc[d][i][j][1]), Elem<T>::round(acc[d][i][j][2]),
-                           Elem<T>::round(acc[d][i][j][3])};
-                *reinterpret_cast<f32x4*>(bcr + (j - 4) * 16 + lg * 4) = v;
-            }
-        }
-    }
-}
-
 // conv taps of both directions -> per K-tile [dir][tap 0..3, bias][KC] fp32 (CX_CW_BYTES per K-tile, zero padded)
 __global__ __launch_bounds__(256) void pack_convw_kernel(const float* __restrict__ wf, const float* __restrict__ bfw,
                                                          const float* __restrict__ wr, const float* __restrict__ brw,
@@ -670,11 +405,11 @@ hipError_t launch_convx(const void* x, const float* convw, const void* Wx0, void
     ConvxDir d0{Wx0, xc0, dtl0, bc0}, d1{Wx1, xc1, dtl1, bc1};
     const int tiles = S * ((L + CX_ROWS - 1) / CX_ROWS);
     const bool zfill = L % 8 == 0;
-    static const bool spec = dev_env("PCAD_CONVX2") != nullptr;    // PCAD_DEV=1 only: wave-specialised form (A/B)
 #define PCAD_CONVX(T, Z)                                                                                              \
     do {                                                                                                                \
-        auto k = spec ? convx2_kernel<T, Z> : convx_kernel<T, Z>;                                                       \
-        (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, CX_LDS);                 \
+        auto k = convx_kernel<T, Z>;                                                                                    \
+        static bool attr = false;                                                                                       \
+        if (!attr) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, CX_LDS); attr = true; } \
         hipLaunchKernelGGL(k, dim3((unsigned)tiles), dim3(CX_THREADS), CX_LDS, s, (const T*)x, convw, d0, d1, S, L, E);  \
     } while (0)
     if (dt == BF16) { if (zfill) PCAD_CONVX(bf16_t, true); else PCAD_CONVX(bf16_t, false); }
