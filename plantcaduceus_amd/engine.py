@@ -44,7 +44,7 @@ SIGNATURES = {
     "pcad_create": (C.c_int, [C.POINTER(PcadConfig), C.POINTER(C.c_void_p)]),
     "pcad_destroy": (None, [C.c_void_p]),
     "pcad_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int64]),
-    "pcad_set_aux_streams": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "pcad_set_side_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
     "pcad_weight_arena_bytes": (C.c_size_t, [C.c_void_p]),
     "pcad_bind_weights": (C.c_int, [C.c_void_p, C.POINTER(PcadTensor), C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
     "pcad_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int, C.c_int]),
@@ -241,14 +241,14 @@ class Engine:
         self._ws = None
 
     def set_two_lanes(self, on: bool):
-        """Two-lane chunk pipeline on two torch-owned streams (`pcad_set_aux_streams`)."""
+        """Norm side lane on a torch-owned second stream (`pcad_set_side_stream`): with >= 2 chunks per forward the add+norm
+        kernels of one chunk run beside the other chunk's GEMM / conv / scan kernels."""
         if on:
             with torch.cuda.device(self.device):
-                self._aux = (torch.cuda.Stream(self.device), torch.cuda.Stream(self.device))
-            _check(self.lib.pcad_set_aux_streams(self._h, self._aux[0].cuda_stream, self._aux[1].cuda_stream),
-                   "pcad_set_aux_streams")
+                self._aux = torch.cuda.Stream(self.device)
+            _check(self.lib.pcad_set_side_stream(self._h, self._aux.cuda_stream), "pcad_set_side_stream")
         else:
-            _check(self.lib.pcad_set_aux_streams(self._h, None, None), "pcad_set_aux_streams")
+            _check(self.lib.pcad_set_side_stream(self._h, None), "pcad_set_side_stream")
             self._aux = None
         self._ws = None
 
