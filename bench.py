@@ -55,8 +55,6 @@ def parse():
     ap.add_argument("--seqlen", type=int, default=512)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--cpu-seqs", type=int, default=-1, help="sample size for the CPU baseline (0 = skip)")
-    ap.add_argument("--two-lanes", action="store_true",
-                    help="pcad_set_aux_streams: chunks alternate between two caller-owned streams (measured: no gain, DESIGN.md §8)")
     ap.add_argument("--chunk-seqs", type=int, default=0, help="pcad_set_option chunk_seqs (0 = engine default)")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--profile-stride", type=int, default=7,
@@ -152,8 +150,6 @@ def main():
     eng = Engine(cfg, sd, tdt, device)
     if args.chunk_seqs:
         eng.set_option("chunk_seqs", args.chunk_seqs)
-    if args.two_lanes:
-        eng.set_two_lanes(True)
 
     B, L, p = args.batch, args.seqlen, 255 if args.seqlen > 255 else args.seqlen // 2
     D = cfg.d_model

@@ -14,9 +14,9 @@
  *   - plain C: pointers and sizes only; no torch / HIP types in any signature (`pcad_stream` is a
  *     hipStream_t passed as void*).
  *   - every buffer and every stream is OWNED BY THE CALLER (ids, outputs, weights, weight arena, workspace); the library
- *     owns only the opaque handle (plus the HIP events of the optional profiling / side-lane modes, freed with it).
+ *     owns only the opaque handle (plus the HIP events of the optional profiling mode, freed with it).
  *     No allocation, no host synchronisation inside pcad_forward.
- *   - all work is enqueued on the caller's stream (and, if given, the caller's side stream: pcad_set_side_stream); a handle is bound to the current device and is not
+ *   - all work is enqueued on the caller's stream; a handle is bound to the current device and is not
  *     thread-safe; distinct handles on distinct devices are independent (one process per GPU).
  *   - status: 0 = OK, negative = error (enum below); message via thread-local pcad_last_error().
  *   - activation layout is token-major: [strand, position, channel] (channel contiguous).
@@ -90,14 +90,6 @@ void   pcad_destroy(pcad_handle h);
  *                 read of anything this forward did not write shows up as NaN outputs (tests/test_gpu_model.py).
  * The library reads NO environment variables unless PCAD_DEV=1 is set (developer A/B switches, see csrc/kernels.hpp). */
 int    pcad_set_option(pcad_handle h, const char* key, int64_t value);
-
-/* Optional side lane: when a second caller-owned stream is given and a batch has >= 2 chunks, pcad_forward walks two chunks
- * at a time and enqueues every residual-add + RMSNorm kernel on `side` (forked from and joined back to its `stream`
- * argument with events, on every exit path), so that one chunk's norm - a pure HBM stream whose small blocks co-reside with
- * the GEMM and conv kernels - runs beside the other chunk's CU-filling kernels instead of between them.  The events are the
- * only objects besides the handle that the library creates; they live until pcad_destroy.  pcad_workspace_bytes doubles
- * accordingly.  Results are bit-identical to the single-stream run.  NULL turns it off (default). */
-int    pcad_set_side_stream(pcad_handle h, pcad_stream side);
 
 /* Bytes of caller-owned device memory that pcad_bind_weights packs the model into. */
 size_t pcad_weight_arena_bytes(pcad_handle h);

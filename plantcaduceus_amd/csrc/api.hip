@@ -64,15 +64,12 @@ struct pcad_engine {
     int rdt;        // residual dtype
     int chunk;      // PCAD_CHUNK_SEQS override: sequences per pass through the layer stack (0: derive from chunk_rows)
     int64_t chunk_rows;   // token-rows (2 strands x L per window) per pass through the layer stack
-    int nstreams;   // 1: everything on the caller's stream; 2: the add+norm kernels run on the caller-provided side stream
     bool gate_once; // SiLU(z) applied once to y_fwd + y_rev (reverse scan) instead of once per direction
     bool convx;     // conv + x_proj of both directions in one kernel (needs xzsplit and Rp == 64); PCAD_NO_CONVX=1: off
     bool xzsplit;   // in_proj writes x and z as two blocked tensors (needs `blocked`); PCAD_PLAIN_XZ=1 turns it off (A/B knob)
     bool blocked;   // xc and y in the blocked layout (common.hpp::blocked_off); PCAD_PLAIN_LAYOUT=1 turns it off (A/B knob)
     bool poison = false;   // pcad_set_option("poison_workspace", 1): debug — fill the workspace with 0xFF (NaN patterns) before every forward
     bool bound = false;
-    hipStream_t side = nullptr;                 // caller-owned (pcad_set_side_stream)
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_n[2] = {nullptr, nullptr}, ev_o[2] = {nullptr, nullptr};
     std::vector<LayerWeights> layers;
     void* emb = nullptr;        // [V, D] dtype
     float* emb_f32 = nullptr;   // [V, D] fp32 copy of the dtype-rounded table
@@ -239,7 +236,6 @@ int pcad_create(const pcad_config* cfg, pcad_handle* out) {
     e->xzsplit = e->blocked && dev_env("PCAD_PLAIN_XZ") == nullptr && e->E % 16 == 0;
     e->convx = e->xzsplit && e->Rp == 64 && dev_env("PCAD_NO_CONVX") == nullptr;
     e->gate_once = true;                  // pcad_set_option("gate_each", 1) restores the per-direction gate
-    e->nstreams = 1;                      // pcad_set_side_stream() turns the norm side lane on
     *out = e;
     return PCAD_OK;
 }
@@ -249,8 +245,6 @@ void pcad_destroy(pcad_handle h) {
     for (int c = 0; c < PCAD_NUM_KERNEL_CLASSES; ++c)
         for (auto& pr : h->prof_ev[c]) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     for (auto ev : h->prof_pool) (void)hipEventDestroy(ev);
-    for (hipEvent_t ev : {h->ev_fork, h->ev_join, h->ev_n[0], h->ev_n[1], h->ev_o[0], h->ev_o[1]})   // the side stream is the caller's
-        if (ev) (void)hipEventDestroy(ev);
     delete h;
 }
 
@@ -266,17 +260,6 @@ int pcad_set_option(pcad_handle h, const char* key, int64_t value) {
         h->poison = value != 0;
     } else {
         return fail(PCAD_ERR_INVALID, "pcad_set_option: unknown option '%s'", key);
-    }
-    return PCAD_OK;
-}
-
-int pcad_set_side_stream(pcad_handle h, pcad_stream side) {
-    if (!h) return fail(PCAD_ERR_INVALID, "pcad_set_side_stream: null handle");
-    h->side = (hipStream_t)side;
-    h->nstreams = side ? 2 : 1;
-    if (side && !h->ev_fork) {
-        for (hipEvent_t* ev : {&h->ev_fork, &h->ev_join, &h->ev_n[0], &h->ev_n[1], &h->ev_o[0], &h->ev_o[1]})
-            HIP_TRY(hipEventCreateWithFlags(ev, hipEventDisableTiming));
     }
     return PCAD_OK;
 }
@@ -385,8 +368,8 @@ size_t pcad_workspace_bytes(pcad_handle h, int batch, int seqlen) {
     if (!h || batch <= 0 || seqlen <= 0) return 0;
     const int Bc = chunk_for(h, batch, seqlen);
     const int nchunks = (batch + Bc - 1) / Bc;
-    const int lanes = (h->nstreams == 2 && nchunks >= 2) ? 2 : 1;     // one workspace slab per concurrent chunk
-    return carve_workspace(h, nullptr, Bc, seqlen).bytes * lanes;
+    (void)nchunks;                                                   // chunks run one after the other in ONE workspace slab
+    return carve_workspace(h, nullptr, Bc, seqlen).bytes;
 }
 
 static int forward_impl(pcad_handle h, const int32_t* ids, int B, int L, const int32_t* positions, int P,
@@ -419,37 +402,18 @@ static int forward_impl(pcad_handle h, const int32_t* ids, int B, int L, const i
     const int Q = pos_per_seq ? 1 : (P ? P : L);
     const int chunk = chunk_for(e, B, L);
     const int nchunks = (B + chunk - 1) / chunk;
-    const int lanes = (e->nstreams == 2 && nchunks >= 2) ? 2 : 1;
-    const size_t slab = carve_workspace(e, nullptr, chunk, L).bytes;
 
-    // One chunk = up to `chunk` windows (2x strands) walking the whole layer stack.  With a side stream (pcad_set_side_stream)
-    // and >= 2 chunks, chunks are walked two at a time, layer by layer, and every add+norm kernel goes to the side stream:
-    // norm(chunk c, layer l+1) depends only on out_proj(c, l), so it runs while the OTHER chunk's CU-filling kernels (in_proj,
-    // conv+x_proj, scans, out_proj) occupy the main stream.  The norm kernel is 4 waves x 40 registers and no LDS per block, so
-    // its blocks co-reside with the 4-wave GEMM (440 of 512 registers per SIMD) and with conv+x_proj; it streams HBM while those
-    // are MFMA / latency bound.
-    struct Lane { Workspace w; int b0, Bc; bool active; };
-    Lane ln[2];
+    // One chunk = up to `chunk` windows (2x strands) walking the whole layer stack, chunks one after the other, everything on
+    // the caller's stream.  (Multi-stream schedules were built and measured twice and removed: chunks alternating between two
+    // streams gain nothing because the big kernels each fill the CUs, +1 %; the add+norm kernels on a side stream beside the other
+    // chunk's GEMM are zero-sum, in_proj stretches by the norm's duration, -4 %: DESIGN.md §8.)
+    struct Lane { Workspace w; int b0, Bc; };
     // debug aid (race / uninitialised-read screen): every byte of the workspace starts as 0xFF, so a kernel that consumes a
     // value no kernel of THIS forward produced turns the outputs into NaN instead of silently reusing the previous call's data
     if (e->poison) HIP_TRY(hipMemsetAsync(workspace, 0xFF, need, cs));
 
-    struct Join {      // runs on EVERY exit path: the caller's stream never runs ahead of work left on the side stream
-        pcad_engine* e; hipStream_t cs; bool on;
-        ~Join() {
-            if (on && hipEventRecord(e->ev_join, e->side) == hipSuccess) (void)hipStreamWaitEvent(cs, e->ev_join, 0);
-        }
-    } join{e, cs, false};
-    hipStream_t ns = cs;                                  // stream of the norm kernels
-    if (lanes == 2) {
-        HIP_TRY(hipEventRecord(e->ev_fork, cs));
-        HIP_TRY(hipStreamWaitEvent(e->side, e->ev_fork, 0));
-        join.on = true;
-        ns = e->side;
-    }
-
-    auto phase_N = [&](Lane& c, int li) -> int {        // residual add + norm (layer 0: RCPS embedding + norm), on `ns`
-        hipStream_t s = ns;
+    auto phase_N = [&](Lane& c, int li) -> int {        // residual add + norm (layer 0: RCPS embedding + norm)
+        hipStream_t s = cs;
         const LayerWeights& W = e->layers[li];
         const int S = 2 * c.Bc;
         const int64_t rows = (int64_t)S * L;
@@ -467,7 +431,7 @@ static int forward_impl(pcad_handle h, const int32_t* ids, int B, int L, const i
         }
         return PCAD_OK;
     };
-    auto phase_P = [&](Lane& c, int li) -> int {        // in_proj, conv + x_proj (both directions), on the main stream
+    auto phase_P = [&](Lane& c, int li) -> int {        // in_proj, conv + x_proj (both directions)
         hipStream_t s = cs;
         const LayerWeights& W = e->layers[li];
         const int S = 2 * c.Bc;
@@ -531,47 +495,19 @@ static int forward_impl(pcad_handle h, const int32_t* ids, int B, int L, const i
         return PCAD_OK;
     };
 
-    for (int g0 = 0; g0 < nchunks; g0 += lanes) {
-        for (int i = 0; i < lanes; ++i) {
-            const int ck = g0 + i;
-            ln[i].active = ck < nchunks;
-            if (!ln[i].active) continue;
-            ln[i].b0 = ck * chunk;
-            ln[i].Bc = (B - ln[i].b0) < chunk ? (B - ln[i].b0) : chunk;
-            ln[i].w = carve_workspace(e, (char*)workspace + (size_t)i * slab, ln[i].Bc, L);
-        }
-        if (lanes == 2) {
-            // a new group re-uses the two workspace slabs: its first norms must not start before the previous group's heads
-            if (g0 > 0) {
-                HIP_TRY(hipEventRecord(e->ev_fork, cs));
-                HIP_TRY(hipStreamWaitEvent(ns, e->ev_fork, 0));
-            }
-            for (int i = 0; i < 2; ++i) {
-                if (!ln[i].active) continue;
-                if (int rc = phase_N(ln[i], 0)) return rc;
-                HIP_TRY(hipEventRecord(e->ev_n[i], ns));
-            }
-        }
+    for (int ck = 0; ck < nchunks; ++ck) {
+        Lane c;
+        c.b0 = ck * chunk;
+        c.Bc = (B - c.b0) < chunk ? (B - c.b0) : chunk;
+        c.w = carve_workspace(e, workspace, c.Bc, L);
         for (int li = 0; li < e->nl; ++li) {
-            for (int i = 0; i < lanes; ++i) {
-                if (!ln[i].active) continue;
-                if (lanes == 2) HIP_TRY(hipStreamWaitEvent(cs, e->ev_n[i], 0));      // u / res of (chunk i, layer li) are ready
-                else if (int rc = phase_N(ln[i], li)) return rc;
-                if (int rc = phase_P(ln[i], li)) return rc;
-                if (int rc = phase_V(ln[i], li)) return rc;
-                if (lanes == 2 && li + 1 < e->nl) {
-                    HIP_TRY(hipEventRecord(e->ev_o[i], cs));
-                    HIP_TRY(hipStreamWaitEvent(ns, e->ev_o[i], 0));
-                    if (int rc = phase_N(ln[i], li + 1)) return rc;                   // beside the other chunk's kernels on cs
-                    HIP_TRY(hipEventRecord(e->ev_n[i], ns));
-                }
-            }
+            if (int rc = phase_N(c, li)) return rc;
+            if (int rc = phase_P(c, li)) return rc;
+            if (int rc = phase_V(c, li)) return rc;
         }
-        for (int i = 0; i < lanes; ++i)
-            if (ln[i].active)
-                if (int rc = phase_head(ln[i])) return rc;
+        if (int rc = phase_head(c)) return rc;
     }
-    return PCAD_OK;      // `join` re-joins the side stream here (and on every early return above)
+    return PCAD_OK;
 }
 
 int pcad_forward(pcad_handle h, const int32_t* ids, int B, int L, const int32_t* positions, int P, void* hidden_out,

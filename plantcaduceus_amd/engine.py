@@ -44,7 +44,6 @@ SIGNATURES = {
     "pcad_create": (C.c_int, [C.POINTER(PcadConfig), C.POINTER(C.c_void_p)]),
     "pcad_destroy": (None, [C.c_void_p]),
     "pcad_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int64]),
-    "pcad_set_side_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
     "pcad_weight_arena_bytes": (C.c_size_t, [C.c_void_p]),
     "pcad_bind_weights": (C.c_int, [C.c_void_p, C.POINTER(PcadTensor), C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
     "pcad_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int, C.c_int]),
@@ -140,13 +139,8 @@ class Engine:
         self._h = C.c_void_p()
         _check(self.lib.pcad_create(C.byref(cfg), C.byref(self._h)), "pcad_create")
         self._ws: Optional[torch.Tensor] = None
-        self._aux = None
         for key, val in (getattr(config, "engine_options", None) or {}).items():
-            if key == "two_lanes":
-                if val:
-                    self.set_two_lanes(True)
-            else:
-                self.set_option(key, int(val))
+            self.set_option(key, int(val))
         with torch.cuda.device(self.device):
             nbytes = self.lib.pcad_weight_arena_bytes(self._h)
             self._arena = torch.empty(nbytes + 256, dtype=torch.uint8, device=self.device)
@@ -238,18 +232,6 @@ class Engine:
     def set_option(self, key: str, value: int):
         """`pcad_set_option`: "chunk_seqs" (windows per pass through the stack), "gate_each" (reference-order SiLU gate)."""
         _check(self.lib.pcad_set_option(self._h, key.encode(), int(value)), "pcad_set_option")
-        self._ws = None
-
-    def set_two_lanes(self, on: bool):
-        """Norm side lane on a torch-owned second stream (`pcad_set_side_stream`): with >= 2 chunks per forward the add+norm
-        kernels of one chunk run beside the other chunk's GEMM / conv / scan kernels."""
-        if on:
-            with torch.cuda.device(self.device):
-                self._aux = torch.cuda.Stream(self.device)
-            _check(self.lib.pcad_set_side_stream(self._h, self._aux.cuda_stream), "pcad_set_side_stream")
-        else:
-            _check(self.lib.pcad_set_side_stream(self._h, None), "pcad_set_side_stream")
-            self._aux = None
         self._ws = None
 
     def profile(self, on):

@@ -12,7 +12,7 @@ DEV = "cuda:0"
 
 def build(cfg, sd, dtype, **engine_options):
     from plantcaduceus_amd.modeling_caduceus import CaduceusForMaskedLM
-    cfg.engine_options = dict(engine_options)        # pcad_set_option / pcad_set_aux_streams at engine creation
+    cfg.engine_options = dict(engine_options)        # pcad_set_option at engine creation
     m = CaduceusForMaskedLM(cfg)
     m.load_state_dict(sd, strict=False)
     m.tie_weights()
@@ -104,8 +104,6 @@ def test_batch_chunking_and_empty_and_all_hidden():
     ids = rand_ids(7, 32, 21)
     m = build(cfg, sd, torch.float32, chunk_seqs=3)                  # 7 sequences -> chunks 3,3,1
     lg = m(input_ids=ids.to(DEV)).logits.cpu()
-    m1 = build(cfg, sd, torch.float32, chunk_seqs=3, two_lanes=True)  # same chunks alternating between two caller-owned aux streams
-    assert torch.equal(lg, m1(input_ids=ids.to(DEV)).logits.cpu())
     m2 = build(cfg, sd, torch.float32, chunk_seqs=64)
     assert torch.equal(lg, m2(input_ids=ids.to(DEV)).logits.cpu())
     # the reference-order gate (each direction gated and rounded) is the same function in fp32 up to rounding
@@ -138,12 +136,12 @@ def test_no_cpu_fallback():
                                           (torch.float32, 64, 1, 2)])
 def test_poisoned_workspace_gives_identical_results(dtype, D, L, B):
     """uninitialised-read screen: with every workspace byte pre-set to 0xFF (NaN) before each forward the outputs must be
-    bit-identical to the normal run, at ragged lengths (partial row blocks / tiles in every kernel) and in the two-lane mode."""
+    bit-identical to the normal run, at ragged lengths (partial row blocks / tiles in every kernel) and with several chunks."""
     cfg = make_config("x", d_model=D, n_layer=2)
     sd = synthetic_state_dict(cfg, seed=11)
     ids = rand_ids(B, L, 3, mask=L // 2).to(DEV)
     ref = build(cfg, sd, dtype)(input_ids=ids, output_hidden_states=True)
-    for opts in (dict(poison_workspace=1), dict(poison_workspace=1, chunk_seqs=2, two_lanes=True)):
+    for opts in (dict(poison_workspace=1), dict(poison_workspace=1, chunk_seqs=2)):
         out = build(cfg, sd, dtype, **opts)(input_ids=ids, output_hidden_states=True)
         assert torch.isfinite(out.logits).all()
         assert torch.equal(out.logits, ref.logits) and torch.equal(out.hidden_states[-1], ref.hidden_states[-1])
