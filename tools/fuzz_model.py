@@ -1,0 +1,44 @@
+"""developer tool (run on the GPU box): randomized model-level parity — random geometry (d_model, layers, dt_rank, batch,
+ragged sequence lengths, positions), fp32 against the torch oracle (1e-4 of max, exact argmax where the margin exceeds noise)
+and bf16 against the bf16-emulating oracle (3e-2 of the logit range).      python tools/fuzz_model.py [cases] [seed]"""
+import os, sys, time
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import caduceus_oracle as O
+from plantcaduceus_amd.checkpoint import make_config, synthetic_state_dict
+from plantcaduceus_amd.modeling_caduceus import CaduceusForMaskedLM
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+bad = 0
+t0 = time.time()
+for case in range(n):
+    D = int(rng.choice([64, 128, 192, 256, 384, 512]))
+    nl = int(rng.integers(1, 4))
+    B = int(rng.integers(1, 6))
+    L = int(rng.choice([1, 2, 3, 5, 7, 8, 9, 15, 16, 17, 31, 33, 63, 64, 65, 100, 127, 128, 129, 200, 255, 257, 300]))
+    bf16 = bool(rng.integers(0, 2))
+    ssm = dict(d_state=16, d_conv=4, expand=2, dt_rank=int(rng.choice([D // 16, max(1, D // 16 - 1), min(64, D // 16 + 3)])), bias=False, conv_bias=True)
+    cfg = make_config("x", d_model=D, n_layer=nl, ssm_cfg=ssm)
+    sd = synthetic_state_dict(cfg, seed=int(rng.integers(0, 1 << 30)), stress=True)
+    ids = torch.from_numpy(rng.integers(0, 8, size=(B, L)))          # every token id incl. PAD / MASK / UNK / the pad row
+    dt = torch.bfloat16 if bf16 else torch.float32
+    m = CaduceusForMaskedLM(cfg); m.load_state_dict(sd, strict=False); m.tie_weights(); m = m.to(dt).to("cuda:0")
+    out = m(input_ids=ids.to("cuda:0"), output_hidden_states=True)
+    lg, hid = out.logits.cpu(), out.hidden_states[-1].float().cpu()
+    P = O.params_from_state_dict(sd, cfg, dtype=dt)
+    ref = O.forward_strands(ids, P, rnd=O.round_bf16 if bf16 else O._ident, tie_fold=bf16)
+    scale = ref["logits"].abs().max().clamp_min(1e-20)
+    e_l = ((lg - ref["logits"]).abs().max() / scale).item()
+    e_h = ((hid - ref["hidden"]).abs().max() / ref["hidden"].abs().max().clamp_min(1e-20)).item()
+    tol = 3e-2 if bf16 else 1e-4
+    ok = e_l < tol and e_h < tol and bool(torch.isfinite(lg).all())
+    pos = sorted(set(int(p) for p in rng.integers(0, L, size=min(L, 3))))
+    outp = m(input_ids=ids.to("cuda:0"), output_hidden_states=True, positions=pos)
+    ok = ok and torch.equal(outp.logits.cpu(), lg[:, pos]) and torch.equal(outp.hidden_states[-1].float().cpu(), hid[:, pos])
+    if not ok:
+        bad += 1
+    print(f"case {case:3d} D={D:3d} nl={nl} R={cfg.dt_rank:2d} B={B} L={L:3d} {'bf16' if bf16 else 'fp32'}  logits {e_l:.2e} hidden {e_h:.2e}  {'ok' if ok else 'FAIL'}")
+    del m
+print(f"{n} random cases, {bad} failed, {time.time() - t0:.0f} s")
+sys.exit(1 if bad else 0)
