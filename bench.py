@@ -56,6 +56,7 @@ def parse():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--cpu-seqs", type=int, default=-1, help="sample size for the CPU baseline (0 = skip)")
     ap.add_argument("--chunk-seqs", type=int, default=0, help="pcad_set_option chunk_seqs (0 = engine default)")
+    ap.add_argument("--opt", action="append", default=[], metavar="KEY=VALUE", help="extra pcad_set_option, e.g. scan_segments=0")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--profile-stride", type=int, default=7,
                     help="HIP events around every N-th launch of each kernel class during the timed region (ODD: the scan class "
@@ -150,6 +151,9 @@ def main():
     eng = Engine(cfg, sd, tdt, device)
     if args.chunk_seqs:
         eng.set_option("chunk_seqs", args.chunk_seqs)
+    for kv in args.opt:
+        k, v = kv.split("=", 1)
+        eng.set_option(k, int(v))
 
     B, L, p = args.batch, args.seqlen, 255 if args.seqlen > 255 else args.seqlen // 2
     D = cfg.d_model

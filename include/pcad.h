@@ -86,6 +86,10 @@ void   pcad_destroy(pcad_handle h);
  *   "gate_each"   1: SiLU(z) applied to each direction's scan output, each rounded, then summed — the reference's order
  *                 (two selective_scan_fn calls);  0 (default): applied once to the sum of both directions (same value in
  *                 exact arithmetic, one rounding fewer, faster).
+ *   "scan_segments"  1 (default): for long sequences with few strands (PlantCAD2's 8 192-bp windows in small batches: at most 768 scan waves in a
+ *                 launch and L >= 2 048) the scan of every strand is cut into up to 8 segments that run as separate workgroups
+ *                 (zero-state pass, carry, real pass: ~1.8x the arithmetic for up to 8x the parallelism; results equal up to fp32
+ *                 rounding of the carried decay product);  0: one workgroup walks the whole strand.  Never used at 512 bp.
  *   "poison_workspace"  1: debug aid — the workspace is filled with 0xFF bytes (NaN in every dtype) before each forward, so a
  *                 read of anything this forward did not write shows up as NaN outputs (tests/test_gpu_model.py).
  * The library reads NO environment variables unless PCAD_DEV=1 is set (developer A/B switches, see csrc/kernels.hpp). */

@@ -68,6 +68,7 @@ struct pcad_engine {
     bool convx;     // conv + x_proj of both directions in one kernel (needs xzsplit and Rp == 64); PCAD_NO_CONVX=1: off
     bool xzsplit;   // in_proj writes x and z as two blocked tensors (needs `blocked`); PCAD_PLAIN_XZ=1 turns it off (A/B knob)
     bool blocked;   // xc and y in the blocked layout (common.hpp::blocked_off); PCAD_PLAIN_LAYOUT=1 turns it off (A/B knob)
+    bool segments = true;  // pcad_set_option("scan_segments", 0): never cut the scan of long strands into segments
     bool poison = false;   // pcad_set_option("poison_workspace", 1): debug — fill the workspace with 0xFF (NaN patterns) before every forward
     bool bound = false;
     std::vector<LayerWeights> layers;
@@ -127,6 +128,7 @@ void carve_weights(pcad_engine* e, Carver& c) {
 struct Workspace {
     void *res, *u, *h, *xz, *zb, *xc[2], *dtl[2], *y;
     float* bc[2];
+    float* seg;      // segmented-scan scratch (long sequences with few strands), or nullptr
     size_t bytes;
 };
 
@@ -150,6 +152,8 @@ Workspace carve_workspace(const pcad_engine* e, void* base, int Bc, int L) {
     w.bc[0] = (float*)c.take(rows * 2 * e->N * 4);   // B_t | C_t rows, fp32 (values rounded to the model dtype)
     w.bc[1] = (float*)c.take(rows * 2 * e->N * 4);
     w.y = c.take(rows8 * E * esz);
+    const size_t segb = e->segments ? scan_segment_bytes(2 * Bc, L, (int)E) : 0;
+    w.seg = segb ? (float*)c.take(segb) : nullptr;
     w.bytes = c.off;
     return w;
 }
@@ -258,6 +262,8 @@ int pcad_set_option(pcad_handle h, const char* key, int64_t value) {
         h->gate_once = value == 0;
     } else if (k == "poison_workspace") {
         h->poison = value != 0;
+    } else if (k == "scan_segments") {
+        h->segments = value != 0;
     } else {
         return fail(PCAD_ERR_INVALID, "pcad_set_option: unknown option '%s'", key);
     }
@@ -473,7 +479,7 @@ static int forward_impl(pcad_handle h, const int32_t* ids, int B, int L, const i
             const bool gated = !e->gate_once || d == 1;
             HIP_TRY(launch_scan(c.w.xc[d], gated ? zp : nullptr, e->xzsplit ? E : 2 * E, nullptr, c.w.dtl[d], Rp, dw.Wdt, Rp,
                                 c.w.bc[d], dw.A2, 1.0f, dw.Dskip, dw.dt_bias, c.w.y, S, L, E, d == 1,
-                                d == 1 ? (e->gate_once ? 2 : 1) : 0, dt, s, e->blocked, e->xzsplit));
+                                d == 1 ? (e->gate_once ? 2 : 1) : 0, dt, s, e->blocked, e->xzsplit, c.w.seg));
         }
         // out_proj on (y_fwd + y_rev): the two tied out_proj calls folded by linearity
         { ProfScope ps(e, PCAD_K_GEMM_OUT, s);

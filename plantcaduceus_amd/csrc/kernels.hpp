@@ -80,10 +80,36 @@ hipError_t launch_convx(const void* x, const float* convw, const void* Wx0, void
 // (A * log2(e), 1) or (A, log2(e)).
 // uy_blocked: u and y are in the blocked layout (whole-tensor row index s*L + t, buffers padded to 8 rows).
 // z_blocked (needs uy_blocked): z is a separate [S*L, E] tensor in the same blocked layout (ldz ignored).
+// seg_ws (fused dt_proj form only): scratch of scan_segment_bytes(S, L, E) bytes; when given and scan_segments() > 1 the walk of
+// every strand is cut into segments that run as separate workgroups (long sequences with few strands: PlantCAD2's 8 192-bp windows).
 hipError_t launch_scan(const void* u, const void* z, int64_t ldz, const void* delta, const void* dt_low, int64_t lddt,
                        const void* Wdt, int Rp, const float* bc, const float* A2, float a_scale, const float* Dskip,
                        const float* dbias, void* y, int S, int L, int E, bool reverse, int accumulate, int dt,
-                       hipStream_t s, bool uy_blocked = false, bool z_blocked = false);
+                       hipStream_t s, bool uy_blocked = false, bool z_blocked = false, float* seg_ws = nullptr);
+
+// Segments per strand for the scan of S strands of L steps over E channels.  Pass A + pass B cost ~1.8x the arithmetic of one
+// walk, and a single wave per SIMD already keeps the VALU ~65 % busy, so cutting only pays when most SIMDs would otherwise idle
+// (measured: 1 536 waves at L = 8 192 are 15 % FASTER uncut).  Cut when the launch has at most 768 waves (0.75 per SIMD) and the
+// strands are long (L >= 2 048): into enough segments for ~2 300 waves, at most 8, each at least 512 steps (16 blocks of 32).
+inline int scan_segments(int S, int L, int E, int* seg_blocks) {
+    const int64_t waves = (int64_t)S * (E / 64);
+    const int nblk = (L + 31) / 32;
+    int G = 1;
+    if (L >= 2048 && waves > 0 && waves <= 768) {
+        G = (int)((2304 + waves - 1) / waves);
+        if (G > 8) G = 8;
+        if (G > nblk / 16) G = nblk / 16;
+        if (G < 3) G = 1;                              // below ~3x the waves the second pass is not paid for
+    }
+    const int sb = (nblk + G - 1) / G;
+    G = (nblk + sb - 1) / sb;                          // no empty segment
+    if (seg_blocks) *seg_blocks = sb;
+    return G;
+}
+inline size_t scan_segment_bytes(int S, int L, int E) {
+    const int G = scan_segments(S, L, E, nullptr);
+    return G > 1 ? (size_t)S * G * E * 17 * sizeof(float) : 0;        // [S][G][E][16] states + [S][G][E] delta sums
+}
 
 // pack.hip --------------------------------------------------------------------------------------
 // generic 2-D copy/convert with zero padding: dst[r, c] (dst_dt, ld = dst_ld) = src[r, c] for r < rows, c < cols else 0

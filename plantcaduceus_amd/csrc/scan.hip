@@ -146,19 +146,27 @@ template <> struct DeltaTile<float> {
 // PRE (bf16, FUSED, Rp == 64): dt_low operand prefetched one block ahead.
 // BLK8: u / y in the blocked layout AND L % 8 == 0 (the engine's case): one scalar block offset per 4-step chunk, the
 // per-step +-128 bytes ride in the buffer instruction's immediate offset.
-template <typename T, bool REV, int ACC, bool HASZ, bool FUSED, bool PRE, bool BLK8>
+// SEG (long sequences with few strands, launch_scan below): the walk of a strand is cut into G segments of `seg_blocks` blocks that
+// run as separate workgroups.  SEG = 1, pass A: from a ZERO state, no output - stores the segment's end state and its sum of delta
+// (the product of its decays is exp2(A2 * sum delta));  SEG = 2, pass B: the normal walk of the segment from the true initial state
+// that scan_carry_kernel derived from pass A.  SEG = 0: the whole strand in one workgroup (G = 1).
+template <typename T, bool REV, int ACC, bool HASZ, bool FUSED, bool PRE, bool BLK8, int SEG = 0>
 __global__ __launch_bounds__(64, 4) void scan_kernel(const T* __restrict__ u, const T* __restrict__ z, int64_t ldz,
                                                   const T* __restrict__ dsrc, int64_t ldd,
                                                   const T* __restrict__ Wdt, int Rp,
                                                   const float* __restrict__ bc,
                                                   const float* __restrict__ A2, float a_scale,
                                                   const float* __restrict__ Dskip, const float* __restrict__ dbias,
-                                                  const T* yin, T* y, int L, int E, int uyb, int zblk) {
+                                                  const T* yin, T* y, int L, int E, int uyb, int zblk, int G, int seg_blocks,
+                                                  float* __restrict__ seg_state) {
     __shared__ float dvs[TB][64];
     const int lane = threadIdx.x;
     const int c0 = blockIdx.x * 64;
     const int c = c0 + lane;
-    const int64_t row0 = (int64_t)blockIdx.y * L;
+    const int strand = SEG ? (int)blockIdx.y / G : (int)blockIdx.y;
+    const int seg = SEG ? (int)blockIdx.y - strand * G : 0;
+    const int nstrands = SEG ? (int)gridDim.y / G : (int)gridDim.y;
+    const int64_t row0 = (int64_t)strand * L;
 
     f2 a2p[NSTATE / 2], hp[NSTATE / 2];
 #pragma unroll
@@ -167,8 +175,21 @@ __global__ __launch_bounds__(64, 4) void scan_kernel(const T* __restrict__ u, co
         a2p[p] = f2{v[0] * a_scale, v[1] * a_scale};
         a2p[p + 1] = f2{v[2] * a_scale, v[3] * a_scale};
     }
+    // seg_state: [strand][segment][E][16] states, then [strand][segment][E] delta sums (pass A output); pass B reads its initial
+    // state from the same [strand][segment][E][16] block (rewritten in place by scan_carry_kernel)
+    float* __restrict__ seg_h = seg_state + (((int64_t)strand * G + seg) * E + c) * NSTATE;
+    if constexpr (SEG == 2) {
 #pragma unroll
-    for (int p = 0; p < NSTATE / 2; ++p) hp[p] = f2{0.f, 0.f};
+        for (int p = 0; p < NSTATE / 2; p += 2) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(seg_h + 2 * p);
+            hp[p] = f2{v[0], v[1]};
+            hp[p + 1] = f2{v[2], v[3]};
+        }
+    } else {
+#pragma unroll
+        for (int p = 0; p < NSTATE / 2; ++p) hp[p] = f2{0.f, 0.f};
+    }
+    float dsum = 0.f;
     const float dsk = Dskip[c];
     const float db = dbias[c];
 
@@ -185,7 +206,7 @@ __global__ __launch_bounds__(64, 4) void scan_kernel(const T* __restrict__ u, co
     // (descriptor based at the tensor, offset = blocked_off of the whole-tensor row; the wave's 64 channels are one or two
     // 128-byte pieces, so the per-lane part is a constant)
     const uint32_t pieces = rowE >> 7;
-    const uint32_t tot_rows = ((uint32_t)gridDim.y * (uint32_t)L + 7u) & ~7u;
+    const uint32_t tot_rows = ((uint32_t)nstrands * (uint32_t)L + 7u) & ~7u;
     const bool blk = BLK8 || uyb;       // BLK8 instantiations: known at compile time
     const auto u_r = blk ? make_rsrc(u, tot_rows * rowE) : make_rsrc(u + row0 * E + c0, (uint32_t)L * rowE);
     const auto y_r = blk ? make_rsrc(y, tot_rows * rowE) : make_rsrc(y + row0 * E + c0, (uint32_t)L * rowE);   // also the ACC input
@@ -229,7 +250,9 @@ __global__ __launch_bounds__(64, 4) void scan_kernel(const T* __restrict__ u, co
             if constexpr (!FUSED) dd[i] = BufIO<T>::load(d_r, voff, t * rowD);
         }
     };
-    load_chunk(0, ub, zb, yb, dr);
+    const int b_begin = SEG ? seg * seg_blocks : 0;                        // first block (walk space) of this workgroup
+    const int s_first = b_begin * TB;
+    load_chunk(s_first, ub, zb, yb, dr);
 
     // B_t | C_t of the step being computed (SGPRs), software-pipelined one step ahead of the VALU work
     f2 bcc[NSTATE];
@@ -238,7 +261,7 @@ __global__ __launch_bounds__(64, 4) void scan_kernel(const T* __restrict__ u, co
 #pragma unroll
         for (int p = 0; p < NSTATE; ++p) dst[p] = r[p];
     };
-    load_bc(0, bcc);
+    load_bc(s_first, bcc);
 
     // one recurrence step on raw inputs (uraw, zraw, yraw, draw) at walk step s
     float dv_cur = 0.f;    // FUSED: delta of the step about to run, read from LDS one step ahead
@@ -258,30 +281,36 @@ __global__ __launch_bounds__(64, 4) void scan_kernel(const T* __restrict__ u, co
         const float du = dv * uv;
         const f2 dv2 = {dv, dv}, du2 = {du, du};
         f2 yacc0 = {dsk * uv, 0.f}, yacc1 = {0.f, 0.f};      // two independent accumulation chains
+        if constexpr (SEG == 1) dsum += dv;
 #pragma unroll
         for (int p = 0; p < NSTATE / 2; p += 2) {
             const f2 e0 = dv2 * a2p[p], e1 = dv2 * a2p[p + 1];
             const f2 a0 = {exp2_hw(e0[0]), exp2_hw(e0[1])}, a1 = {exp2_hw(e1[0]), exp2_hw(e1[1])};
             hp[p] = a0 * hp[p] + du2 * bcc[p];
             hp[p + 1] = a1 * hp[p + 1] + du2 * bcc[p + 1];
-            yacc0 = hp[p] * bcc[NSTATE / 2 + p] + yacc0;
-            yacc1 = hp[p + 1] * bcc[NSTATE / 2 + p + 1] + yacc1;
+            if constexpr (SEG != 1) {
+                yacc0 = hp[p] * bcc[NSTATE / 2 + p] + yacc0;
+                yacc1 = hp[p + 1] * bcc[NSTATE / 2 + p + 1] + yacc1;
+            }
         }
-        const f2 yacc = yacc0 + yacc1;
-        float yv = yacc[0] + yacc[1];
-        if constexpr (ACC == 2) yv += Elem<T>::to_f32(yraw);                        // sum of both directions, gated once
-        if constexpr (HASZ) yv *= silu(Elem<T>::to_f32(zraw));
-        if constexpr (ACC == 1) yv = Elem<T>::round(yv) + Elem<T>::to_f32(yraw);    // each direction is rounded, then summed
-        BufIO<T>::store(Elem<T>::from_f32(yv), y_r, vy, oy);
+        if constexpr (SEG != 1) {
+            const f2 yacc = yacc0 + yacc1;
+            float yv = yacc[0] + yacc[1];
+            if constexpr (ACC == 2) yv += Elem<T>::to_f32(yraw);                        // sum of both directions, gated once
+            if constexpr (HASZ) yv *= silu(Elem<T>::to_f32(zraw));
+            if constexpr (ACC == 1) yv = Elem<T>::round(yv) + Elem<T>::to_f32(yraw);    // each direction is rounded, then summed
+            BufIO<T>::store(Elem<T>::from_f32(yv), y_r, vy, oy);
+        }
 #pragma unroll
         for (int p = 0; p < NSTATE; ++p) bcc[p] = bcn[p];
         dv_cur = dv_next;
     };
 
     DeltaPre pre;
-    if constexpr (PRE) pre = delta_prefetch((const bf16_t*)dsrc, ldd, row0, REV ? (L - TB) : 0, L, lane);
+    if constexpr (PRE) pre = delta_prefetch((const bf16_t*)dsrc, ldd, row0, REV ? (L - (b_begin + 1) * TB) : b_begin * TB, L, lane);
 
-    for (int b = 0; b < nblk; ++b) {
+    const int b_end = SEG ? min(nblk, b_begin + seg_blocks) : nblk;
+    for (int b = b_begin; b < b_end; ++b) {
         const int tb0 = REV ? (L - (b + 1) * TB) : b * TB;
         if constexpr (FUSED) {
             f32x16 acc0, acc1;
@@ -323,18 +352,67 @@ __global__ __launch_bounds__(64, 4) void scan_kernel(const T* __restrict__ u, co
                 if (s0 + i < s_end) step(s0 + i, tb0, uy_soff(s0, i), uy_voff(i), ub[i], zb[i], yb[i], dr[i]);
         }
     }
+    if constexpr (SEG == 1) {
+#pragma unroll
+        for (int p = 0; p < NSTATE / 2; p += 2)
+            *reinterpret_cast<f32x4*>(seg_h + 2 * p) = f32x4{hp[p][0], hp[p][1], hp[p + 1][0], hp[p + 1][1]};
+        seg_state[(int64_t)nstrands * G * E * NSTATE + ((int64_t)strand * G + seg) * E + c] = dsum;
+    }
+}
+
+// Carry between the segments of a strand, in walk order: the state a segment starts from is
+//   h0[g] = exp2(A2 * a_scale * dsum[g-1]) (.) h0[g-1] + h_end[g-1],   h0[0] = 0
+// (the product of a segment's per-step decays exp2(delta_t * A2) is exp2(A2 * sum_t delta_t)).  In place: h_end[g] -> h0[g].
+__global__ __launch_bounds__(256) void scan_carry_kernel(float* __restrict__ seg_state, const float* __restrict__ A2, float a_scale,
+                                                         int S, int G, int E) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;       // (strand, channel)
+    if (i >= (int64_t)S * E) return;
+    const int strand = (int)(i / E), c = (int)(i - (int64_t)strand * E);
+    const float* dsum = seg_state + (int64_t)S * G * E * NSTATE;
+    float a[NSTATE], h[NSTATE];
+#pragma unroll
+    for (int n = 0; n < NSTATE; ++n) { a[n] = A2[(int64_t)c * NSTATE + n] * a_scale; h[n] = 0.f; }
+    for (int g = 0; g < G; ++g) {
+        float* hs = seg_state + (((int64_t)strand * G + g) * E + c) * NSTATE;
+        const float ds = dsum[((int64_t)strand * G + g) * E + c];
+#pragma unroll
+        for (int n = 0; n < NSTATE; ++n) {
+            const float hend = hs[n];
+            hs[n] = h[n];                                             // initial state of segment g
+            h[n] = exp2_hw(a[n] * ds) * h[n] + hend;
+        }
+    }
 }
 
 template <typename T, bool FUSED, bool PRE = false, bool BLK8 = false>
 static hipError_t launch_scan_t(const void* u, const void* z, int64_t ldz, const void* dsrc, int64_t ldd,
                                 const void* Wdt, int Rp, const float* bc, const float* A2, float a_scale,
                                 const float* Dskip, const float* dbias, void* y, int S, int L, int E, bool reverse,
-                                int accumulate, hipStream_t s, bool uyb, bool zblk = false) {
+                                int accumulate, hipStream_t s, bool uyb, bool zblk = false, float* seg_ws = nullptr) {
     dim3 grid((unsigned)(E / 64), (unsigned)S), block(64);
-#define PCAD_SCAN(REV, ACC, HZ)                                                                                    \
-    hipLaunchKernelGGL((scan_kernel<T, REV, ACC, HZ, FUSED, PRE, BLK8>), grid, block, 0, s, (const T*)u, (const T*)z, ldz,       \
-                       (const T*)dsrc, ldd, (const T*)Wdt, Rp, bc, A2, a_scale, Dskip, dbias, (const T*)y, (T*)y, L, E, (int)uyb, (int)zblk)
     const bool hz = z != nullptr;
+#define PCAD_SCAN_ARGS(ZP) (const T*)u, (const T*)(ZP), ldz, (const T*)dsrc, ldd, (const T*)Wdt, Rp, bc, A2, a_scale, Dskip, dbias, \
+                           (const T*)y, (T*)y, L, E, (int)uyb, (int)zblk
+    // ---- long strands, few of them: G segments per strand as separate workgroups (pass A, carry, pass B) --------------------
+    if constexpr (FUSED) {
+        int sb = 0;
+        const int G = seg_ws ? scan_segments(S, L, E, &sb) : 1;
+        const bool combo = (!reverse && accumulate == 0) || (reverse && accumulate == 2 && hz) || (reverse && accumulate == 1 && hz);
+        if (G > 1 && combo) {
+            dim3 gseg((unsigned)(E / 64), (unsigned)(S * G));
+#define PCAD_SEG(REV, ACC, HZ, SEGM, ZP)                                                                                  \
+            hipLaunchKernelGGL((scan_kernel<T, REV, ACC, HZ, FUSED, PRE, BLK8, SEGM>), gseg, block, 0, s, PCAD_SCAN_ARGS(ZP), G, sb, seg_ws)
+            if (reverse) PCAD_SEG(true, 0, false, 1, nullptr); else PCAD_SEG(false, 0, false, 1, nullptr);
+            hipLaunchKernelGGL(scan_carry_kernel, dim3((unsigned)(((int64_t)S * E + 255) / 256)), dim3(256), 0, s, seg_ws, A2, a_scale, S, G, E);
+            if (!reverse) { if (hz) PCAD_SEG(false, 0, true, 2, z); else PCAD_SEG(false, 0, false, 2, nullptr); }
+            else if (accumulate == 2) PCAD_SEG(true, 2, true, 2, z);
+            else PCAD_SEG(true, 1, true, 2, z);
+#undef PCAD_SEG
+            return hipGetLastError();
+        }
+    }
+#define PCAD_SCAN(REV, ACC, HZ)                                                                                    \
+    hipLaunchKernelGGL((scan_kernel<T, REV, ACC, HZ, FUSED, PRE, BLK8>), grid, block, 0, s, PCAD_SCAN_ARGS(z), 1, 0, (float*)nullptr)
     if (accumulate == 2) {                    // (y_prev + y) * silu(z): the bi-directional sum gated once
         if (!hz) return hipErrorInvalidValue;
         if (reverse) PCAD_SCAN(true, 2, true); else PCAD_SCAN(false, 2, true);
@@ -344,13 +422,14 @@ static hipError_t launch_scan_t(const void* u, const void* z, int64_t ldz, const
     else if (reverse && !accumulate) { if (hz) PCAD_SCAN(true, 0, true); else PCAD_SCAN(true, 0, false); }
     else { if (hz) PCAD_SCAN(true, 1, true); else PCAD_SCAN(true, 1, false); }
 #undef PCAD_SCAN
+#undef PCAD_SCAN_ARGS
     return hipGetLastError();
 }
 
 hipError_t launch_scan(const void* u, const void* z, int64_t ldz, const void* delta, const void* dt_low, int64_t lddt,
                        const void* Wdt, int Rp, const float* bc, const float* A2, float a_scale, const float* Dskip,
                        const float* dbias, void* y, int S, int L, int E, bool reverse, int accumulate, int dt,
-                       hipStream_t s, bool uyb, bool zblk) {
+                       hipStream_t s, bool uyb, bool zblk, float* seg_ws) {
     if (zblk && !uyb) return hipErrorInvalidValue;
     if (S <= 0 || L <= 0) return hipSuccess;
     if (E % 64) return hipErrorInvalidValue;
@@ -361,14 +440,14 @@ hipError_t launch_scan(const void* u, const void* z, int64_t ldz, const void* de
     if (fused && (!dt_low || !Wdt || Rp <= 0 || Rp % 64)) return hipErrorInvalidValue;
     if (dt == BF16) {
         if (fused && Rp == 64 && lddt % 8 == 0 && uyb && L % 8 == 0)
-            return launch_scan_t<bf16_t, true, true, true>(u, z, ldz, dt_low, lddt, Wdt, Rp, bc, A2, a_scale, Dskip, dbias, y, S, L, E, reverse, accumulate, s, uyb, zblk);
+            return launch_scan_t<bf16_t, true, true, true>(u, z, ldz, dt_low, lddt, Wdt, Rp, bc, A2, a_scale, Dskip, dbias, y, S, L, E, reverse, accumulate, s, uyb, zblk, seg_ws);
         if (fused && Rp == 64 && lddt % 8 == 0)
-            return launch_scan_t<bf16_t, true, true>(u, z, ldz, dt_low, lddt, Wdt, Rp, bc, A2, a_scale, Dskip, dbias, y, S, L, E, reverse, accumulate, s, uyb, zblk);
-        if (fused) return launch_scan_t<bf16_t, true>(u, z, ldz, dt_low, lddt, Wdt, Rp, bc, A2, a_scale, Dskip, dbias, y, S, L, E, reverse, accumulate, s, uyb, zblk);
-        return launch_scan_t<bf16_t, false>(u, z, ldz, delta, E, nullptr, 0, bc, A2, a_scale, Dskip, dbias, y, S, L, E, reverse, accumulate, s, uyb, zblk);
+            return launch_scan_t<bf16_t, true, true>(u, z, ldz, dt_low, lddt, Wdt, Rp, bc, A2, a_scale, Dskip, dbias, y, S, L, E, reverse, accumulate, s, uyb, zblk, seg_ws);
+        if (fused) return launch_scan_t<bf16_t, true>(u, z, ldz, dt_low, lddt, Wdt, Rp, bc, A2, a_scale, Dskip, dbias, y, S, L, E, reverse, accumulate, s, uyb, zblk, seg_ws);
+        return launch_scan_t<bf16_t, false>(u, z, ldz, delta, E, nullptr, 0, bc, A2, a_scale, Dskip, dbias, y, S, L, E, reverse, accumulate, s, uyb, zblk, seg_ws);
     }
-    if (fused) return launch_scan_t<float, true>(u, z, ldz, dt_low, lddt, Wdt, Rp, bc, A2, a_scale, Dskip, dbias, y, S, L, E, reverse, accumulate, s, uyb, zblk);
-    return launch_scan_t<float, false>(u, z, ldz, delta, E, nullptr, 0, bc, A2, a_scale, Dskip, dbias, y, S, L, E, reverse, accumulate, s, uyb, zblk);
+    if (fused) return launch_scan_t<float, true>(u, z, ldz, dt_low, lddt, Wdt, Rp, bc, A2, a_scale, Dskip, dbias, y, S, L, E, reverse, accumulate, s, uyb, zblk, seg_ws);
+    return launch_scan_t<float, false>(u, z, ldz, delta, E, nullptr, 0, bc, A2, a_scale, Dskip, dbias, y, S, L, E, reverse, accumulate, s, uyb, zblk, seg_ws);
 }
 
 }  // namespace pcad

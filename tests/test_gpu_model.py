@@ -180,6 +180,32 @@ def test_long_window_8192():
     assert (lg[:, 0, 3:7].argmax(-1) == lg_ref[:, 4095, 3:7].argmax(-1)).all()
 
 
+@pytest.mark.parametrize("dtype,D,L,B", [(torch.float32, 256, 4096, 1), (torch.bfloat16, 384, 8192, 2), (torch.bfloat16, 768, 2048, 3),
+                                          (torch.float32, 128, 2080, 2)])
+def test_segmented_scan_equals_single_walk(dtype, D, L, B):
+    """long windows, few strands: the scan cuts every strand into segments run by separate workgroups (zero-state pass, carry,
+    real pass; csrc/kernels.hpp::scan_segments).  Same function as one workgroup walking the whole strand (`scan_segments` = 0):
+    fp32 to 2e-5 of max (the carried decay is exp2(A * sum delta) instead of a product of per-step exps), bf16 to bf16 noise;
+    L = 2080: last segment shorter than the others and a partial 32-step block."""
+    cfg = make_config("x", d_model=D, n_layer=2)
+    sd = synthetic_state_dict(cfg, seed=31)
+    ids = rand_ids(B, L, 3, mask=L // 2).to(DEV)
+    pos = [L // 2, 0, L - 1, 1031]
+    a = build(cfg, sd, dtype)(input_ids=ids, output_hidden_states=True, positions=pos)
+    b = build(cfg, sd, dtype, scan_segments=0)(input_ids=ids, output_hidden_states=True, positions=pos)
+    la, lb = a.logits.float().cpu(), b.logits.float().cpu()
+    ha, hb = a.hidden_states[-1].float().cpu(), b.hidden_states[-1].float().cpu()
+    tol = 2e-5 if dtype == torch.float32 else 2e-2
+    assert torch.isfinite(la).all()
+    assert ((la - lb).abs().max() / lb.abs().max()).item() < tol
+    assert ((ha - hb).abs().max() / hb.abs().max()).item() < tol
+    if dtype == torch.float32:
+        assert torch.equal(la[..., 3:7].argmax(-1), lb[..., 3:7].argmax(-1))
+    # and poisoned: the segment scratch is written before it is read
+    c = build(cfg, sd, dtype, poison_workspace=1)(input_ids=ids, output_hidden_states=True, positions=pos)
+    assert torch.equal(c.logits, a.logits)
+
+
 def test_maximum_chunk_bit_identical_to_small_chunks():
     """maximum sizes: at the l32 width one default chunk is 512 windows = 524 288 token-rows, whose x / xc / y tensors are
     2 GiB each, so the kernels' unsigned 32-bit byte offsets run past 2^31.  Rows are independent, so the result must be
