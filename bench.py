@@ -244,7 +244,7 @@ def main():
                              "hbm_frac": by_seq * total / dt / 1e9 / world / PEAK_HBM,
                              "note": "per GPU; SURVEY.md §8(d) algorithmic flops (tie-folded) and bytes (GEMM-boundary fusion) "
                                      "per window x windows / timed wall clock"}
-        chunk_max = max(1, (1 << 31) // (cfg.d_inner * esz) // (2 * L))                      # as api.hip
+        chunk_max = max(1, ((((1 << 32) - (2 << 20)) // (cfg.d_inner * esz)) & ~7) // (2 * L))   # as api.hip
         if args.chunk_seqs:
             chunk_max = args.chunk_seqs
         elif os.environ.get("PCAD_DEV") == "1" and os.environ.get("PCAD_CHUNK_SEQS"):

@@ -228,13 +228,14 @@ int pcad_create(const pcad_config* cfg, pcad_handle* out) {
     e->rdt = (cfg->residual_in_fp32 || cfg->dtype == PCAD_F32) ? F32 : BF16;
     const char* ck = dev_env("PCAD_CHUNK_SEQS");       // PCAD_DEV=1 only; the ABI's knob is pcad_set_option("chunk_seqs")
     // Token-rows per chunk: bounded by the kernels' unsigned 32-bit in-tensor byte offsets (rows * E * esz < 2^32 in the scan,
-    // the fused conv+x_proj kernel and the 4-wave GEMM); 2^31 / (E * esz) = 524288 rows = 512 windows of 512 bp at l32 bf16
-    // (15 GB of workspace) keeps a factor 2 of margin.  Fewer, larger launches: 1024 windows as 4 chunks instead of 16 measured +6 %
-    // (each of the 193 launches per chunk pays a fill/drain of the chip).  Floor: one launch of the scan should fill the
-    // chip's 4096 wave slots (2 strands x E/64 waves per window).
+    // the fused conv+x_proj kernel and the 4-wave GEMM): (2^32 - 2 MiB) / (E * esz) rows = 1023 windows of 512 bp at l32 bf16
+    // (30 GB of workspace), 85 windows of 8 192 bp at the l28 width.  Fewer, larger launches: 1024 windows as 4 chunks instead of
+    // 16 measured +6 % (each of the 193 launches per chunk pays a fill/drain of the chip), and for long windows the chunk is what
+    // sets the scan's wave count (strands x E/64): 80 windows of 8 192 bp as one chunk instead of two, +20 %.  Floor: one launch
+    // of the scan should fill the chip's 4096 wave slots (2 strands x E/64 waves per window).
     e->chunk = ck ? atoi(ck) : 0;
     if (e->chunk < 0) e->chunk = 0;
-    e->chunk_rows = ((int64_t)1 << 31) / ((int64_t)e->E * e->esz);
+    e->chunk_rows = ((((int64_t)1 << 32) - ((int64_t)2 << 20)) / ((int64_t)e->E * e->esz)) & ~(int64_t)7;
     // developer A/B switches (honoured only with PCAD_DEV=1): plain layouts / unfused conv
     e->blocked = dev_env("PCAD_PLAIN_LAYOUT") == nullptr && (e->E * e->esz) % 128 == 0;
     e->xzsplit = e->blocked && dev_env("PCAD_PLAIN_XZ") == nullptr && e->E % 16 == 0;

@@ -207,16 +207,16 @@ def test_segmented_scan_equals_single_walk(dtype, D, L, B):
 
 
 def test_maximum_chunk_bit_identical_to_small_chunks():
-    """maximum sizes: at the l32 width one default chunk is 512 windows = 524 288 token-rows, whose x / xc / y tensors are
-    2 GiB each, so the kernels' unsigned 32-bit byte offsets run past 2^31.  Rows are independent, so the result must be
-    bit-identical to the same batch walked in 64-window chunks."""
+    """maximum sizes: at the l32 width one chunk holds up to 1023 windows = 1 047 552 token-rows, whose x / xc / y tensors are just
+    under 4 GiB each, so the kernels' unsigned 32-bit byte offsets run to the top of their range.  Rows are independent, so the
+    result must be bit-identical to the same batch walked in 64-window chunks (and to a 512-window chunk: offsets past 2^31)."""
     cfg = make_config("l32", n_layer=1)
     sd = synthetic_state_dict(cfg, seed=8)
-    ids = rand_ids(520, 512, 77, mask=255)           # 520 -> chunks of 260 + 260 by default; rows of the 2nd half past 2^31 B / 2
+    ids = rand_ids(1023, 512, 77, mask=255)
     pos = [255, 0, 511]
     big = build(cfg, sd, torch.bfloat16)
-    a = big(input_ids=ids[:512].to(DEV), output_hidden_states=True, positions=pos)       # ONE chunk of 512 windows
-    b = big(input_ids=ids.to(DEV), output_hidden_states=True, positions=pos)
+    a = big(input_ids=ids[:512].to(DEV), output_hidden_states=True, positions=pos)       # one chunk of 512 windows
+    b = big(input_ids=ids.to(DEV), output_hidden_states=True, positions=pos)             # ONE chunk of 1023 windows
     la, ha = a.logits.cpu(), a.hidden_states[-1].float().cpu()
     lb, hb = b.logits.cpu(), b.hidden_states[-1].float().cpu()
     del big, a, b
