@@ -186,8 +186,8 @@ class CaduceusPreTrainedModel(PreTrainedModel):
         return model
 
     def preferred_batch_size(self, seqlen: int) -> int:
-        """Windows per forward call at which the engine's launches are largest: two full chunks of the layer-stack walk
-        (a chunk is 2^31 / (d_inner * elem) token-rows: 512 windows of 512 bp at l32 bf16, see csrc/api.hip).  Results do
+        """Windows per forward call the host loops batch up to: 2 x 2^31 / (d_inner * elem) token-rows (1024 windows of 512 bp
+        at l32 bf16 = two 512-window chunks of the layer-stack walk, the benchmark's batch; see csrc/api.hip).  Results do
         not depend on the batch size (windows are independent), so host loops may batch up to this regardless of the
         `-batchSize` they were given."""
         p = self._backbone_owner().caduceus_param()
