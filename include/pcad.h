@@ -75,14 +75,22 @@ typedef struct pcad_tensor {
 
 int         pcad_version(void);
 const char* pcad_last_error(void);
+/* sha1 (16 hex digits) over the kernel sources the library was built from (csrc/source_hash.py): a loader that has the
+ * sources beside it compares the two and refuses a stale binary (plantcaduceus_amd/engine.py, bench.py). */
+const char* pcad_build_hash(void);
 
 /* Replaces: AutoModelForMaskedLM.from_pretrained(...).to(device)  (src/zero_shot_score.py:91-97) */
 int    pcad_create(const pcad_config* cfg, pcad_handle* out);
 void   pcad_destroy(pcad_handle h);
 
 /* Options (call before pcad_workspace_bytes / pcad_forward):
- *   "chunk_seqs"  windows per pass through the layer stack (0 = default: as many as the kernels' 32-bit offsets allow,
- *                 512 at l32 bf16).  Results do not depend on it (rows are independent); workspace size does.
+ *   "chunk_seqs"  windows per pass through the layer stack (0 = default: as many as the kernels' unsigned 32-bit in-tensor
+ *                 offsets allow, (2^32 - 2 MiB) / (d_inner * elem) token-rows = 1 023 windows of 512 bp at l32 bf16, the batch
+ *                 split evenly into the fewest such chunks).  Results do not depend on it (rows are independent); the
+ *                 workspace does: ~30 MB per window at l32 bf16, i.e. up to ~30 GB for one 1 023-window chunk (a batch of
+ *                 1 024 runs as two chunks of 512 in a 15.3 GB workspace) - always size it with pcad_workspace_bytes.
+ *   "last_layer_shortcut"  1 (default): when pcad_forward is given a list of positions, the LAST layer's scans stop at the
+ *                 furthest evaluated row and its out_proj runs on the evaluated rows only (bit-identical outputs);  0: full layer.
  *   "gate_each"   1: SiLU(z) applied to each direction's scan output, each rounded, then summed — the reference's order
  *                 (two selective_scan_fn calls);  0 (default): applied once to the sum of both directions (same value in
  *                 exact arithmetic, one rounding fewer, faster).
@@ -94,6 +102,15 @@ void   pcad_destroy(pcad_handle h);
  *                 read of anything this forward did not write shows up as NaN outputs (tests/test_gpu_model.py).
  * The library reads NO environment variables unless PCAD_DEV=1 is set (developer A/B switches, see csrc/kernels.hpp). */
 int    pcad_set_option(pcad_handle h, const char* key, int64_t value);
+
+/* Asynchronous input validation.  The reference raises (nn.Embedding index error / tensor index error) for a token id
+ * outside the vocabulary or an evaluated position outside the window; pcad_forward* never synchronise, so they report these
+ * through a caller-owned DEVICE word: bit PCAD_STATUS_BAD_TOKEN / PCAD_STATUS_BAD_POSITION is OR-ed into *status by the
+ * forward's last kernel (such an id is embedded as id & 7, such a position is clamped, so nothing is read out of bounds and
+ * the affected rows are simply wrong).  The caller zeroes the word, and reads it at its next synchronisation point.
+ * NULL (default): no reporting. */
+enum pcad_status_bits { PCAD_STATUS_BAD_TOKEN = 1, PCAD_STATUS_BAD_POSITION = 2 };
+int    pcad_set_status_buffer(pcad_handle h, int32_t* status);
 
 /* Bytes of caller-owned device memory that pcad_bind_weights packs the model into. */
 size_t pcad_weight_arena_bytes(pcad_handle h);
@@ -122,8 +139,9 @@ int    pcad_forward(pcad_handle h, const int32_t* ids, int B, int L,
                     void* workspace, size_t workspace_bytes, pcad_stream stream);
 
 /* In-silico-mutagenesis form (reference pipelines/in-silico-mutagenesis -> src/zero_shot_score.py -input-vcf, one
- * masked forward per variant position): window b is evaluated at its own position pos_per_seq[b] (device int32 [B],
- * clamped to [0, L)).  hidden_out [B, 1, 2*D] / logits_out [B, 1, vocab], either may be NULL. */
+ * masked forward per variant position): window b is evaluated at its own position pos_per_seq[b] (device int32 [B]; a value
+ * outside [0, L) is clamped AND reported through pcad_set_status_buffer).  hidden_out [B, 1, 2*D] / logits_out [B, 1, vocab],
+ * either may be NULL. */
 int    pcad_forward_at(pcad_handle h, const int32_t* ids, int B, int L, const int32_t* pos_per_seq,
                        void* hidden_out, float* logits_out,
                        void* workspace, size_t workspace_bytes, pcad_stream stream);

@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "../../include/pcad.h"
+#include "build_hash.h"
 #include "kernels.hpp"
 
 using namespace pcad;
@@ -69,8 +70,10 @@ struct pcad_engine {
     bool xzsplit;   // in_proj writes x and z as two blocked tensors (needs `blocked`); PCAD_PLAIN_XZ=1 turns it off (A/B knob)
     bool blocked;   // xc and y in the blocked layout (common.hpp::blocked_off); PCAD_PLAIN_LAYOUT=1 turns it off (A/B knob)
     bool segments = true;  // pcad_set_option("scan_segments", 0): never cut the scan of long strands into segments
+    bool shortcut = true;  // pcad_set_option("last_layer_shortcut", 0): run the last layer in full even when only a few positions are evaluated
     bool poison = false;   // pcad_set_option("poison_workspace", 1): debug — fill the workspace with 0xFF (NaN patterns) before every forward
     bool bound = false;
+    int32_t* status = nullptr;   // caller-owned device word for asynchronous input-validation flags (pcad_set_status_buffer)
     std::vector<LayerWeights> layers;
     void* emb = nullptr;        // [V, D] dtype
     float* emb_f32 = nullptr;   // [V, D] fp32 copy of the dtype-rounded table
@@ -204,6 +207,7 @@ int64_t numel(const pcad_tensor* t) {
 extern "C" {
 
 int pcad_version(void) { return PCAD_VERSION; }
+const char* pcad_build_hash(void) { return PCAD_BUILD_HASH; }
 const char* pcad_last_error(void) { return g_err; }
 
 int pcad_create(const pcad_config* cfg, pcad_handle* out) {
@@ -265,9 +269,18 @@ int pcad_set_option(pcad_handle h, const char* key, int64_t value) {
         h->poison = value != 0;
     } else if (k == "scan_segments") {
         h->segments = value != 0;
+    } else if (k == "last_layer_shortcut") {
+        h->shortcut = value != 0;
     } else {
         return fail(PCAD_ERR_INVALID, "pcad_set_option: unknown option '%s'", key);
     }
+    return PCAD_OK;
+}
+
+int pcad_set_status_buffer(pcad_handle h, int32_t* status) {
+    if (!h) return fail(PCAD_ERR_INVALID, "pcad_set_status_buffer: null handle");
+    if (((uintptr_t)status) % 4) return fail(PCAD_ERR_INVALID, "pcad_set_status_buffer: misaligned pointer");
+    h->status = status;
     return PCAD_OK;
 }
 
@@ -460,11 +473,25 @@ static int forward_impl(pcad_handle h, const int32_t* ids, int B, int L, const i
         }
         return PCAD_OK;
     };
+    // Last-layer shortcut (reference callers read ONE position: src/zero_shot_score.py:117,
+    // src/train_XGBoost.py:105): with a shared list of P evaluated positions only rows p_q of the forward strands and L - 1 - p_q of
+    // the reverse-complement strands of the LAST mixer's output are consumed.  The left-to-right scan stops after the furthest of
+    // them, the right-to-left scan likewise (walk_len steps each), and the tied out_proj runs on the 2B * P gathered rows.  Same
+    // arithmetic on the consumed rows (sequential walks, row-independent GEMM): results are bit-identical to the full layer.
+    int walk_len = 0;
+    if (e->shortcut && P > 0 && !pos_per_seq && !all_hidden && (int64_t)P * E <= (int64_t)L * D) {
+        int pmin = pos.p[0], pmax = pos.p[0];
+        for (int i = 1; i < P; ++i) { pmin = pos.p[i] < pmin ? pos.p[i] : pmin; pmax = pos.p[i] > pmax ? pos.p[i] : pmax; }
+        const int need = (pmax + 1 > L - pmin) ? pmax + 1 : L - pmin;      // forward strands need row pmax, rc strands row L - 1 - pmin
+        walk_len = (need + 7) / 8 * 8;                                   // whole 8-step groups (two prefetch chunks)
+        if (walk_len > L) walk_len = L;
+    }
     auto phase_V = [&](Lane& c, int li) -> int {        // x_proj + fused dt_proj/scan, both directions; out_proj
         hipStream_t s = cs;
         const LayerWeights& W = e->layers[li];
         const int S = 2 * c.Bc;
         const int64_t rows = (int64_t)S * L;
+        const bool last_short = walk_len > 0 && li + 1 == e->nl;
         for (int d = 0; d < 2; ++d) {
             const DirWeights& dw = W.dir[d];
             // x_proj -> dt_low [rows, Rp] (model dtype, zero padded) and B_t | C_t [rows, 32] (fp32 side output)
@@ -480,7 +507,13 @@ static int forward_impl(pcad_handle h, const int32_t* ids, int B, int L, const i
             const bool gated = !e->gate_once || d == 1;
             HIP_TRY(launch_scan(c.w.xc[d], gated ? zp : nullptr, e->xzsplit ? E : 2 * E, nullptr, c.w.dtl[d], Rp, dw.Wdt, Rp,
                                 c.w.bc[d], dw.A2, 1.0f, dw.Dskip, dw.dt_bias, c.w.y, S, L, E, d == 1,
-                                d == 1 ? (e->gate_once ? 2 : 1) : 0, dt, s, e->blocked, e->xzsplit, c.w.seg));
+                                d == 1 ? (e->gate_once ? 2 : 1) : 0, dt, s, e->blocked, e->xzsplit, c.w.seg, last_short ? walk_len : 0));
+        }
+        if (last_short) {       // out_proj on the evaluated rows only: gather (-> u, dead since in_proj) and a small GEMM (-> first rows of h)
+            ProfScope ps(e, PCAD_K_HEAD, s);          // counted with the head: not a full-size out_proj launch
+            HIP_TRY(launch_gather_rows(c.w.y, c.w.u, c.Bc, L, E, pos, dt, e->blocked, s));
+            HIP_TRY(launch_gemm_nt(c.w.u, E, W.W_out, E, c.w.h, D, (int64_t)S * P, D, E, dt, dt, false, s, false));
+            return PCAD_OK;
         }
         // out_proj on (y_fwd + y_rev): the two tied out_proj calls folded by linearity
         { ProfScope ps(e, PCAD_K_GEMM_OUT, s);
@@ -497,7 +530,8 @@ static int forward_impl(pcad_handle h, const int32_t* ids, int B, int L, const i
         if (hout || lout) {
             ProfScope ps(e, PCAD_K_HEAD, cs);
             HIP_TRY(launch_final_head(c.w.h, c.w.res, e->normf_w, e->emb, e->emb_f32, e->comp, hout, lout, c.Bc, L, D, eps,
-                                      pos, pos_per_seq ? pos_per_seq + c.b0 : nullptr, dt, rdt, cs));
+                                      pos, pos_per_seq ? pos_per_seq + c.b0 : nullptr, dt, rdt, cs, walk_len > 0,
+                                      ids + (int64_t)c.b0 * L, e->status));
         }
         return PCAD_OK;
     };

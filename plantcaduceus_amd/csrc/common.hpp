@@ -33,6 +33,7 @@ template <> struct Elem<float> {
     static __device__ __forceinline__ float from_f32(float v) { return v; }
     static __device__ __forceinline__ void store(float* p, float v) { *p = v; }
     static __device__ __forceinline__ float round(float v) { return v; }
+    static __device__ __forceinline__ f32x2_t round2(f32x2_t v) { return v; }
 };
 template <> struct Elem<bf16_t> {
     static __device__ __forceinline__ float load(const bf16_t* p) { return bf16_to_f32(*p); }
@@ -40,6 +41,10 @@ template <> struct Elem<bf16_t> {
     static __device__ __forceinline__ bf16_t from_f32(float v) { return f32_to_bf16(v); }
     static __device__ __forceinline__ void store(bf16_t* p, float v) { *p = f32_to_bf16(v); }
     static __device__ __forceinline__ float round(float v) { return round_to_bf16(v); }
+    static __device__ __forceinline__ f32x2_t round2(f32x2_t v) {         // one v_cvt_pk_bf16_f32 for the pair
+        const uint32_t pk = pack_bf16x2(v[0], v[1]);
+        return f32x2_t{bf16lo_to_f32(pk), bf16hi_to_f32(pk)};
+    }
 };
 
 // 8 consecutive elements <-> 8 floats (16-byte accesses for bf16, 2x16 bytes for fp32)
@@ -105,6 +110,25 @@ __device__ __forceinline__ float softplus(float x) {
     const float small = p * e;
     const float l = e < 0.015625f ? small : big;
     return x > 20.0f ? x : l;
+}
+
+// Two values at once on the packed fp32 pipe, branch- and select-free:
+//   softplus(x) = max(x, 0) + log1p(e),  e = exp(-|x|) in (0, 1]
+//   log1p(e)    = log2(w) ln 2 + r (1 - e),  w = fl(1 + e),  r = e - (w - 1)  (the rounding error of 1 + e, exact)
+// r / w is the first-order correction of log(w + r); 1 / w ~ 1 - e where it matters (e << 1: the result is ~e and log2(w)
+// alone would lose it to the rounding of 1 + e), and for e -> 1 the term is < 2^-25 absolute against a result > 0.4.
+// For x > 20 the sum is x + 2e-9 = x exactly (torch's threshold branch needs no select) and nothing overflows.
+// Per pair: 7 packed ops + 2 v_max + 2 v_exp_f32 + 2 v_log_f32 (the select form above: 20 plain ops + 4 transcendentals).
+typedef float f2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f2_t softplus2(f2_t x) {
+    const f2_t t = x * f2_t{kLog2e, kLog2e};
+    const f2_t e = {fast_exp2(-__builtin_fabsf(t[0])), fast_exp2(-__builtin_fabsf(t[1]))};
+    const f2_t w = e + f2_t{1.0f, 1.0f};
+    const f2_t r = e - (w - f2_t{1.0f, 1.0f});
+    const f2_t lg = {fast_log2(w[0]), fast_log2(w[1])};
+    const f2_t c = r - r * e;
+    const f2_t m = {__builtin_fmaxf(x[0], 0.0f), __builtin_fmaxf(x[1], 0.0f)};
+    return lg * f2_t{kLn2, kLn2} + (c + m);
 }
 
 }  // namespace pcad

@@ -29,11 +29,13 @@ hipError_t launch_embed_rmsnorm(const int32_t* ids, const void* emb, const int32
                                 void* y, void* res_out, int B, int L, int D, float eps, int dt, int rdt,
                                 hipStream_t s);
 // final add + norm_f + RC re-assembly + tied RCPS LM head, only at the requested positions (a shared list `pos`,
-// or one position per window from the device array `pos_per_seq` [B]).
+// or one position per window from the device array `pos_per_seq` [B]).  h_compact: h holds only the evaluated rows,
+// [(strand * P + q), D] as launch_gather_rows orders them (the residual stream `res` is always the full tensor).
+// ids [B, L] + status (device word, or nullptr): token ids outside [0, 8) / per-window positions outside [0, L) set bits 1 / 2.
 hipError_t launch_final_head(const void* h, const void* res, const float* w, const void* emb,
                              const float* emb_f32, const int32_t* comp8, void* hidden_out, float* logits_out,
                              int B, int L, int D, float eps, Positions pos, const int32_t* pos_per_seq, int dt, int rdt,
-                             hipStream_t s);
+                             hipStream_t s, bool h_compact = false, const int32_t* ids = nullptr, int32_t* status = nullptr);
 // hidden_states[i] (block input = previous mixer output / embedding) assembled in RCPS layout.
 hipError_t launch_assemble_hidden(const void* h, void* out, int B, int L, int D, int dt, hipStream_t s);
 hipError_t launch_embed_only(const int32_t* ids, const void* emb, const int32_t* comp8, void* h, int B, int L,
@@ -82,10 +84,12 @@ hipError_t launch_convx(const void* x, const float* convw, const void* Wx0, void
 // z_blocked (needs uy_blocked): z is a separate [S*L, E] tensor in the same blocked layout (ldz ignored).
 // seg_ws (fused dt_proj form only): scratch of scan_segment_bytes(S, L, E) bytes; when given and scan_segments() > 1 the walk of
 // every strand is cut into segments that run as separate workgroups (long sequences with few strands: PlantCAD2's 8 192-bp windows).
+// walk_len (0 or >= L: the whole strand): only the first walk_len steps of the walk are run (forward: rows [0, walk_len); reverse:
+// rows [L - walk_len, L)); the other rows of y are not written.  Ignored when the walk is cut into segments.
 hipError_t launch_scan(const void* u, const void* z, int64_t ldz, const void* delta, const void* dt_low, int64_t lddt,
                        const void* Wdt, int Rp, const float* bc, const float* A2, float a_scale, const float* Dskip,
                        const float* dbias, void* y, int S, int L, int E, bool reverse, int accumulate, int dt,
-                       hipStream_t s, bool uy_blocked = false, bool z_blocked = false, float* seg_ws = nullptr);
+                       hipStream_t s, bool uy_blocked = false, bool z_blocked = false, float* seg_ws = nullptr, int walk_len = 0);
 
 // Segments per strand for the scan of S strands of L steps over E channels.  Pass A + pass B cost ~1.8x the arithmetic of one
 // walk, and a single wave per SIMD already keeps the VALU ~65 % busy, so cutting only pays when most SIMDs would otherwise idle
@@ -112,6 +116,9 @@ inline size_t scan_segment_bytes(int S, int L, int E) {
 }
 
 // pack.hip --------------------------------------------------------------------------------------
+// rows (strand b, p_q) and (strand B + b, L - 1 - p_q) of a [2B*L, E] activation tensor (plain or blocked) -> out[(strand * P + q), E]
+hipError_t launch_gather_rows(const void* src, void* out, int B, int L, int E, Positions pos, int dt, bool blocked,
+                              hipStream_t s);
 // generic 2-D copy/convert with zero padding: dst[r, c] (dst_dt, ld = dst_ld) = src[r, c] for r < rows, c < cols else 0
 hipError_t launch_pack2d(const void* src, int src_dt, int64_t src_ld, void* dst, int dst_dt, int64_t dst_ld,
                          int rows, int cols, int dst_rows, int dst_cols, hipStream_t s);

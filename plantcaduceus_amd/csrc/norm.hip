@@ -12,6 +12,8 @@
 
 namespace pcad {
 
+constexpr int PCAD_STATUS_BAD_TOKEN_BIT = 1, PCAD_STATUS_BAD_POSITION_BIT = 2;     // = pcad.h PCAD_STATUS_*
+
 template <typename T, typename RT, int MAXC, bool EMBED>
 __global__ __launch_bounds__(256) void add_rmsnorm_kernel(const T* __restrict__ x, const RT* __restrict__ res_in,
                                                           const float* __restrict__ w, T* __restrict__ y,
@@ -119,13 +121,26 @@ __global__ __launch_bounds__(128) void final_head_kernel(const T* __restrict__ h
                                                          const float* __restrict__ w, const float* __restrict__ emb,
                                                          const int32_t* __restrict__ comp8, T* __restrict__ hidden_out,
                                                          float* __restrict__ logits_out, int B, int L, int D, float eps,
-                                                         Positions pos, const int32_t* __restrict__ pos_per_seq) {
+                                                         Positions pos, const int32_t* __restrict__ pos_per_seq, int h_compact,
+                                                         const int32_t* __restrict__ ids, int32_t* __restrict__ status) {
     __shared__ float part[8];
     const int lane = threadIdx.x & 63;
     const int wv = threadIdx.x >> 6;   // 0: forward strand, 1: rc strand
     const int Q = pos_per_seq ? 1 : (pos.n ? pos.n : L);
     const int b = blockIdx.x / Q, q = blockIdx.x - b * Q;
     int p = q;
+    // Input validation without a host round trip: the reference's nn.Embedding / tensor indexing raise for a token id outside the
+    // vocabulary or a position outside the window; here the first block of every window scans its ids (the embedding gather
+    // aliased them to id & 7) and every block checks its own position (clamped below so that nothing is read out of bounds), and
+    // a violation sets a bit of the caller's status word, which the host reads whenever it next synchronises (pcad.h).
+    if (status != nullptr) {
+        if (q == 0 && wv == 0 && ids != nullptr) {
+            bool bad = false;
+            for (int t = lane; t < L; t += 64) bad |= (unsigned)ids[(int64_t)b * L + t] > 7u;
+            if (__any(bad) && lane == 0) atomicOr(status, PCAD_STATUS_BAD_TOKEN_BIT);
+        }
+        if (pos_per_seq && wv == 0 && lane == 0 && (unsigned)pos_per_seq[b] >= (unsigned)L) atomicOr(status, PCAD_STATUS_BAD_POSITION_BIT);
+    }
     if (pos_per_seq) {
         p = min(max(pos_per_seq[b], 0), L - 1);      // one evaluated position per window (in-silico mutagenesis sweeps)
     } else if (pos.n) {
@@ -135,6 +150,7 @@ __global__ __launch_bounds__(128) void final_head_kernel(const T* __restrict__ h
             if (i == q) p = pos.p[i];
     }
     const int64_t row = wv == 0 ? ((int64_t)b * L + p) : ((int64_t)(B + b) * L + (L - 1 - p));
+    const int64_t hrow = h_compact ? ((int64_t)(wv == 0 ? b : B + b) * Q + q) : row;     // mixer output: full tensor or evaluated rows only
     const int nchunk = D >> 3;
     float v[MAXC][8];
     float ss = 0.f;
@@ -143,7 +159,7 @@ __global__ __launch_bounds__(128) void final_head_kernel(const T* __restrict__ h
         const int c = lane + 64 * j;
         if (c < nchunk) {
             float r[8];
-            load8<T>(h + row * D + c * 8, v[j]);
+            load8<T>(h + hrow * D + c * 8, v[j]);
             load8<RT>(res + row * D + c * 8, r);
 #pragma unroll
             for (int i = 0; i < 8; ++i) { v[j][i] += r[i]; ss += v[j][i] * v[j][i]; }
@@ -207,13 +223,14 @@ __global__ __launch_bounds__(128) void final_head_kernel(const T* __restrict__ h
 template <typename T, typename RT>
 static hipError_t launch_final_t(const void* h, const void* res, const float* w, const float* emb_f32,
                                  const int32_t* comp8, void* hidden_out, float* logits_out, int B, int L, int D,
-                                 float eps, Positions pos, const int32_t* pos_per_seq, hipStream_t s) {
+                                 float eps, Positions pos, const int32_t* pos_per_seq, hipStream_t s, int h_compact,
+                                 const int32_t* ids, int32_t* status) {
     const int Q = pos_per_seq ? 1 : (pos.n ? pos.n : L);
     dim3 grid((unsigned)(B * Q)), block(128);
     if (B * Q == 0) return hipSuccess;
 #define PCAD_FH(MC)                                                                                          \
     hipLaunchKernelGGL((final_head_kernel<T, RT, MC>), grid, block, 0, s, (const T*)h, (const RT*)res, w, emb_f32, \
-                       comp8, (T*)hidden_out, logits_out, B, L, D, eps, pos, pos_per_seq)
+                       comp8, (T*)hidden_out, logits_out, B, L, D, eps, pos, pos_per_seq, h_compact, ids, status)
     if (D <= 512) PCAD_FH(1);
     else if (D <= 1024) PCAD_FH(2);
     else PCAD_FH(4);
@@ -224,14 +241,16 @@ static hipError_t launch_final_t(const void* h, const void* res, const float* w,
 hipError_t launch_final_head(const void* h, const void* res, const float* w, const void* /*emb*/,
                              const float* emb_f32, const int32_t* comp8, void* hidden_out, float* logits_out, int B,
                              int L, int D, float eps, Positions pos, const int32_t* pos_per_seq, int dt, int rdt,
-                             hipStream_t s) {
+                             hipStream_t s, bool h_compact, const int32_t* ids, int32_t* status) {
     if (D % 8 || D > 2048) return hipErrorInvalidValue;
+    if (h_compact && (pos_per_seq || pos.n == 0)) return hipErrorInvalidValue;
+    const int hc = h_compact ? 1 : 0;
     if (dt == BF16 && rdt == F32)
-        return launch_final_t<bf16_t, float>(h, res, w, emb_f32, comp8, hidden_out, logits_out, B, L, D, eps, pos, pos_per_seq, s);
+        return launch_final_t<bf16_t, float>(h, res, w, emb_f32, comp8, hidden_out, logits_out, B, L, D, eps, pos, pos_per_seq, s, hc, ids, status);
     if (dt == BF16 && rdt == BF16)
-        return launch_final_t<bf16_t, bf16_t>(h, res, w, emb_f32, comp8, hidden_out, logits_out, B, L, D, eps, pos, pos_per_seq, s);
+        return launch_final_t<bf16_t, bf16_t>(h, res, w, emb_f32, comp8, hidden_out, logits_out, B, L, D, eps, pos, pos_per_seq, s, hc, ids, status);
     if (dt == F32 && rdt == F32)
-        return launch_final_t<float, float>(h, res, w, emb_f32, comp8, hidden_out, logits_out, B, L, D, eps, pos, pos_per_seq, s);
+        return launch_final_t<float, float>(h, res, w, emb_f32, comp8, hidden_out, logits_out, B, L, D, eps, pos, pos_per_seq, s, hc, ids, status);
     return hipErrorInvalidValue;
 }
 

@@ -54,4 +54,39 @@ hipError_t launch_pack_A(const void* A_log, int src_dt, float* A2, int64_t n, fl
     return hipGetLastError();
 }
 
+// Rows of the 2B-strand activation tensor that a positions-only forward consumes after the last mixer: strand b row p_q,
+// strand B + b row L - 1 - p_q  ->  compact out[(strand * P + q), E] (plain rows).  One wave per row, 16-byte accesses.
+template <typename T>
+__global__ __launch_bounds__(256) void gather_rows_kernel(const T* __restrict__ src, T* __restrict__ out, int B, int L, int E,
+                                                          Positions pos, int blocked) {
+    const int P = pos.n;
+    const int wave = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6), lane = threadIdx.x & 63;
+    if (wave >= 2 * B * P) return;
+    const int strand = wave / P, q = wave - strand * P;
+    int p = 0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+        if (i == q) p = pos.p[i];
+    const int64_t row = (int64_t)strand * L + (strand < B ? p : L - 1 - p);
+    const int64_t rowb = (int64_t)E * sizeof(T);
+    const char* sb = reinterpret_cast<const char*>(src);
+    char* db = reinterpret_cast<char*>(out) + (int64_t)wave * rowb;
+    for (int64_t cb = (int64_t)lane * 16; cb < rowb; cb += 64 * 16) {
+        const int64_t so = blocked ? blocked_off(row, cb, rowb >> 7) : row * rowb + cb;
+        *reinterpret_cast<u32x4*>(db + cb) = *reinterpret_cast<const u32x4*>(sb + so);
+    }
+}
+
+hipError_t launch_gather_rows(const void* src, void* out, int B, int L, int E, Positions pos, int dt, bool blocked,
+                              hipStream_t s) {
+    const int64_t rows = (int64_t)2 * B * pos.n;
+    if (rows <= 0) return hipSuccess;
+    const int esz = dt == BF16 ? 2 : 4;
+    if ((E * esz) % 16 || (blocked && (E * esz) % 128)) return hipErrorInvalidValue;
+    dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+    if (dt == BF16) hipLaunchKernelGGL(gather_rows_kernel<bf16_t>, grid, block, 0, s, (const bf16_t*)src, (bf16_t*)out, B, L, E, pos, (int)blocked);
+    else hipLaunchKernelGGL(gather_rows_kernel<float>, grid, block, 0, s, (const float*)src, (float*)out, B, L, E, pos, (int)blocked);
+    return hipGetLastError();
+}
+
 }  // namespace pcad

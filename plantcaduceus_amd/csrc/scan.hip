@@ -150,7 +150,12 @@ template <> struct DeltaTile<float> {
 // run as separate workgroups.  SEG = 1, pass A: from a ZERO state, no output - stores the segment's end state and its sum of delta
 // (the product of its decays is exp2(A2 * sum delta));  SEG = 2, pass B: the normal walk of the segment from the true initial state
 // that scan_carry_kernel derived from pass A.  SEG = 0: the whole strand in one workgroup (G = 1).
-template <typename T, bool REV, int ACC, bool HASZ, bool FUSED, bool PRE, bool BLK8, int SEG = 0>
+// AIO (bf16, BLK8, z blocked or absent — the engine's instantiations): the row loads are `buffer_load_short_d16_hi` into registers
+// whose low half stays zero, so a loaded register IS the fp32 value (no shift per element), the y rows of two steps are converted by
+// one v_cvt_pk_bf16_f32 and stored from the two halves of that register, and the loads are waited for with hand-counted
+// `s_waitcnt vmcnt` (inline asm: hipcc has no pattern for d16_hi buffer accesses).  The kernel is bound by the energy of its VALU
+// stream (profiles/r03_valu_microbench.txt), so every instruction removed per (t, channel) counts.
+template <typename T, bool REV, int ACC, bool HASZ, bool FUSED, bool PRE, bool BLK8, int SEG = 0, bool ZB = false, bool AIO = false>
 __global__ __launch_bounds__(64, 4) void scan_kernel(const T* __restrict__ u, const T* __restrict__ z, int64_t ldz,
                                                   const T* __restrict__ dsrc, int64_t ldd,
                                                   const T* __restrict__ Wdt, int Rp,
@@ -158,8 +163,10 @@ __global__ __launch_bounds__(64, 4) void scan_kernel(const T* __restrict__ u, co
                                                   const float* __restrict__ A2, float a_scale,
                                                   const float* __restrict__ Dskip, const float* __restrict__ dbias,
                                                   const T* yin, T* y, int L, int E, int uyb, int zblk, int G, int seg_blocks,
-                                                  float* __restrict__ seg_state) {
-    __shared__ float dvs[TB][64];
+                                                  float* __restrict__ seg_state, int Lw) {
+    // delta slab: rows 1..TB hold the block's TB steps; rows 0 and TB + 1 are never-consumed landing rows for the one-step-ahead
+    // read at the block's ends, so that read needs no wrap (its address is a per-chunk base + a compile-time offset)
+    __shared__ float dvs[TB + 2][64];
     const int lane = threadIdx.x;
     const int c0 = blockIdx.x * 64;
     const int c = c0 + lane;
@@ -193,7 +200,9 @@ __global__ __launch_bounds__(64, 4) void scan_kernel(const T* __restrict__ u, co
     const float dsk = Dskip[c];
     const float db = dbias[c];
 
-    const int nblk = (L + TB - 1) / TB;
+    // Lw <= L: number of walk steps to run (the last layer of a forward that is evaluated at a few positions only needs the
+    // walk up to the furthest of them: rows past it are left as they were and are never read).  Addresses still clamp at L.
+    const int nblk = (Lw + TB - 1) / TB;
     // walk order: step s = 0..L-1 visits t = REV ? L-1-s : s.  Block b covers walk steps [b*TB, (b+1)*TB), i.e.
     // memory rows [tb0, tb0+TB) with tb0 = REV ? L-(b+1)*TB : b*TB (tb0 < 0 / rows >= L are clamped loads whose
     // delta is never consumed); blocks are aligned in WALK space so the CH-step prefetch chunks never straddle.
@@ -210,7 +219,7 @@ __global__ __launch_bounds__(64, 4) void scan_kernel(const T* __restrict__ u, co
     const bool blk = BLK8 || uyb;       // BLK8 instantiations: known at compile time
     const auto u_r = blk ? make_rsrc(u, tot_rows * rowE) : make_rsrc(u + row0 * E + c0, (uint32_t)L * rowE);
     const auto y_r = blk ? make_rsrc(y, tot_rows * rowE) : make_rsrc(y + row0 * E + c0, (uint32_t)L * rowE);   // also the ACC input
-    const bool zb_ = HASZ && blk && zblk;      // z: separate tensor in the same blocked layout as u -> same offsets
+    const bool zb_ = ZB || (HASZ && blk && zblk);      // z: separate tensor in the same blocked layout as u -> same offsets (ZB: known at compile time)
     const auto z_r = zb_ ? make_rsrc(z, tot_rows * rowE) : make_rsrc(HASZ ? z + row0 * ldz + c0 : u, (uint32_t)L * rowZ);
     const auto d_r = make_rsrc(FUSED ? u : dsrc + row0 * ldd + c0, (uint32_t)L * rowD);
     const float* __restrict__ bc_s = bc + row0 * (2 * NSTATE);
@@ -244,15 +253,55 @@ __global__ __launch_bounds__(64, 4) void scan_kernel(const T* __restrict__ u, co
 #pragma unroll
         for (int i = 0; i < CH; ++i) {
             const uint32_t t = (uint32_t)tclamp(s0 + i);
-            uu[i] = BufIO<T>::load(u_r, uy_voff(i), uy_soff(s0, i));
-            if constexpr (HASZ) zz[i] = zb_ ? BufIO<T>::load(z_r, uy_voff(i), uy_soff(s0, i)) : BufIO<T>::load(z_r, voff, t * rowZ);
-            if constexpr (ACC != 0) yy[i] = BufIO<T>::load(y_r, uy_voff(i), uy_soff(s0, i));
+#ifdef PCAD_SCAN_HOT      // timing-only ablation: every row load comes from the first 64 KiB of its tensor (cache hits)
+            const uint32_t so = uy_soff(s0, i) & 0xffffu;
+#else
+            const uint32_t so = uy_soff(s0, i);
+#endif
+            uu[i] = BufIO<T>::load(u_r, uy_voff(i), so);
+            if constexpr (HASZ && ZB) zz[i] = BufIO<T>::load(z_r, uy_voff(i), so);
+            else if constexpr (HASZ) zz[i] = zb_ ? BufIO<T>::load(z_r, uy_voff(i), so) : BufIO<T>::load(z_r, voff, t * rowZ);
+            if constexpr (ACC != 0) yy[i] = BufIO<T>::load(y_r, uy_voff(i), so);
             if constexpr (!FUSED) dd[i] = BufIO<T>::load(d_r, voff, t * rowD);
         }
     };
     const int b_begin = SEG ? seg * seg_blocks : 0;                        // first block (walk space) of this workgroup
     const int s_first = b_begin * TB;
-    load_chunk(s_first, ub, zb, yb, dr);
+    // ---- AIO: d16_hi row loads with hand-counted waits ------------------------------------------------------------------------
+    // NL asm loads per step, issued in step order, one chunk (CH steps) per call.  When step i of a chunk is consumed, the asm loads
+    // issued after ITS loads are the rest of its chunk and the whole next chunk (the other register set, loaded before this
+    // chunk's steps run): vmcnt(NL * (CH - 1 - i) + NL * CH).  Stores and compiler-generated loads in between only make the
+    // real count larger, i.e. the wait conservative (VMEM returns in order).
+    constexpr int NL = 1 + (HASZ ? 1 : 0) + (ACC != 0 ? 1 : 0);
+    uint32_t ua[2][CH], za[2][CH], ya[2][CH];
+    u32x4 urs = {0, 0, 0, 0}, zrs = {0, 0, 0, 0}, yrs = {0, 0, 0, 0};
+    if constexpr (AIO) {
+        auto mk = [&](const void* base, uint32_t bytes) {
+            const uint64_t a = (uint64_t)base;
+            return u32x4{(uint32_t)a, (uint32_t)(a >> 32) & 0xffffu, bytes, 0x00020000u};
+        };
+        urs = mk(u, tot_rows * rowE);
+        zrs = mk(HASZ ? z : u, tot_rows * rowE);
+        yrs = mk(y, tot_rows * rowE);
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+#pragma unroll
+            for (int i = 0; i < CH; ++i) { ua[k][i] = 0u; za[k][i] = 0u; ya[k][i] = 0u; }
+    }
+#define PCAD_LD16HI(reg, rs, so, imm) \
+    asm volatile("buffer_load_short_d16_hi %0, %1, %2, %3 offen offset:%4" : "+v"(reg) : "v"(voff_uy), "s"(rs), "s"(so), "n"(imm))
+    auto aio_load = [&](int s0, uint32_t (&uu)[CH], uint32_t (&zz)[CH], uint32_t (&yy)[CH]) __attribute__((always_inline)) {
+        const uint32_t so = uy_soff(s0, 0);            // BLK8: one scalar offset per chunk, the step's +-128 B in the immediate
+#define PCAD_LD_STEP(i)                                                                  \
+        PCAD_LD16HI(uu[i], urs, so, 128 * (REV ? CH - 1 - (i) : (i)));                   \
+        if constexpr (HASZ) PCAD_LD16HI(zz[i], zrs, so, 128 * (REV ? CH - 1 - (i) : (i))); \
+        if constexpr (ACC != 0) PCAD_LD16HI(yy[i], yrs, so, 128 * (REV ? CH - 1 - (i) : (i)))
+        PCAD_LD_STEP(0); PCAD_LD_STEP(1); PCAD_LD_STEP(2); PCAD_LD_STEP(3);
+#undef PCAD_LD_STEP
+    };
+    static_assert(CH == 4, "aio_load / aio_chunk are written for 4-step chunks");
+    if constexpr (AIO) aio_load(s_first, ua[0], za[0], ya[0]);
+    else load_chunk(s_first, ub, zb, yb, dr);
 
     // B_t | C_t of the step being computed (SGPRs), software-pipelined one step ahead of the VALU work
     f2 bcc[NSTATE];
@@ -265,45 +314,42 @@ __global__ __launch_bounds__(64, 4) void scan_kernel(const T* __restrict__ u, co
 
     // one recurrence step on raw inputs (uraw, zraw, yraw, draw) at walk step s
     float dv_cur = 0.f;    // FUSED: delta of the step about to run, read from LDS one step ahead
-    auto step = [&](int s, int tb0, uint32_t oy, int vy, T uraw, T zraw, T yraw, T draw) {
+    // dvp: this lane's column of the delta slab at the chunk's base row (walk step s0 of the block, k0 = s0 - s_begin):
+    //   forward &dvs[k0][lane], reverse &dvs[TB - CH - k0][lane]; the NEXT step's delta of chunk step i is a compile-time
+    //   number of rows from there (slab row = block row + 1; at the block's ends the landing rows are read and never consumed)
+    // uv / zv / yv: this step's u, z and (ACC) other-direction y as fp32.  Returns the value to store (SEG == 1: nothing).
+    auto step = [&](int s, int i, const float* dvp, float uv, float zv, float yprev, T draw) -> float {
         f2 bcn[NSTATE];
         load_bc(s + 1, bcn);
-        const uint32_t t = (uint32_t)tclamp(s);
         float dv, dv_next = 0.f;
         if constexpr (FUSED) {
             dv = dv_cur;
-            // next step's row of the slab; wraps at the end of the block, where the value is never used
-            dv_next = dvs[((int)t - tb0 + (REV ? -1 : 1)) & (TB - 1)][lane];
+            dv_next = dvp[(REV ? CH - 1 - i : i + 2) * 64];
         } else {
             dv = softplus(Elem<T>::to_f32(draw) + db);
         }
-        const float uv = Elem<T>::to_f32(uraw);
         const float du = dv * uv;
         const f2 dv2 = {dv, dv}, du2 = {du, du};
-        f2 yacc0 = {dsk * uv, 0.f}, yacc1 = {0.f, 0.f};      // two independent accumulation chains
+        // D skip (and, gated-once reverse pass, the other direction's output) seed the accumulation: one fma, no separate add
+        f2 yacc = {ACC == 2 ? __builtin_fmaf(dsk, uv, yprev) : dsk * uv, 0.f};
         if constexpr (SEG == 1) dsum += dv;
 #pragma unroll
-        for (int p = 0; p < NSTATE / 2; p += 2) {
-            const f2 e0 = dv2 * a2p[p], e1 = dv2 * a2p[p + 1];
-            const f2 a0 = {exp2_hw(e0[0]), exp2_hw(e0[1])}, a1 = {exp2_hw(e1[0]), exp2_hw(e1[1])};
+        for (int p = 0; p < NSTATE / 2; ++p) {
+            const f2 e0 = dv2 * a2p[p];
+            const f2 a0 = {exp2_hw(e0[0]), exp2_hw(e0[1])};
             hp[p] = a0 * hp[p] + du2 * bcc[p];
-            hp[p + 1] = a1 * hp[p + 1] + du2 * bcc[p + 1];
-            if constexpr (SEG != 1) {
-                yacc0 = hp[p] * bcc[NSTATE / 2 + p] + yacc0;
-                yacc1 = hp[p + 1] * bcc[NSTATE / 2 + p + 1] + yacc1;
-            }
+            if constexpr (SEG != 1) yacc = hp[p] * bcc[NSTATE / 2 + p] + yacc;
         }
+        float yv = 0.f;
         if constexpr (SEG != 1) {
-            const f2 yacc = yacc0 + yacc1;
-            float yv = yacc[0] + yacc[1];
-            if constexpr (ACC == 2) yv += Elem<T>::to_f32(yraw);                        // sum of both directions, gated once
-            if constexpr (HASZ) yv *= silu(Elem<T>::to_f32(zraw));
-            if constexpr (ACC == 1) yv = Elem<T>::round(yv) + Elem<T>::to_f32(yraw);    // each direction is rounded, then summed
-            BufIO<T>::store(Elem<T>::from_f32(yv), y_r, vy, oy);
+            yv = yacc[0] + yacc[1];
+            if constexpr (HASZ) yv *= silu(zv);
+            if constexpr (ACC == 1) yv = Elem<T>::round(yv) + yprev;    // each direction is rounded, then summed
         }
 #pragma unroll
         for (int p = 0; p < NSTATE; ++p) bcc[p] = bcn[p];
         dv_cur = dv_next;
+        return yv;
     };
 
     DeltaPre pre;
@@ -328,28 +374,83 @@ __global__ __launch_bounds__(64, 4) void scan_kernel(const T* __restrict__ u, co
                 // lanes 32..63 of acc0[r] <-> lanes 0..31 of acc1[r]
                 const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc0[r]), __float_as_uint(acc1[r]),
                                                                  false, false);
-                const float v0 = __uint_as_float(sw[0]), v1 = __uint_as_float(sw[1]);
                 const int tt = (r & 3) + 8 * (r >> 2);
-                dvs[tt][lane] = softplus(Elem<T>::round(v0) + db);
-                dvs[tt + 4][lane] = softplus(Elem<T>::round(v1) + db);
+                // dt_proj output rounded to the model dtype (as F.linear returns it), + bias, softplus: both values on the packed pipe
+                const f2 dl = softplus2(Elem<T>::round2(f2{__uint_as_float(sw[0]), __uint_as_float(sw[1])}) + f2{db, db});
+                dvs[tt + 1][lane] = dl[0];
+                dvs[tt + 5][lane] = dl[1];
             }
         }
         const int s_begin = b * TB;                                      // first walk step of the block
-        const int s_end = min(L, s_begin + TB);                          // one past the last
-        if constexpr (FUSED) dv_cur = dvs[tclamp(s_begin) - tb0][lane];
-        int s0 = s_begin;
-        for (; s0 + CH <= s_end; s0 += CH) {                             // full chunks: straight-line body
-            T un[CH], zn[CH], yn[CH], dn[CH];
-            load_chunk(s0 + CH, un, zn, yn, dn);
+        const int s_end = min(Lw, s_begin + TB);                         // one past the last
+        if constexpr (FUSED) dv_cur = dvs[REV ? TB : 1][lane];          // block row of the first walk step: 0 forward, TB - 1 reverse
+        auto dv_base = [&](int s0) -> const float* { return &dvs[REV ? TB - CH - (s0 - s_begin) : (s0 - s_begin)][lane]; };
+        auto run_step = [&](int s, int i, const float* dvp, uint32_t oy, int vy, T uraw, T zraw, T yraw, T draw) {
+            const float yv = step(s, i, dvp, Elem<T>::to_f32(uraw), HASZ ? Elem<T>::to_f32(zraw) : 0.f,
+                                  ACC != 0 ? Elem<T>::to_f32(yraw) : 0.f, draw);
+            if constexpr (SEG != 1) BufIO<T>::store(Elem<T>::from_f32(yv), y_r, vy, oy);
+        };
+        auto run_chunk = [&](int s0, T (&uu)[CH], T (&zz)[CH], T (&yy)[CH], T (&dd)[CH]) {
+            const float* dvp = dv_base(s0);
 #pragma unroll
-            for (int i = 0; i < CH; ++i) step(s0 + i, tb0, uy_soff(s0, i), uy_voff(i), ub[i], zb[i], yb[i], dr[i]);
+            for (int i = 0; i < CH; ++i) run_step(s0 + i, i, dvp, uy_soff(s0, i), uy_voff(i), uu[i], zz[i], yy[i], dd[i]);
+        };
+        // AIO: one chunk from a register set whose loads were issued a chunk ago
+        auto aio_chunk = [&](int s0, uint32_t (&uu)[CH], uint32_t (&zz)[CH], uint32_t (&yy)[CH]) __attribute__((always_inline)) {
+            const float* dvp = dv_base(s0);
+            const uint32_t so = uy_soff(s0, 0);
+            float out[CH];
+#define PCAD_AIO_STEP(i)                                                                                                   \
+            if constexpr (HASZ && ACC != 0) asm volatile("s_waitcnt vmcnt(%3)" : "+v"(uu[i]), "+v"(zz[i]), "+v"(yy[i]) : "n"(NL * (CH - 1 - (i)) + NL * CH)); \
+            else if constexpr (HASZ) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(uu[i]), "+v"(zz[i]) : "n"(NL * (CH - 1 - (i)) + NL * CH)); \
+            else if constexpr (ACC != 0) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(uu[i]), "+v"(yy[i]) : "n"(NL * (CH - 1 - (i)) + NL * CH)); \
+            else asm volatile("s_waitcnt vmcnt(%1)" : "+v"(uu[i]) : "n"(NL * (CH - 1 - (i)) + NL * CH));           \
+            out[i] = step(s0 + (i), (i), dvp, __uint_as_float(uu[i]), __uint_as_float(zz[i]), __uint_as_float(yy[i]), (T)0)
+#define PCAD_AIO_STORE(i)                                                                                                  \
+            if constexpr (SEG != 1) {                                                                                      \
+                const uint32_t pk = pack_bf16x2(out[i], out[(i) + 1]);                                                     \
+                asm volatile("buffer_store_short %0, %1, %2, %3 offen offset:%4" :: "v"(pk), "v"(voff_uy), "s"(yrs), "s"(so),          \
+                             "n"(128 * (REV ? CH - 1 - (i) : (i))) : "memory");                                            \
+                asm volatile("buffer_store_short_d16_hi %0, %1, %2, %3 offen offset:%4" :: "v"(pk), "v"(voff_uy), "s"(yrs), "s"(so),   \
+                             "n"(128 * (REV ? CH - 2 - (i) : (i) + 1)) : "memory");                                        \
+            }
+            PCAD_AIO_STEP(0); PCAD_AIO_STEP(1); PCAD_AIO_STORE(0)
+            PCAD_AIO_STEP(2); PCAD_AIO_STEP(3); PCAD_AIO_STORE(2)
+#undef PCAD_AIO_STEP
+#undef PCAD_AIO_STORE
+        };
+        int s0 = s_begin;
+        if constexpr (AIO) {
+            // whole 8-step groups only (BLK8: L % 8 == 0, and a shortened walk is rounded up to 8): set 0 holds the chunk at s0
+            for (; s0 + 2 * CH <= s_end; s0 += 2 * CH) {
+                aio_load(s0 + CH, ua[1], za[1], ya[1]);
+                aio_chunk(s0, ua[0], za[0], ya[0]);
+                aio_load(s0 + 2 * CH, ua[0], za[0], ya[0]);
+                aio_chunk(s0 + CH, ua[1], za[1], ya[1]);
+            }
+            continue;
+        }
+        // two chunks per iteration on alternating register sets: no copies between the sets, and each set is waited for at
+        // its first use (a full chunk of work after its loads were issued) instead of at the end of the previous chunk
+        T un[CH], zn[CH], yn[CH], dn[CH];
+        for (; s0 + 2 * CH <= s_end; s0 += 2 * CH) {
+            load_chunk(s0 + CH, un, zn, yn, dn);
+            run_chunk(s0, ub, zb, yb, dr);
+            load_chunk(s0 + 2 * CH, ub, zb, yb, dr);
+            run_chunk(s0 + CH, un, zn, yn, dn);
+        }
+        if (s0 + CH <= s_end) {                                          // odd full chunk (only at the end of a sequence)
+            load_chunk(s0 + CH, un, zn, yn, dn);
+            run_chunk(s0, ub, zb, yb, dr);
 #pragma unroll
             for (int i = 0; i < CH; ++i) { ub[i] = un[i]; zb[i] = zn[i]; yb[i] = yn[i]; dr[i] = dn[i]; }
+            s0 += CH;
         }
         if (s0 < s_end) {                                                // tail (< CH steps, end of the sequence)
+            const float* dvp = dv_base(s0);
 #pragma unroll
             for (int i = 0; i < CH - 1; ++i)
-                if (s0 + i < s_end) step(s0 + i, tb0, uy_soff(s0, i), uy_voff(i), ub[i], zb[i], yb[i], dr[i]);
+                if (s0 + i < s_end) run_step(s0 + i, i, dvp, uy_soff(s0, i), uy_voff(i), ub[i], zb[i], yb[i], dr[i]);
         }
     }
     if constexpr (SEG == 1) {
@@ -384,15 +485,21 @@ __global__ __launch_bounds__(256) void scan_carry_kernel(float* __restrict__ seg
     }
 }
 
-template <typename T, bool FUSED, bool PRE = false, bool BLK8 = false>
+template <typename T, bool FUSED, bool PRE = false, bool BLK8 = false, bool ZB = false>
 static hipError_t launch_scan_t(const void* u, const void* z, int64_t ldz, const void* dsrc, int64_t ldd,
                                 const void* Wdt, int Rp, const float* bc, const float* A2, float a_scale,
                                 const float* Dskip, const float* dbias, void* y, int S, int L, int E, bool reverse,
-                                int accumulate, hipStream_t s, bool uyb, bool zblk = false, float* seg_ws = nullptr) {
+                                int accumulate, hipStream_t s, bool uyb, bool zblk = false, float* seg_ws = nullptr, int walk_len = 0) {
     dim3 grid((unsigned)(E / 64), (unsigned)S), block(64);
     const bool hz = z != nullptr;
+#ifdef PCAD_SCAN_NOAIO
+    constexpr bool AIOK = false;
+#else
+    constexpr bool AIOK = sizeof(T) == 2 && FUSED && PRE && BLK8 && ZB;      // every layout fixed at compile time: asm row I/O
+#endif
 #define PCAD_SCAN_ARGS(ZP) (const T*)u, (const T*)(ZP), ldz, (const T*)dsrc, ldd, (const T*)Wdt, Rp, bc, A2, a_scale, Dskip, dbias, \
                            (const T*)y, (T*)y, L, E, (int)uyb, (int)zblk
+#define PCAD_WALK (walk_len > 0 && walk_len < L ? walk_len : L)
     // ---- long strands, few of them: G segments per strand as separate workgroups (pass A, carry, pass B) --------------------
     if constexpr (FUSED) {
         int sb = 0;
@@ -401,7 +508,7 @@ static hipError_t launch_scan_t(const void* u, const void* z, int64_t ldz, const
         if (G > 1 && combo) {
             dim3 gseg((unsigned)(E / 64), (unsigned)(S * G));
 #define PCAD_SEG(REV, ACC, HZ, SEGM, ZP)                                                                                  \
-            hipLaunchKernelGGL((scan_kernel<T, REV, ACC, HZ, FUSED, PRE, BLK8, SEGM>), gseg, block, 0, s, PCAD_SCAN_ARGS(ZP), G, sb, seg_ws)
+            hipLaunchKernelGGL((scan_kernel<T, REV, ACC, HZ, FUSED, PRE, BLK8, SEGM, ZB && HZ, AIOK>), gseg, block, 0, s, PCAD_SCAN_ARGS(ZP), G, sb, seg_ws, L)
             if (reverse) PCAD_SEG(true, 0, false, 1, nullptr); else PCAD_SEG(false, 0, false, 1, nullptr);
             hipLaunchKernelGGL(scan_carry_kernel, dim3((unsigned)(((int64_t)S * E + 255) / 256)), dim3(256), 0, s, seg_ws, A2, a_scale, S, G, E);
             if (!reverse) { if (hz) PCAD_SEG(false, 0, true, 2, z); else PCAD_SEG(false, 0, false, 2, nullptr); }
@@ -412,7 +519,7 @@ static hipError_t launch_scan_t(const void* u, const void* z, int64_t ldz, const
         }
     }
 #define PCAD_SCAN(REV, ACC, HZ)                                                                                    \
-    hipLaunchKernelGGL((scan_kernel<T, REV, ACC, HZ, FUSED, PRE, BLK8>), grid, block, 0, s, PCAD_SCAN_ARGS(z), 1, 0, (float*)nullptr)
+    hipLaunchKernelGGL((scan_kernel<T, REV, ACC, HZ, FUSED, PRE, BLK8, 0, ZB && HZ, AIOK>), grid, block, 0, s, PCAD_SCAN_ARGS(z), 1, 0, (float*)nullptr, PCAD_WALK)
     if (accumulate == 2) {                    // (y_prev + y) * silu(z): the bi-directional sum gated once
         if (!hz) return hipErrorInvalidValue;
         if (reverse) PCAD_SCAN(true, 2, true); else PCAD_SCAN(false, 2, true);
@@ -422,6 +529,7 @@ static hipError_t launch_scan_t(const void* u, const void* z, int64_t ldz, const
     else if (reverse && !accumulate) { if (hz) PCAD_SCAN(true, 0, true); else PCAD_SCAN(true, 0, false); }
     else { if (hz) PCAD_SCAN(true, 1, true); else PCAD_SCAN(true, 1, false); }
 #undef PCAD_SCAN
+#undef PCAD_WALK
 #undef PCAD_SCAN_ARGS
     return hipGetLastError();
 }
@@ -429,7 +537,7 @@ static hipError_t launch_scan_t(const void* u, const void* z, int64_t ldz, const
 hipError_t launch_scan(const void* u, const void* z, int64_t ldz, const void* delta, const void* dt_low, int64_t lddt,
                        const void* Wdt, int Rp, const float* bc, const float* A2, float a_scale, const float* Dskip,
                        const float* dbias, void* y, int S, int L, int E, bool reverse, int accumulate, int dt,
-                       hipStream_t s, bool uyb, bool zblk, float* seg_ws) {
+                       hipStream_t s, bool uyb, bool zblk, float* seg_ws, int walk_len) {
     if (zblk && !uyb) return hipErrorInvalidValue;
     if (S <= 0 || L <= 0) return hipSuccess;
     if (E % 64) return hipErrorInvalidValue;
@@ -439,15 +547,17 @@ hipError_t launch_scan(const void* u, const void* z, int64_t ldz, const void* de
     const bool fused = delta == nullptr;
     if (fused && (!dt_low || !Wdt || Rp <= 0 || Rp % 64)) return hipErrorInvalidValue;
     if (dt == BF16) {
+        if (fused && Rp == 64 && lddt % 8 == 0 && uyb && L % 8 == 0 && zblk)      // the engine's case: every layout known at compile time
+            return launch_scan_t<bf16_t, true, true, true, true>(u, z, ldz, dt_low, lddt, Wdt, Rp, bc, A2, a_scale, Dskip, dbias, y, S, L, E, reverse, accumulate, s, uyb, zblk, seg_ws, walk_len);
         if (fused && Rp == 64 && lddt % 8 == 0 && uyb && L % 8 == 0)
-            return launch_scan_t<bf16_t, true, true, true>(u, z, ldz, dt_low, lddt, Wdt, Rp, bc, A2, a_scale, Dskip, dbias, y, S, L, E, reverse, accumulate, s, uyb, zblk, seg_ws);
+            return launch_scan_t<bf16_t, true, true, true>(u, z, ldz, dt_low, lddt, Wdt, Rp, bc, A2, a_scale, Dskip, dbias, y, S, L, E, reverse, accumulate, s, uyb, zblk, seg_ws, walk_len);
         if (fused && Rp == 64 && lddt % 8 == 0)
-            return launch_scan_t<bf16_t, true, true>(u, z, ldz, dt_low, lddt, Wdt, Rp, bc, A2, a_scale, Dskip, dbias, y, S, L, E, reverse, accumulate, s, uyb, zblk, seg_ws);
-        if (fused) return launch_scan_t<bf16_t, true>(u, z, ldz, dt_low, lddt, Wdt, Rp, bc, A2, a_scale, Dskip, dbias, y, S, L, E, reverse, accumulate, s, uyb, zblk, seg_ws);
-        return launch_scan_t<bf16_t, false>(u, z, ldz, delta, E, nullptr, 0, bc, A2, a_scale, Dskip, dbias, y, S, L, E, reverse, accumulate, s, uyb, zblk, seg_ws);
+            return launch_scan_t<bf16_t, true, true>(u, z, ldz, dt_low, lddt, Wdt, Rp, bc, A2, a_scale, Dskip, dbias, y, S, L, E, reverse, accumulate, s, uyb, zblk, seg_ws, walk_len);
+        if (fused) return launch_scan_t<bf16_t, true>(u, z, ldz, dt_low, lddt, Wdt, Rp, bc, A2, a_scale, Dskip, dbias, y, S, L, E, reverse, accumulate, s, uyb, zblk, seg_ws, walk_len);
+        return launch_scan_t<bf16_t, false>(u, z, ldz, delta, E, nullptr, 0, bc, A2, a_scale, Dskip, dbias, y, S, L, E, reverse, accumulate, s, uyb, zblk, seg_ws, walk_len);
     }
-    if (fused) return launch_scan_t<float, true>(u, z, ldz, dt_low, lddt, Wdt, Rp, bc, A2, a_scale, Dskip, dbias, y, S, L, E, reverse, accumulate, s, uyb, zblk, seg_ws);
-    return launch_scan_t<float, false>(u, z, ldz, delta, E, nullptr, 0, bc, A2, a_scale, Dskip, dbias, y, S, L, E, reverse, accumulate, s, uyb, zblk, seg_ws);
+    if (fused) return launch_scan_t<float, true>(u, z, ldz, dt_low, lddt, Wdt, Rp, bc, A2, a_scale, Dskip, dbias, y, S, L, E, reverse, accumulate, s, uyb, zblk, seg_ws, walk_len);
+    return launch_scan_t<float, false>(u, z, ldz, delta, E, nullptr, 0, bc, A2, a_scale, Dskip, dbias, y, S, L, E, reverse, accumulate, s, uyb, zblk, seg_ws, walk_len);
 }
 
 }  // namespace pcad

@@ -21,7 +21,7 @@ import numpy as np
 import torch
 
 from . import sharding
-from .zero_shot import effective_batch, local_ids
+from .zero_shot import _window_len, check_model_inputs, effective_batch, iter_device_batches, local_ids
 
 
 def load_data(filepath):
@@ -31,22 +31,19 @@ def load_data(filepath):
     return data["sequences"].tolist(), data["label"].tolist()
 
 
-def extract_embeddings(model, sequences, device, tokenIdx: int, tokenizer=None, batch_size: int = 128) -> np.ndarray:
+def extract_embeddings(model, sequences, device, tokenIdx: int, tokenizer=None, batch_size: int = 128,
+                       batch_explicit: bool = False) -> np.ndarray:
     logging.info("Extracting embeddings")
     n_total = len(sequences)
     rank, ws = sharding.world()
-    start, stop, per = sharding.shard_bounds(n_total, rank, ws)
-    ids_local = local_ids(sequences, start, stop, tokenizer, None)            # only this rank's block is tokenised
-    if ws > 1:
-        ids_local = sharding.pad_rows(ids_local, per)
+    start, stop, per = sharding.shard_bounds(n_total, rank, ws)            # only this rank's block is tokenised
     fast = bool(getattr(model, "supports_positions", False))
-    if fast and ids_local.shape[0]:
-        batch_size = effective_batch(model, batch_size, ids_local.shape[1])
+    if fast and n_total:
+        batch_size = effective_batch(model, batch_size, _window_len(sequences), batch_explicit)
     model.eval()
     outs = []
     with torch.inference_mode():
-        for b0 in range(0, ids_local.shape[0], batch_size):
-            cur = ids_local[b0:b0 + batch_size].to(device, non_blocking=True)
+        for cur in iter_device_batches(sequences, start, stop, per if ws > 1 else 0, batch_size, tokenizer, None, device):
             if fast:
                 e = model(input_ids=cur, output_hidden_states=True, positions=[tokenIdx]).hidden_states[-1][:, 0, :]
             else:
@@ -60,7 +57,9 @@ def extract_embeddings(model, sequences, device, tokenIdx: int, tokenizer=None, 
             d = getattr(getattr(model, "config", None), "d_model", 0)
             emb = torch.empty((0, d), dtype=torch.float32, device=device)
         emb = sharding.all_gather_rows(emb, n_total)
-    return emb.cpu().numpy()
+    out = emb.cpu().numpy()
+    check_model_inputs(model)
+    return out
 
 
 def save_embedding_cache(path: str, **arrays):

@@ -41,6 +41,8 @@ class PcadTensor(C.Structure):
 SIGNATURES = {
     "pcad_version": (C.c_int, []),
     "pcad_last_error": (C.c_char_p, []),
+    "pcad_build_hash": (C.c_char_p, []),
+    "pcad_set_status_buffer": (C.c_int, [C.c_void_p, C.c_void_p]),
     "pcad_create": (C.c_int, [C.POINTER(PcadConfig), C.POINTER(C.c_void_p)]),
     "pcad_destroy": (None, [C.c_void_p]),
     "pcad_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int64]),
@@ -73,6 +75,17 @@ SIGNATURES = {
 
 _lib = None
 
+STATUS_BAD_TOKEN, STATUS_BAD_POSITION = 1, 2       # include/pcad.h pcad_status_bits
+
+
+def source_hash() -> str:
+    """sha1 over csrc/*.hip, *.hpp (csrc/source_hash.py: the value the Makefile bakes into libpcad.so as pcad_build_hash)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("_pcad_source_hash", os.path.join(CSRC, "source_hash.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod.source_hash(CSRC)
+
 
 def build_library(force: bool = False) -> str:
     """Compile the HIP sources in-tree (`hipcc --offload-arch=gfx950`, cross-compiles without a GPU)."""
@@ -99,6 +112,13 @@ def load_library():
         fn = getattr(lib, name)   # AttributeError if the symbol is missing
         fn.restype = res
         fn.argtypes = args
+    # a binary that was not built from the sources beside it would silently run (and be benchmarked as) other kernels
+    if os.path.exists(os.path.join(CSRC, "source_hash.py")) and os.environ.get("PCAD_ALLOW_STALE") != "1":
+        built, have = lib.pcad_build_hash().decode(), source_hash()
+        if built != have:
+            raise RuntimeError(
+                f"{LIB_PATH} was built from other kernel sources (pcad_build_hash {built}, sources {have}): rebuild it with "
+                "`make -C plantcaduceus_amd/csrc` / `__graft_entry__.build()` (PCAD_ALLOW_STALE=1 overrides, for A/B of old builds)")
     _lib = lib
     return lib
 
@@ -145,6 +165,12 @@ class Engine:
             nbytes = self.lib.pcad_weight_arena_bytes(self._h)
             self._arena = torch.empty(nbytes + 256, dtype=torch.uint8, device=self.device)
             self._bind(state_dict)
+            # input-validation flags: a device word the kernels OR bits into + a pinned host mirror filled by an async copy
+            self._status = torch.zeros(1, dtype=torch.int32, device=self.device)
+            self._status_host = torch.zeros(1, dtype=torch.int32).pin_memory()
+            self._status_event = torch.cuda.Event()
+            self._status_event.record()
+            _check(self.lib.pcad_set_status_buffer(self._h, self._status.data_ptr()), "pcad_set_status_buffer")
 
     def _aligned(self, t: torch.Tensor) -> int:
         return (t.data_ptr() + 255) // 256 * 256
@@ -184,18 +210,20 @@ class Engine:
                 want_hidden: bool = False, want_logits: bool = True, all_hidden: bool = False):
         """ids [B, L] (any int dtype, on this device) -> (logits fp32 [B,Q,8] | None, hidden [B,Q,2D] | None[, all]).
         positions: None (all L), a short list shared by every window, or an integer tensor [B] on this device
-        (one position per window, Q = 1)."""
+        (one position per window, Q = 1).
+
+        Nothing here synchronises with the device.  Token ids outside the vocabulary and per-window positions outside the
+        window - for which the reference raises an index error - are detected by the forward's last kernel and reported
+        asynchronously: `check_status()` (which the host loops of this package call where they read results back) raises
+        IndexError, and so does the next `forward` call once the flag of an earlier one has arrived."""
         _require_gpu(input_ids, "input_ids")
         if input_ids.dim() != 2:
             raise ValueError(f"input_ids must be [B, L], got {tuple(input_ids.shape)}")
         if input_ids.device != self.device:
             raise RuntimeError(f"input_ids on {input_ids.device}, engine on {self.device}")
+        self._poll_status()
         ids = input_ids.to(torch.int32).contiguous()
         B, L = ids.shape
-        V = int(self.config.padded_vocab_size)
-        if B and bool(((ids < 0) | (ids >= V)).any()):
-            # the reference's nn.Embedding raises an index error; the kernels would alias the id to another row (ids & 7)
-            raise IndexError(f"input_ids contain token ids outside [0, {V}): check the tokenizer's vocabulary against the model")
         D = self.config.d_model
         per_seq = None
         if torch.is_tensor(positions):
@@ -213,24 +241,55 @@ class Engine:
             ws, ws_bytes = self._workspace(B, L)
             lp = logits.data_ptr() if logits is not None else None
             hp = hidden.data_ptr() if hidden is not None else None
-            if all_hidden:
-                if positions is not None or per_seq is not None:
-                    raise ValueError("all_hidden requires positions=None")
-                allh = torch.empty((self.config.n_layer, B, L, 2 * D), dtype=self.dtype, device=self.device)
-                _check(self.lib.pcad_forward_all_hidden(self._h, ids.data_ptr(), B, L, allh.data_ptr(), hp, lp, ws,
-                                                        ws_bytes, _stream_ptr()), "pcad_forward_all_hidden")
-                return logits, hidden, allh
-            if per_seq is not None:
-                _check(self.lib.pcad_forward_at(self._h, ids.data_ptr(), B, L, per_seq.data_ptr(), hp, lp, ws, ws_bytes,
-                                                _stream_ptr()), "pcad_forward_at")
-                return logits, hidden
-            pos_arr = (C.c_int32 * P)(*[int(p) for p in positions]) if P else None
-            _check(self.lib.pcad_forward(self._h, ids.data_ptr(), B, L, pos_arr, P, hp, lp, ws, ws_bytes,
-                                         _stream_ptr()), "pcad_forward")
+            try:
+                if all_hidden:
+                    if positions is not None or per_seq is not None:
+                        raise ValueError("all_hidden requires positions=None")
+                    allh = torch.empty((self.config.n_layer, B, L, 2 * D), dtype=self.dtype, device=self.device)
+                    _check(self.lib.pcad_forward_all_hidden(self._h, ids.data_ptr(), B, L, allh.data_ptr(), hp, lp, ws,
+                                                            ws_bytes, _stream_ptr()), "pcad_forward_all_hidden")
+                    return logits, hidden, allh
+                if per_seq is not None:
+                    _check(self.lib.pcad_forward_at(self._h, ids.data_ptr(), B, L, per_seq.data_ptr(), hp, lp, ws, ws_bytes,
+                                                    _stream_ptr()), "pcad_forward_at")
+                    return logits, hidden
+                pos_arr = (C.c_int32 * P)(*[int(p) for p in positions]) if P else None
+                _check(self.lib.pcad_forward(self._h, ids.data_ptr(), B, L, pos_arr, P, hp, lp, ws, ws_bytes,
+                                             _stream_ptr()), "pcad_forward")
+            finally:
+                # the status word follows the forward on the stream into pinned host memory; nobody waits for it here
+                self._status_host.copy_(self._status, non_blocking=True)
+                self._status_event.record()
         return logits, hidden
 
+    # -- asynchronous input validation (include/pcad.h pcad_set_status_buffer) ----------------------------------------
+    def _raise_status(self, bits: int):
+        self._status.zero_()
+        self._status_host.zero_()
+        V = int(self.config.padded_vocab_size)
+        what = []
+        if bits & STATUS_BAD_TOKEN:
+            what.append(f"input_ids contain token ids outside [0, {V}): check the tokenizer's vocabulary against the model")
+        if bits & STATUS_BAD_POSITION:
+            what.append("a per-window position is outside [0, L)")
+        raise IndexError("; ".join(what) + " (detected on the device; results of that forward are invalid)")
+
+    def _poll_status(self):
+        """Non-blocking: raises if the status word of an EARLIER forward has already arrived and is set."""
+        if self._status_event.query() and int(self._status_host[0]) != 0:
+            self._raise_status(int(self._status_host[0]))
+
+    def check_status(self):
+        """Blocking: waits for the forwards enqueued so far and raises IndexError if any of them saw an invalid token id or
+        position (the reference's nn.Embedding / indexing errors).  Host loops call this where they read results back."""
+        self._status_event.synchronize()
+        bits = int(self._status_host[0])
+        if bits:
+            self._raise_status(bits)
+
     def set_option(self, key: str, value: int):
-        """`pcad_set_option`: "chunk_seqs" (windows per pass through the stack), "gate_each" (reference-order SiLU gate)."""
+        """`pcad_set_option` (include/pcad.h): "chunk_seqs" (windows per pass through the stack), "gate_each" (reference-order
+        SiLU gate), "scan_segments" (segmented scan of long strands), "last_layer_shortcut", "poison_workspace" (debug)."""
         _check(self.lib.pcad_set_option(self._h, key.encode(), int(value)), "pcad_set_option")
         self._ws = None
 

@@ -99,15 +99,19 @@ class _LMHead(nn.Module):
         self.lm_head = _Weight(cfg.padded_vocab_size, cfg.d_model)
 
 
-class LastHiddenOnly(tuple):
+class LastHiddenOnly:
     """`hidden_states` when only the last level was materialised (the default: the reference's callers read `[-1]` only and
-    all n_layer+1 levels at B=1024 / l32 are 71 GB).  Behaves like the HF tuple for what exists — `len()` is n_layer + 1,
-    `[-1]` / `[n_layer]` is the final hidden state — and raises, loudly, for any level that was not kept."""
+    all n_layer+1 levels at B=1024 / l32 are 71 GB).  A plain sequence-like object (NOT a tuple subclass: helpers that rebuild
+    containers with `type(obj)(generator)` — accelerate's `honor_type`, copy, pickle — must not mistake it for a tuple of
+    n_layer + 1 tensors): `len()` is n_layer + 1, `[-1]` / `[n_layer]` is the final hidden state, and any level that was not kept
+    raises, loudly.  Not supported: iteration, slicing, `torch.stack(hidden_states)`, accelerate device_map hooks that walk
+    outputs — set `config.materialize_all_hidden_states = True` to get the real tuple for those."""
 
-    def __new__(cls, last, n_levels: int):
-        self = super().__new__(cls, (last,))
+    __slots__ = ("last", "_n")
+
+    def __init__(self, last, n_levels: int):
+        self.last = last
         self._n = int(n_levels)
-        return self
 
     def __len__(self):
         return self._n
@@ -117,7 +121,7 @@ class LastHiddenOnly(tuple):
             raise IndexError("only hidden_states[-1] is materialised; set config.materialize_all_hidden_states = True for slices")
         j = i + self._n if i < 0 else i
         if j == self._n - 1:
-            return tuple.__getitem__(self, 0)
+            return self.last
         if 0 <= j < self._n:
             raise IndexError(f"hidden_states[{i}] was not materialised (only [-1] is, by default); set "
                              "config.materialize_all_hidden_states = True to get all n_layer + 1 levels")
@@ -125,6 +129,15 @@ class LastHiddenOnly(tuple):
 
     def __iter__(self):
         raise TypeError("only hidden_states[-1] is materialised; set config.materialize_all_hidden_states = True to iterate")
+
+    def __reduce__(self):
+        return (LastHiddenOnly, (self.last, self._n))
+
+    def to(self, *args, **kwargs):
+        return LastHiddenOnly(self.last.to(*args, **kwargs), self._n)
+
+    def __repr__(self):
+        return f"LastHiddenOnly(levels={self._n}, last={tuple(self.last.shape)})"
 
 
 # ---- HF models --------------------------------------------------------------------------------------
@@ -186,13 +199,32 @@ class CaduceusPreTrainedModel(PreTrainedModel):
         return model
 
     def preferred_batch_size(self, seqlen: int) -> int:
-        """Windows per forward call the host loops batch up to: 2 x 2^31 / (d_inner * elem) token-rows (1024 windows of 512 bp
-        at l32 bf16 = two 512-window chunks of the layer-stack walk, the benchmark's batch; see csrc/api.hip).  Results do
-        not depend on the batch size (windows are independent), so host loops may batch up to this regardless of the
-        `-batchSize` they were given."""
+        """Windows per forward call the host loops batch up to when the user gave no `-batchSize`: two chunks of 2^31 bytes per
+        [rows, d_inner] tensor (1024 windows of 512 bp at l32 bf16 = the benchmark's batch, two 512-window chunks of the
+        layer-stack walk sharing one 15.3 GB workspace; see csrc/api.hip — the engine's own cap per chunk is (2^32 - 2 MiB) bytes,
+        and it splits a batch evenly into the fewest chunks, so this batch never runs as ONE chunk of twice the workspace),
+        clamped to what fits in a third of the device's free memory (~30 MB of workspace per window at l32 bf16)."""
         p = self._backbone_owner().caduceus_param()
+        L = max(1, int(seqlen))
         rows = (1 << 31) // (self.config.d_inner * p.element_size())
-        return max(1, 2 * (rows // (2 * max(1, int(seqlen)))))
+        want = max(1, 2 * (rows // (2 * L)))
+        cap_rows = (((1 << 32) - (2 << 20)) // (self.config.d_inner * p.element_size())) & ~7
+        if want <= cap_rows // (2 * L):                      # would fit ONE chunk (narrow models): keep it at two chunks' worth of rows
+            want = max(1, min(want, cap_rows // (2 * L)))
+        if p.device.type == "cuda":
+            try:
+                free, _ = torch.cuda.mem_get_info(p.device)
+                per_window = 2 * L * (self.config.d_inner * 6 + self.config.d_model * 4) * p.element_size() * 1.25
+                want = max(1, min(want, int(free / 3 / per_window) * 2))
+            except Exception:
+                pass
+        return want
+
+    def check_status(self):
+        """Deferred input validation of the engine (token ids / positions outside their range raise IndexError here)."""
+        eng = getattr(self._backbone_owner(), "_pcad_engine", None)
+        if eng is not None:
+            eng.check_status()
 
     # -- engine plumbing ----------------------------------------------------------------------------
     def _backbone_owner(self):

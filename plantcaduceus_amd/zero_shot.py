@@ -51,11 +51,16 @@ def parse_args(argv: Optional[Sequence[str]] = None):
                         help="Output in BED format instead of tab-separated file, only works with -input-table")
     parser.add_argument("-model", dest="model", default=None, help="The directory of pre-trained model")
     parser.add_argument("-device", dest="device", default="cuda:0", help="The device to run the model")
-    parser.add_argument("-batchSize", dest="batchSize", default=128, type=int, help="The batch size for the model")
+    parser.add_argument("-batchSize", dest="batchSize", default=None, type=int,
+                        help="The batch size for the model (default 128 as in the reference, raised to the engine's preferred "
+                             "batch; a value given here is used as is, e.g. to bound the workspace on a shared GPU)")
     parser.add_argument("-numWorkers", dest="numWorkers", default=4, type=int,
                         help="Accepted for compatibility (the reference parses but never uses it)")
     parser.add_argument("-tokenIdx", dest="tokenIdx", default=255, type=int, help="The index of the nucleotide to mask")
     args = parser.parse_args(argv)
+    args.batchExplicit = args.batchSize is not None
+    if args.batchSize is None:
+        args.batchSize = 128
     if args.inputVCF is not None and args.inputFasta is None:
         sys.exit("-input-fasta is required with -input-vcf")
     return args
@@ -134,9 +139,12 @@ def _has_vocab(model_dir: str) -> bool:
     return os.path.exists(os.path.join(model_dir, "vocab.json"))
 
 
-def effective_batch(model, batch_size: int, seqlen: int) -> int:
-    """`-batchSize` is a lower bound here: windows are independent, so when the model advertises a larger preferred batch
-    (the HIP engine: two full chunks, 1024 windows at l32) the host loop uses it — fewer, larger launches, same results."""
+def effective_batch(model, batch_size: int, seqlen: int, explicit: bool = False) -> int:
+    """Windows per forward call.  `-batchSize` is how the reference's user bounds memory, so a value the user PASSED is kept;
+    the default (128, src/zero_shot_score.py:28) is raised to what the model advertises (`preferred_batch_size`: the HIP engine's
+    two full chunks, 1024 windows at l32) — windows are independent, so only launch count and workspace size depend on it."""
+    if explicit:
+        return int(batch_size)
     pref = getattr(model, "preferred_batch_size", None)
     if callable(pref):
         try:
@@ -146,8 +154,49 @@ def effective_batch(model, batch_size: int, seqlen: int) -> int:
     return int(batch_size)
 
 
+def iter_device_batches(sequences, start: int, stop: int, pad_to: int, batch_size: int, tokenizer, tokenIdx: Optional[int],
+                        device):
+    """Rows [start, stop) of the window list (+ dummy rows up to `pad_to`, repeating the last row, for equal work per rank) as
+    integer tensors [b, L] on `device`, `batch_size` rows at a time.  Batch k + 1 is tokenised (and masked) on a worker
+    thread into pinned host memory while the caller enqueues batch k, and its host-to-device copy is asynchronous — with a
+    forward that never synchronises (engine.Engine.forward) the tokeniser, the PCIe copy and the GPU overlap."""
+    from concurrent.futures import ThreadPoolExecutor
+    n_real = max(0, stop - start)
+    n_rows = max(n_real, pad_to)
+    if n_rows == 0:
+        return
+    on_gpu = str(device).startswith("cuda")
+
+    def prepare(b0: int) -> torch.Tensor:
+        b1 = min(b0 + batch_size, n_rows)
+        r0, r1 = min(b0, n_real), min(b1, n_real)
+        blk = local_ids(sequences, start + r0, start + r1, tokenizer, tokenIdx) if r1 > r0 else None
+        if b1 > r1:                                              # dummy rows past this rank's block
+            last = blk[-1:] if blk is not None else (local_ids(sequences, start + n_real - 1, start + n_real, tokenizer, tokenIdx)
+                                                     if n_real else torch.zeros((1, len(sequences[0]) if len(sequences) else 0), dtype=torch.int32))
+            pad = last.expand(b1 - max(b0, r1), *last.shape[1:])
+            blk = torch.cat([blk, pad], dim=0) if blk is not None else pad.clone()
+        return blk.pin_memory() if on_gpu else blk
+
+    with ThreadPoolExecutor(max_workers=1) as pool:
+        nxt = pool.submit(prepare, 0)
+        for b0 in range(0, n_rows, batch_size):
+            cur = nxt.result()
+            if b0 + batch_size < n_rows:
+                nxt = pool.submit(prepare, b0 + batch_size)
+            yield cur.to(device, non_blocking=True)
+
+
+def check_model_inputs(model):
+    """Raise the engine's deferred IndexError (token id / position out of range, detected on the device) where results are read."""
+    chk = getattr(model, "check_status", None)
+    if callable(chk):
+        chk()
+
+
 # ---- a3: batched forward -> [N, 4] probabilities ------------------------------------------------------
-def extract_logits(model, sequences, device, tokenIdx: int, tokenizer, batch_size: int = 128) -> np.ndarray:
+def extract_logits(model, sequences, device, tokenIdx: int, tokenizer, batch_size: int = 128,
+                   batch_explicit: bool = False) -> np.ndarray:
     """sequences: list of equal-length strings, or a pre-tokenised+masked integer array [N, L].
     Returns softmax over the (a,c,g,t) logits at tokenIdx, fp32 [N, 4], rows in input order (all ranks)."""
     logging.info("Extracting logits")
@@ -155,17 +204,13 @@ def extract_logits(model, sequences, device, tokenIdx: int, tokenizer, batch_siz
     vocab = tokenizer.get_vocab()
     cols = [vocab[nc] for nc in "acgt"]
     rank, ws = sharding.world()
-    start, stop, per = sharding.shard_bounds(n_total, rank, ws)
-    ids_local = local_ids(sequences, start, stop, tokenizer, tokenIdx)        # only this rank's block is tokenised
-    if ws > 1:
-        ids_local = sharding.pad_rows(ids_local, per)
+    start, stop, per = sharding.shard_bounds(n_total, rank, ws)            # only this rank's block is tokenised
     fast = bool(getattr(model, "supports_positions", False))
-    if fast and ids_local.shape[0]:
-        batch_size = effective_batch(model, batch_size, ids_local.shape[1])
+    if fast and n_total:
+        batch_size = effective_batch(model, batch_size, _window_len(sequences), batch_explicit)
     outs = []
     with torch.inference_mode():
-        for b0 in range(0, ids_local.shape[0], batch_size):
-            cur = ids_local[b0:b0 + batch_size].to(device, non_blocking=True)
+        for cur in iter_device_batches(sequences, start, stop, per if ws > 1 else 0, batch_size, tokenizer, tokenIdx, device):
             if fast:
                 lg = model(input_ids=cur, positions=[tokenIdx]).logits[:, 0, :]
             else:
@@ -176,7 +221,15 @@ def extract_logits(model, sequences, device, tokenIdx: int, tokenizer, batch_siz
         else:
             probs = torch.empty((0, 4), dtype=torch.float32, device=device)
         probs = sharding.all_gather_rows(probs, n_total)
-    return probs.cpu().numpy()
+    out = probs.cpu().numpy()
+    check_model_inputs(model)
+    return out
+
+
+def _window_len(sequences) -> int:
+    if isinstance(sequences, (np.ndarray, torch.Tensor)):
+        return int(sequences.shape[1]) if sequences.ndim == 2 else 0
+    return len(sequences[0]) if len(sequences) else 0
 
 
 # ---- a15: scores ------------------------------------------------------------------------------------
@@ -253,15 +306,19 @@ class FastaIndex:
                     length, offset, linebases, linewidth, short_seen = 0, pos + len(raw), 0, 0, False
                 elif name is not None:
                     body = raw.rstrip(b"\r\n")
-                    if body or raw:
-                        if linebases == 0 and body:
-                            linebases, linewidth = len(body), len(raw)
-                        elif body:
-                            if short_seen or len(body) > linebases:
-                                raise ValueError(f"{path}: sequence {name} has lines of unequal length; cannot index")
-                            if len(body) < linebases:
-                                short_seen = True        # only the last line of a record may be short
-                        length += len(body)
+                    if not body:
+                        # a blank line occupies bytes that the uniform-line-width arithmetic of fetch() does not know about: it is
+                        # only harmless at the very end of a record (samtools faidx rejects it elsewhere), so any later base raises
+                        short_seen = True
+                    elif linebases == 0 and not short_seen:
+                        linebases, linewidth = len(body), len(raw)
+                    else:
+                        if short_seen or len(body) > linebases:
+                            raise ValueError(f"{path}: sequence {name} has lines of unequal length (or a blank line inside "
+                                             "the record); cannot index")
+                        if len(body) < linebases:
+                            short_seen = True        # only the last line of a record may be short
+                    length += len(body)
                 pos += len(raw)
         if name is not None:
             idx[name] = (length, offset, linebases, linewidth)
@@ -415,7 +472,7 @@ def main(argv: Optional[Sequence[str]] = None):
     else:
         sequences, recordIndices, inverse = windows_from_vcf(args)        # one forward per distinct (chrom, pos)
     model, tokenizer = load_model_and_tokenizer(args.model, args.device)
-    logits = extract_logits(model, sequences, args.device, args.tokenIdx, tokenizer, args.batchSize)
+    logits = extract_logits(model, sequences, args.device, args.tokenIdx, tokenizer, args.batchSize, args.batchExplicit)
     if args.inputDF is None:
         logits = logits[np.asarray(inverse, dtype=np.int64)] if len(inverse) else logits[:0]      # fan back out per record
     rank, _ = sharding.world()

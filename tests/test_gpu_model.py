@@ -148,16 +148,42 @@ def test_poisoned_workspace_gives_identical_results(dtype, D, L, B):
 
 
 def test_out_of_vocabulary_ids_raise():
-    """the reference's nn.Embedding raises on an id outside the table; the engine must not alias it to another row."""
+    """the reference's nn.Embedding raises on an id outside the table; the engine must not alias it to another row silently.
+    Detection is on the device (no host synchronisation inside forward): `check_status()` — what the host loops call where
+    they read results back — raises, and so does a later forward once the flag has arrived; a clean batch afterwards is fine."""
     cfg = make_config("x", d_model=64, n_layer=1)
     m = build(cfg, synthetic_state_dict(cfg, seed=2), torch.float32)
     ids = rand_ids(2, 16, 0)
-    m(input_ids=ids.to(DEV))
+    good = m(input_ids=ids.to(DEV)).logits.clone()
+    m.check_status()
     for bad in (8, -1, 1000):
         ids2 = ids.clone()
         ids2[1, 3] = bad
+        m(input_ids=ids2.to(DEV), positions=[3])
         with pytest.raises(IndexError, match="outside"):
-            m(input_ids=ids2.to(DEV))
+            m.check_status()
+        m(input_ids=ids2.to(DEV))
+        torch.cuda.synchronize()
+        with pytest.raises(IndexError, match="outside"):         # the next forward reports the earlier one's flag
+            m(input_ids=ids.to(DEV))
+        assert torch.equal(m(input_ids=ids.to(DEV)).logits, good)
+        m.check_status()
+    # per-window positions (pcad_forward_at) outside the window: flagged instead of silently clamped
+    eng = m._engine()
+    for bad in (16, -1):
+        pos = torch.tensor([3, bad], dtype=torch.int32, device=DEV)
+        eng.forward(ids.to(DEV), positions=pos)
+        with pytest.raises(IndexError, match="position"):
+            eng.check_status()
+    eng.forward(ids.to(DEV), positions=torch.tensor([3, 15], dtype=torch.int32, device=DEV))
+    eng.check_status()
+    # the host loop surfaces it too
+    from plantcaduceus_amd import zero_shot
+    from plantcaduceus_amd.tokenization_caduceus import CaduceusTokenizer
+    arr = ids.numpy().astype("int32").copy()
+    arr[0, 5] = 9
+    with pytest.raises(IndexError, match="outside"):
+        zero_shot.extract_logits(m, arr, DEV, 7, CaduceusTokenizer())
 
 
 def test_long_window_8192():
@@ -243,3 +269,27 @@ def test_repeated_forward_is_bit_identical():
             ref = cur
         else:
             assert torch.equal(cur[0], ref[0]) and torch.equal(cur[1], ref[1])
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("D,nl,B,L,pos", [(128, 2, 5, 64, [31]), (128, 3, 3, 45, [0]), (128, 2, 3, 45, [44, 7]),
+                                          (256, 2, 4, 512, [255]), (256, 1, 2, 512, [3, 200, 511]), (256, 2, 3, 203, [101])])
+def test_last_layer_shortcut_bit_identical(dtype, D, nl, B, L, pos):
+    """SURVEY.md §7 step 6 (the reference's callers read one position: src/zero_shot_score.py:117, src/train_XGBoost.py:105):
+    with a list of evaluated positions the last layer's scans stop at the furthest one and out_proj runs on the gathered rows
+    only.  Must equal the full last layer (option off) and the slice of the all-positions forward, bit for bit."""
+    cfg = make_config("x", d_model=D, n_layer=nl)
+    sd = synthetic_state_dict(cfg, seed=11, stress=True)
+    ids = rand_ids(B, L, 3, mask=pos[0]).to(DEV)
+    m_on = build(cfg, sd, dtype)
+    a = m_on(input_ids=ids, output_hidden_states=True, positions=pos)
+    full = m_on(input_ids=ids, output_hidden_states=True)
+    m_off = build(cfg, sd, dtype, last_layer_shortcut=0)
+    b = m_off(input_ids=ids, output_hidden_states=True, positions=pos)
+    assert torch.equal(a.logits, b.logits) and torch.equal(a.hidden_states[-1], b.hidden_states[-1])
+    assert torch.equal(a.logits, full.logits[:, pos]) and torch.equal(a.hidden_states[-1], full.hidden_states[-1][:, pos])
+    assert torch.isfinite(a.logits).all()
+    # with every workspace byte poisoned first: the shortened walks / gathered rows read nothing they did not write
+    m_p = build(cfg, sd, dtype, poison_workspace=1)
+    c = m_p(input_ids=ids, output_hidden_states=True, positions=pos)
+    assert torch.equal(a.logits, c.logits) and torch.equal(a.hidden_states[-1], c.hidden_states[-1])

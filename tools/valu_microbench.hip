@@ -23,6 +23,18 @@ __global__ __launch_bounds__(256) void k(float* out, long long* cyc, int iters, 
 #pragma unroll
                 for (int j = 0; j < NFMA; ++j) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(f[(i + j) & 7]) : "v"(ca[0]), "v"(cb[0]));
             }
+            if (MODE == 5) asm volatile("v_log_f32 %0, %0" : "+v"(e[i]));
+            if (MODE == 6) asm volatile("v_rcp_f32 %0, %0" : "+v"(e[i]));
+            if (MODE == 7) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(p[i]) : "v"(ca));
+            if (MODE == 8) asm volatile("v_cvt_pk_bf16_f32 %0, %0, %1" : "+v"(f[i]) : "v"(ca[0]));
+            if (MODE == 9) {   // the scan's per-state-pair mix: 2 v_exp_f32 + 2 v_pk_mul_f32 + 2 v_pk_fma_f32
+                asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(p[i]) : "v"(ca));
+                asm volatile("v_exp_f32 %0, %0" : "+v"(e[i]));
+                asm volatile("v_exp_f32 %0, %0" : "+v"(f[i]));
+                asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(p[(i + 1) & 7]) : "v"(ca));
+                asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(p[(i + 2) & 7]) : "v"(ca), "v"(cb));
+                asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(p[(i + 3) & 7]) : "v"(ca), "v"(cb));
+            }
             if (MODE == 4) {
 #pragma unroll
                 for (int j = 0; j < NFMA; ++j) asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(p[(i + j) & 7]) : "v"(ca), "v"(cb));
@@ -54,8 +66,10 @@ void run(const char* name, int waves_per_simd) {
     const double groups = (double)iters * 8;                       // instruction groups per wave
     // wall-clock based: SIMD-cycles (at 2.4 GHz) per group per wave, divided by waves sharing the SIMD
     const double wall_cyc_per_group = ms * 1e-3 * 2.4e9 / groups / waves_per_simd;
-    printf("%-28s waves/SIMD=%d  wall %.3f ms  -> %.2f SIMD-cycles@2.4GHz per group (1 exp%s)   [in-kernel counter: %.1f ticks/group/wave]\n",
-           name, waves_per_simd, ms, wall_cyc_per_group, "", avg / groups);
+    // effective shader clock of the timed launch = s_memtime ticks one wave counted (tick = shader cycle) / wall time
+    printf("%-28s waves/SIMD=%d  wall %.3f ms  -> %.2f SIMD-cycles@2.4GHz per group   [in-kernel counter: %.1f ticks/group/wave, "
+           "%.2f per SIMD; effective clock %.2f GHz]\n",
+           name, waves_per_simd, ms, wall_cyc_per_group, avg / groups, avg / groups / waves_per_simd, avg / (ms * 1e-3) / 1e9);
     hipFree(out); hipFree(cyc);
 }
 
@@ -71,6 +85,11 @@ int main() {
         run<4, 1>("exp + 1 pk_fma", w);
         run<4, 2>("exp + 2 pk_fma", w);
         run<4, 3>("exp + 3 pk_fma", w);
+        run<5, 0>("log only", w);
+        run<6, 0>("rcp only", w);
+        run<7, 0>("pk_mul only", w);
+        run<8, 0>("cvt_pk_bf16 only", w);
+        run<9, 0>("scan pair mix (2 exp + 4 pk)", w);
         printf("\n");
     }
     return 0;
