@@ -58,6 +58,11 @@ def parse():
     ap.add_argument("--chunk-seqs", type=int, default=0, help="pcad_set_option chunk_seqs (0 = engine default)")
     ap.add_argument("--opt", action="append", default=[], metavar="KEY=VALUE", help="extra pcad_set_option, e.g. scan_segments=0")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise the RCCL process group even at world size 1 and run the distributed branch (all_gather_into_tensor, "
+                         "barrier, all_reduce MAX) inside the timed loop: what --gpus 8 executes, on the one GPU at hand")
+    ap.add_argument("--host-seqs", type=int, default=-1,
+                    help="windows for the host-side timings of the `host` object (tokeniser, H2D, writers); 0 = skip, -1 = 100000")
     ap.add_argument("--profile-stride", type=int, default=7,
                     help="HIP events around every N-th launch of each kernel class during the timed region (ODD: the scan class "
                          "alternates forward / reverse launches, which differ by 14 %; an even stride samples one direction only)")
@@ -109,14 +114,55 @@ def algorithmic_work(cfg, rows, esz):
 
 
 def source_hash():
-    """sha1 over the kernel sources: ties a committed PMC profile to the build it was measured on."""
-    h = hashlib.sha1()
-    d = os.path.join(ROOT, "plantcaduceus_amd", "csrc")
-    for fn in sorted(os.listdir(d)):
-        if fn.endswith((".hip", ".hpp")):
-            h.update(fn.encode())
-            h.update(open(os.path.join(d, fn), "rb").read())
-    return h.hexdigest()[:16]
+    """sha1 over the kernel sources: ties a committed PMC profile to the build it was measured on (and, through
+    pcad_build_hash(), the loaded libpcad.so to the sources: engine.load_library refuses a stale binary)."""
+    from plantcaduceus_amd.engine import source_hash as sh
+    return sh()
+
+
+def host_timings(n, L, device, torch, np):
+    """SURVEY.md §8(d) 'host tokenisation excluded and also reported separately' / row f1: the host side of the path at
+    the GPU's pace?  Tokeniser windows/s (vectorised LUT, zero_shot.tokenize_masked), host->device copy of one 1024-window batch
+    from pageable and from pinned memory, TSV and VCF-INFO writer rows/s.  Bounded: a few seconds on one core."""
+    import io
+    import tempfile
+    from plantcaduceus_amd import zero_shot
+    from plantcaduceus_amd.tokenization_caduceus import CaduceusTokenizer
+    rng = np.random.default_rng(7)
+    letters = np.frombuffer(b"ACGT", dtype=np.uint8)
+    seqs = [bytes(letters[rng.integers(0, 4, size=L)]).decode() for _ in range(min(n, 4096))]
+    seqs = (seqs * (n // len(seqs) + 1))[:n]
+    tok = CaduceusTokenizer()
+    t0 = time.perf_counter()
+    ids = zero_shot.tokenize_masked(seqs, tok, L // 2 - 1)
+    t_tok = time.perf_counter() - t0
+    out = {"windows": n, "tokenise_windows_per_s": n / t_tok}
+    blk = torch.from_numpy(np.ascontiguousarray(ids[:1024]))
+    pin = blk.pin_memory()
+    for name, src in (("h2d_pageable_ms_per_1024", blk), ("h2d_pinned_ms_per_1024", pin)):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(20):
+            d = src.to(device, non_blocking=True)
+        torch.cuda.synchronize()
+        out[name] = 1e3 * (time.perf_counter() - t0) / 20
+    # writers: the -input-table TSV (pandas, as the reference does) and the ISM VCF rows (ism._write_rows)
+    import pandas as pd
+    from plantcaduceus_amd import ism
+    m = min(n, 100000)
+    df = pd.DataFrame({"chr": "1", "pos": np.arange(m), "ref": "A", "alt": "C", "sequences": seqs[:m],
+                       "zeroShotScore": rng.standard_normal(m)})
+    with tempfile.TemporaryDirectory() as td:
+        t0 = time.perf_counter()
+        df.to_csv(os.path.join(td, "o.tsv"), sep="\t", index=False)
+        out["tsv_rows_per_s"] = m / (time.perf_counter() - t0)
+    refs = list("ACGT" * (m // 4))
+    sc = rng.standard_normal((len(refs), 4))
+    buf = io.StringIO()
+    t0 = time.perf_counter()
+    rows = ism._write_rows(buf, "1", 0, refs, sc)
+    out["ism_vcf_rows_per_s"] = rows / (time.perf_counter() - t0)
+    return out
 
 
 def main():
@@ -140,8 +186,12 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     device = torch.device(f"cuda:{local_rank}")
     torch.cuda.set_device(device)
-    if world > 1:
+    dist_on = world > 1 or args.force_dist
+    if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group(backend="nccl", device_id=device)
 
     cfg = make_config(args.model)
@@ -172,7 +222,7 @@ def main():
     ids = torch.from_numpy(ids_np).to(device)                         # resident in HBM before the timed region
     pos_dev = torch.from_numpy(pos_np).to(device) if pos_np is not None else None
     width = D if args.workload == "embed" else 4
-    gathered = torch.empty((world * B, width), dtype=torch.float32, device=device) if world > 1 else None
+    gathered = torch.empty((world * B, width), dtype=torch.float32, device=device) if dist_on else None
 
     def step():
         if args.workload == "embed":
@@ -185,14 +235,14 @@ def main():
         else:
             logits, _ = eng.forward(ids, positions=[p], want_logits=True)
             res = torch.softmax(logits[:, 0, 3:7], dim=1)             # a,c,g,t (src/zero_shot_score.py:116-119)
-        if world > 1:
+        if dist_on:
             dist.all_gather_into_tensor(gathered, res.contiguous())
             return gathered
         return res
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if dist_on:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -207,7 +257,8 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     eng.profile(False)
-    if world > 1:
+    eng.check_status()               # deferred input validation of the engine (device-side; raises on invalid ids / positions)
+    if dist_on:
         t = torch.tensor([dt], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -235,6 +286,8 @@ def main():
                                    % (args.model, cfg.d_model, cfg.n_layer, args.dtype, what),
                        "batch_per_gpu": B, "seq_len": L,
                        "parallelism": "dp%d (batch-sharded, all_gather of [B,%d])" % (world, width)},
+            "build_hash": eng.lib.pcad_build_hash().decode(),
+            "distributed_branch_executed": bool(dist_on),
         }
         # ---- whole step against the chip peaks, from SURVEY.md §8(d)'s per-sequence counts ----------------------
         fl_seq, by_seq = per_sequence_work(cfg, L, esz)
@@ -308,8 +361,11 @@ def main():
                     if key:
                         prow = float(pj.get("rows_per_launch", 65536))
                         res["roofline"]["traffic"] = int(pj["classes"][key]["traffic_bytes_per_launch"] * rows / prow)
-                        res["roofline"]["traffic_source"] = ("profiled offline on this build (src_hash %s): %s, measured at %d "
-                                                             "rows per launch, scaled to %d" % (sh, os.path.basename(hit[-1]), prow, rows))
+                        res["roofline"]["traffic_source"] = (
+                            "profiled offline on this build (src_hash %s): %s, measured at %d rows per launch%s"
+                            % (sh, os.path.basename(hit[-1]), prow, "" if prow == rows else ", scaled to %d" % rows))
+                        if "effective_clock_GHz" in pj["classes"][key]:
+                            res["roofline"]["effective_clock_GHz_profiled"] = pj["classes"][key]["effective_clock_GHz"]
                 else:
                     res["roofline"]["traffic_source"] = "no committed PMC profile matches this build (src_hash %s)" % sh
             except Exception:
@@ -355,8 +411,14 @@ def main():
             except Exception as ex:   # the baseline is a reported extra; never lose the bench line over it
                 res["cpu_baseline"] = {"value": None, "unit": "sequences/s", "cores": os.cpu_count(), "kind": "port",
                                        "sample": "failed: %r" % (ex,)}
+        nh = args.host_seqs if world == 1 else 0
+        if nh != 0:
+            try:
+                res["host"] = host_timings(100000 if nh < 0 else nh, L, device, torch, np)
+            except Exception as ex:
+                res["host"] = {"failed": repr(ex)}
         print(json.dumps(res))
-    if world > 1:
+    if dist_on:
         dist.barrier()
         dist.destroy_process_group()
 

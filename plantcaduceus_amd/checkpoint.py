@@ -83,6 +83,20 @@ def synthetic_state_dict(config: CaduceusConfig, seed: int = 1234, stress: bool 
     return sd
 
 
+def harsh_state_dict(config: CaduceusConfig, seed: int = 21, proj_scale: float = 4.0, dt_scale: float = 16.0) -> Dict[str, torch.Tensor]:
+    """The `stress` checkpoint (distinct fwd/rev parameters, perturbed A_log / D / norm weights) with every in_proj and x_proj
+    weight scaled by `proj_scale` and every dt_proj weight by `dt_scale`: activations |x| >> 1 through the whole stack and
+    time steps large enough that ~10 % of the (t, channel) elements take softplus's pass-through branch (delta + bias > 20) —
+    the regime the benign benchmark checkpoint never reaches (tools/argmax_census.py, tests/test_gpu_fulldepth.py)."""
+    sd = synthetic_state_dict(config, seed=seed, stress=True)
+    for k in list(sd):
+        if k.endswith("in_proj.weight") or k.endswith("x_proj.weight"):
+            sd[k] = sd[k] * proj_scale
+        elif k.endswith("dt_proj.weight"):
+            sd[k] = sd[k] * dt_scale
+    return sd
+
+
 def save_checkpoint(path: str, config: CaduceusConfig, sd: Dict[str, torch.Tensor], with_tokenizer: bool = True):
     from safetensors.torch import save_file
     os.makedirs(path, exist_ok=True)

@@ -150,12 +150,7 @@ template <> struct DeltaTile<float> {
 // run as separate workgroups.  SEG = 1, pass A: from a ZERO state, no output - stores the segment's end state and its sum of delta
 // (the product of its decays is exp2(A2 * sum delta));  SEG = 2, pass B: the normal walk of the segment from the true initial state
 // that scan_carry_kernel derived from pass A.  SEG = 0: the whole strand in one workgroup (G = 1).
-// AIO (bf16, BLK8, z blocked or absent — the engine's instantiations): the row loads are `buffer_load_short_d16_hi` into registers
-// whose low half stays zero, so a loaded register IS the fp32 value (no shift per element), the y rows of two steps are converted by
-// one v_cvt_pk_bf16_f32 and stored from the two halves of that register, and the loads are waited for with hand-counted
-// `s_waitcnt vmcnt` (inline asm: hipcc has no pattern for d16_hi buffer accesses).  The kernel is bound by the energy of its VALU
-// stream (profiles/r03_valu_microbench.txt), so every instruction removed per (t, channel) counts.
-template <typename T, bool REV, int ACC, bool HASZ, bool FUSED, bool PRE, bool BLK8, int SEG = 0, bool ZB = false, bool AIO = false>
+template <typename T, bool REV, int ACC, bool HASZ, bool FUSED, bool PRE, bool BLK8, int SEG = 0, bool ZB = false>
 __global__ __launch_bounds__(64, 4) void scan_kernel(const T* __restrict__ u, const T* __restrict__ z, int64_t ldz,
                                                   const T* __restrict__ dsrc, int64_t ldd,
                                                   const T* __restrict__ Wdt, int Rp,
@@ -267,41 +262,7 @@ __global__ __launch_bounds__(64, 4) void scan_kernel(const T* __restrict__ u, co
     };
     const int b_begin = SEG ? seg * seg_blocks : 0;                        // first block (walk space) of this workgroup
     const int s_first = b_begin * TB;
-    // ---- AIO: d16_hi row loads with hand-counted waits ------------------------------------------------------------------------
-    // NL asm loads per step, issued in step order, one chunk (CH steps) per call.  When step i of a chunk is consumed, the asm loads
-    // issued after ITS loads are the rest of its chunk and the whole next chunk (the other register set, loaded before this
-    // chunk's steps run): vmcnt(NL * (CH - 1 - i) + NL * CH).  Stores and compiler-generated loads in between only make the
-    // real count larger, i.e. the wait conservative (VMEM returns in order).
-    constexpr int NL = 1 + (HASZ ? 1 : 0) + (ACC != 0 ? 1 : 0);
-    uint32_t ua[2][CH], za[2][CH], ya[2][CH];
-    u32x4 urs = {0, 0, 0, 0}, zrs = {0, 0, 0, 0}, yrs = {0, 0, 0, 0};
-    if constexpr (AIO) {
-        auto mk = [&](const void* base, uint32_t bytes) {
-            const uint64_t a = (uint64_t)base;
-            return u32x4{(uint32_t)a, (uint32_t)(a >> 32) & 0xffffu, bytes, 0x00020000u};
-        };
-        urs = mk(u, tot_rows * rowE);
-        zrs = mk(HASZ ? z : u, tot_rows * rowE);
-        yrs = mk(y, tot_rows * rowE);
-#pragma unroll
-        for (int k = 0; k < 2; ++k)
-#pragma unroll
-            for (int i = 0; i < CH; ++i) { ua[k][i] = 0u; za[k][i] = 0u; ya[k][i] = 0u; }
-    }
-#define PCAD_LD16HI(reg, rs, so, imm) \
-    asm volatile("buffer_load_short_d16_hi %0, %1, %2, %3 offen offset:%4" : "+v"(reg) : "v"(voff_uy), "s"(rs), "s"(so), "n"(imm))
-    auto aio_load = [&](int s0, uint32_t (&uu)[CH], uint32_t (&zz)[CH], uint32_t (&yy)[CH]) __attribute__((always_inline)) {
-        const uint32_t so = uy_soff(s0, 0);            // BLK8: one scalar offset per chunk, the step's +-128 B in the immediate
-#define PCAD_LD_STEP(i)                                                                  \
-        PCAD_LD16HI(uu[i], urs, so, 128 * (REV ? CH - 1 - (i) : (i)));                   \
-        if constexpr (HASZ) PCAD_LD16HI(zz[i], zrs, so, 128 * (REV ? CH - 1 - (i) : (i))); \
-        if constexpr (ACC != 0) PCAD_LD16HI(yy[i], yrs, so, 128 * (REV ? CH - 1 - (i) : (i)))
-        PCAD_LD_STEP(0); PCAD_LD_STEP(1); PCAD_LD_STEP(2); PCAD_LD_STEP(3);
-#undef PCAD_LD_STEP
-    };
-    static_assert(CH == 4, "aio_load / aio_chunk are written for 4-step chunks");
-    if constexpr (AIO) aio_load(s_first, ua[0], za[0], ya[0]);
-    else load_chunk(s_first, ub, zb, yb, dr);
+    load_chunk(s_first, ub, zb, yb, dr);
 
     // B_t | C_t of the step being computed (SGPRs), software-pipelined one step ahead of the VALU work
     f2 bcc[NSTATE];
@@ -395,41 +356,7 @@ __global__ __launch_bounds__(64, 4) void scan_kernel(const T* __restrict__ u, co
 #pragma unroll
             for (int i = 0; i < CH; ++i) run_step(s0 + i, i, dvp, uy_soff(s0, i), uy_voff(i), uu[i], zz[i], yy[i], dd[i]);
         };
-        // AIO: one chunk from a register set whose loads were issued a chunk ago
-        auto aio_chunk = [&](int s0, uint32_t (&uu)[CH], uint32_t (&zz)[CH], uint32_t (&yy)[CH]) __attribute__((always_inline)) {
-            const float* dvp = dv_base(s0);
-            const uint32_t so = uy_soff(s0, 0);
-            float out[CH];
-#define PCAD_AIO_STEP(i)                                                                                                   \
-            if constexpr (HASZ && ACC != 0) asm volatile("s_waitcnt vmcnt(%3)" : "+v"(uu[i]), "+v"(zz[i]), "+v"(yy[i]) : "n"(NL * (CH - 1 - (i)) + NL * CH)); \
-            else if constexpr (HASZ) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(uu[i]), "+v"(zz[i]) : "n"(NL * (CH - 1 - (i)) + NL * CH)); \
-            else if constexpr (ACC != 0) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(uu[i]), "+v"(yy[i]) : "n"(NL * (CH - 1 - (i)) + NL * CH)); \
-            else asm volatile("s_waitcnt vmcnt(%1)" : "+v"(uu[i]) : "n"(NL * (CH - 1 - (i)) + NL * CH));           \
-            out[i] = step(s0 + (i), (i), dvp, __uint_as_float(uu[i]), __uint_as_float(zz[i]), __uint_as_float(yy[i]), (T)0)
-#define PCAD_AIO_STORE(i)                                                                                                  \
-            if constexpr (SEG != 1) {                                                                                      \
-                const uint32_t pk = pack_bf16x2(out[i], out[(i) + 1]);                                                     \
-                asm volatile("buffer_store_short %0, %1, %2, %3 offen offset:%4" :: "v"(pk), "v"(voff_uy), "s"(yrs), "s"(so),          \
-                             "n"(128 * (REV ? CH - 1 - (i) : (i))) : "memory");                                            \
-                asm volatile("buffer_store_short_d16_hi %0, %1, %2, %3 offen offset:%4" :: "v"(pk), "v"(voff_uy), "s"(yrs), "s"(so),   \
-                             "n"(128 * (REV ? CH - 2 - (i) : (i) + 1)) : "memory");                                        \
-            }
-            PCAD_AIO_STEP(0); PCAD_AIO_STEP(1); PCAD_AIO_STORE(0)
-            PCAD_AIO_STEP(2); PCAD_AIO_STEP(3); PCAD_AIO_STORE(2)
-#undef PCAD_AIO_STEP
-#undef PCAD_AIO_STORE
-        };
         int s0 = s_begin;
-        if constexpr (AIO) {
-            // whole 8-step groups only (BLK8: L % 8 == 0, and a shortened walk is rounded up to 8): set 0 holds the chunk at s0
-            for (; s0 + 2 * CH <= s_end; s0 += 2 * CH) {
-                aio_load(s0 + CH, ua[1], za[1], ya[1]);
-                aio_chunk(s0, ua[0], za[0], ya[0]);
-                aio_load(s0 + 2 * CH, ua[0], za[0], ya[0]);
-                aio_chunk(s0 + CH, ua[1], za[1], ya[1]);
-            }
-            continue;
-        }
         // two chunks per iteration on alternating register sets: no copies between the sets, and each set is waited for at
         // its first use (a full chunk of work after its loads were issued) instead of at the end of the previous chunk
         T un[CH], zn[CH], yn[CH], dn[CH];
@@ -492,11 +419,6 @@ static hipError_t launch_scan_t(const void* u, const void* z, int64_t ldz, const
                                 int accumulate, hipStream_t s, bool uyb, bool zblk = false, float* seg_ws = nullptr, int walk_len = 0) {
     dim3 grid((unsigned)(E / 64), (unsigned)S), block(64);
     const bool hz = z != nullptr;
-#ifdef PCAD_SCAN_NOAIO
-    constexpr bool AIOK = false;
-#else
-    constexpr bool AIOK = sizeof(T) == 2 && FUSED && PRE && BLK8 && ZB;      // every layout fixed at compile time: asm row I/O
-#endif
 #define PCAD_SCAN_ARGS(ZP) (const T*)u, (const T*)(ZP), ldz, (const T*)dsrc, ldd, (const T*)Wdt, Rp, bc, A2, a_scale, Dskip, dbias, \
                            (const T*)y, (T*)y, L, E, (int)uyb, (int)zblk
 #define PCAD_WALK (walk_len > 0 && walk_len < L ? walk_len : L)
@@ -508,7 +430,7 @@ static hipError_t launch_scan_t(const void* u, const void* z, int64_t ldz, const
         if (G > 1 && combo) {
             dim3 gseg((unsigned)(E / 64), (unsigned)(S * G));
 #define PCAD_SEG(REV, ACC, HZ, SEGM, ZP)                                                                                  \
-            hipLaunchKernelGGL((scan_kernel<T, REV, ACC, HZ, FUSED, PRE, BLK8, SEGM, ZB && HZ, AIOK>), gseg, block, 0, s, PCAD_SCAN_ARGS(ZP), G, sb, seg_ws, L)
+            hipLaunchKernelGGL((scan_kernel<T, REV, ACC, HZ, FUSED, PRE, BLK8, SEGM, ZB && HZ>), gseg, block, 0, s, PCAD_SCAN_ARGS(ZP), G, sb, seg_ws, L)
             if (reverse) PCAD_SEG(true, 0, false, 1, nullptr); else PCAD_SEG(false, 0, false, 1, nullptr);
             hipLaunchKernelGGL(scan_carry_kernel, dim3((unsigned)(((int64_t)S * E + 255) / 256)), dim3(256), 0, s, seg_ws, A2, a_scale, S, G, E);
             if (!reverse) { if (hz) PCAD_SEG(false, 0, true, 2, z); else PCAD_SEG(false, 0, false, 2, nullptr); }
@@ -519,7 +441,7 @@ static hipError_t launch_scan_t(const void* u, const void* z, int64_t ldz, const
         }
     }
 #define PCAD_SCAN(REV, ACC, HZ)                                                                                    \
-    hipLaunchKernelGGL((scan_kernel<T, REV, ACC, HZ, FUSED, PRE, BLK8, 0, ZB && HZ, AIOK>), grid, block, 0, s, PCAD_SCAN_ARGS(z), 1, 0, (float*)nullptr, PCAD_WALK)
+    hipLaunchKernelGGL((scan_kernel<T, REV, ACC, HZ, FUSED, PRE, BLK8, 0, ZB && HZ>), grid, block, 0, s, PCAD_SCAN_ARGS(z), 1, 0, (float*)nullptr, PCAD_WALK)
     if (accumulate == 2) {                    // (y_prev + y) * silu(z): the bi-directional sum gated once
         if (!hz) return hipErrorInvalidValue;
         if (reverse) PCAD_SCAN(true, 2, true); else PCAD_SCAN(false, 2, true);

@@ -166,8 +166,9 @@ class Engine:
             self._arena = torch.empty(nbytes + 256, dtype=torch.uint8, device=self.device)
             self._bind(state_dict)
             # input-validation flags: a device word the kernels OR bits into + a pinned host mirror filled by an async copy
-            self._status = torch.zeros(1, dtype=torch.int32, device=self.device)
-            self._status_host = torch.zeros(1, dtype=torch.int32).pin_memory()
+            with torch.inference_mode(False):      # normal tensors: they are updated in place from inside AND outside inference mode
+                self._status = torch.zeros(1, dtype=torch.int32, device=self.device)
+                self._status_host = torch.zeros(1, dtype=torch.int32).pin_memory()
             self._status_event = torch.cuda.Event()
             self._status_event.record()
             _check(self.lib.pcad_set_status_buffer(self._h, self._status.data_ptr()), "pcad_set_status_buffer")

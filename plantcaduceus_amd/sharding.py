@@ -22,23 +22,37 @@ def world() -> Tuple[int, int]:
 
 
 def init_from_env(device: str) -> str:
-    """Under `torchrun` (WORLD_SIZE > 1): join the process group (RCCL for ROCm devices, gloo for cpu) and return
-    this rank's device (`cuda:LOCAL_RANK`); otherwise return `device` unchanged."""
+    """Under `torchrun` (WORLD_SIZE set in the environment, any value >= 1): join the process group (RCCL for ROCm devices, gloo
+    for cpu) and return this rank's device (`cuda:LOCAL_RANK`); otherwise (plain `python`) return `device` unchanged.  A
+    one-rank launch still creates the group, so `torchrun --nproc-per-node 1` runs the same collectives as 8 ranks do."""
     import os
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC, before the first GPU call (RCCL needs it here)
-    ws = int(os.environ.get("WORLD_SIZE", "1"))
-    if ws <= 1 or not dist.is_available():
+    if "WORLD_SIZE" not in os.environ or "RANK" not in os.environ or not dist.is_available():
         return device
     if str(device).startswith("cuda"):
         device = "cuda:%d" % int(os.environ.get("LOCAL_RANK", "0"))
         torch.cuda.set_device(torch.device(device))
     if not dist.is_initialized():
+        global _OWN_GROUP
+        _OWN_GROUP = True
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if str(device).startswith("cuda"):
             dist.init_process_group(backend="nccl", device_id=torch.device(device))
         else:
             dist.init_process_group(backend="gloo")
     return device
+
+
+_OWN_GROUP = False
+
+
+def shutdown():
+    """Destroy the process group if `init_from_env` created it (end of a command-line run)."""
+    global _OWN_GROUP
+    if _OWN_GROUP and dist.is_available() and dist.is_initialized():
+        dist.barrier()
+        dist.destroy_process_group()
+    _OWN_GROUP = False
 
 
 def shard_bounds(n: int, rank: int, world_size: int) -> Tuple[int, int, int]:
@@ -76,6 +90,6 @@ def _all_gather(local: torch.Tensor, ws: int) -> torch.Tensor:
 def all_gather_rows(local: torch.Tensor, n_total: int) -> torch.Tensor:
     """local [per_rank, ...] (equal on every rank) -> [n_total, ...] in rank order, padding stripped."""
     rank, ws = world()
-    if ws == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return local[:n_total]
-    return _all_gather(local, ws)[:n_total]
+    return _all_gather(local, ws)[:n_total]                 # also at world size 1 (a one-rank torchrun): same code path as N ranks

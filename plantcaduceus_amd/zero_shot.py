@@ -477,6 +477,7 @@ def main(argv: Optional[Sequence[str]] = None):
         logits = logits[np.asarray(inverse, dtype=np.int64)] if len(inverse) else logits[:0]      # fan back out per record
     rank, _ = sharding.world()
     if rank != 0:
+        sharding.shutdown()
         return
     if args.inputDF is not None:
         snpDF["zeroShotScore"] = zero_shot_score(snpDF, logits)
@@ -490,6 +491,7 @@ def main(argv: Optional[Sequence[str]] = None):
     else:
         zero_shot_score_vcf(args, recordIndices, logits)
     logging.info(f"Zero-shot scores saved to {args.output}")
+    sharding.shutdown()
 
 
 if __name__ == "__main__":

@@ -10,7 +10,7 @@ import sys
 import pandas as pd
 
 NOTE_SRC = ("rocprofv3 --kernel-trace --pmc {FETCH_SIZE | WRITE_SIZE | SQ_*} (three separate passes) -- python3 bench.py --steps 1 "
-            "--warmup 1 --cpu-seqs 0 --no-profile --batch 128  (l32 bf16, 65536 token-rows per launch)")
+            "--warmup 1 --cpu-seqs 0 --no-profile --batch {batch}  (l32 bf16, {rows} token-rows per launch)")
 NOTE_CORR = ("per MI355X_MICROARCH.md §HBM: FETCH_SIZE on gfx950 reports 1/2 of a wide coalesced read (checked: conv and add_rmsnorm raw "
              "values are 0.52x / 0.49x their algorithmic read bytes); WRITE_SIZE is 1:1 (scan = rows*E*2 exactly). traffic_bytes = "
              "2*FETCH_SIZE + WRITE_SIZE. The scan's 2-byte-per-lane loads are outside the calibrated width, so its read side is an "
@@ -23,6 +23,7 @@ def short(n):
 
 def main():
     base, out = sys.argv[1].rstrip("/") + "/", sys.argv[2]
+    rows = int(sys.argv[3]) if len(sys.argv) > 3 else 524288        # token-rows per launch of the profiled run (--batch 1024: 524288)
     res = {}
     for c in ("FETCH_SIZE", "WRITE_SIZE"):
         df = pd.read_csv(base + f"{c}/p_counter_collection.csv")
@@ -54,15 +55,19 @@ def main():
         if k in res:
             res[k].update({c: float(row[c]) for c in p.columns})
             gui = row["GRBM_GUI_ACTIVE"] / 8.0          # summed over the 8 XCDs
+            d = df[(df.k == k) & (df.Counter_Name == "GRBM_GUI_ACTIVE")]
+            dur = float((d.End_Timestamp - d.Start_Timestamp).mean())            # ns, the profiled dispatches themselves
+            res[k]["profiled_duration_us"] = round(dur / 1e3, 2)
+            res[k]["effective_clock_GHz"] = round(gui / dur, 3)                  # shader clock during the (profiled) dispatch
             res[k]["valu_busy_frac"] = round(row["SQ_ACTIVE_INST_VALU"] * 4 / 1024 / gui, 3)   # quad-cycles
             res[k]["mfma_busy_frac"] = round(row["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024 / gui, 3)
     cls = {"selective_scan": [k for k in res if "scan_kernel" in k],
            "gemm_in_out_proj": [k for k in res if "gemm256" in k] or [k for k in res if "gemm_nt_kernel" in k and k.endswith("false>")],
            "gemm_x_proj": [k for k in res if "gemm_nt_kernel" in k and k.endswith("true>")],
            "conv1d_bidir": [k for k in res if "conv_bidir" in k],
-           "conv_xproj_fused": [k for k in res if "convx_kernel" in k],
+           "conv_xproj_fused": [k for k in res if "convx" in k],
            "add_rmsnorm": [k for k in res if "add_rmsnorm" in k and k.endswith("false>")]}
-    o = {"source": NOTE_SRC, "correction": NOTE_CORR, "rows_per_launch": 65536, "kernels": res, "classes": {}}
+    o = {"source": NOTE_SRC.format(batch=rows // 512, rows=rows), "correction": NOTE_CORR, "rows_per_launch": rows, "kernels": res, "classes": {}}
     try:
         o["src_hash"] = open(base + "src_hash.txt").read().strip()     # bench.source_hash() of the profiled build
     except OSError:
@@ -79,7 +84,8 @@ def main():
                            "read_bytes": round(read_b), "read_bytes_source": "TCC_EA0_RDREQ_{32B,64B,128B}" if rb else "2 x FETCH_SIZE",
                            "write_bytes": round(w * 1024),
                            "valu_busy_frac": round(sum(res[k].get("valu_busy_frac", 0) for k in ks) / len(ks), 3),
-                           "mfma_busy_frac": round(sum(res[k].get("mfma_busy_frac", 0) for k in ks) / len(ks), 3)}
+                           "mfma_busy_frac": round(sum(res[k].get("mfma_busy_frac", 0) for k in ks) / len(ks), 3),
+                           "effective_clock_GHz": round(sum(res[k].get("effective_clock_GHz", 0) for k in ks) / len(ks), 3)}
     json.dump(o, open(out, "w"), indent=1)
     print(json.dumps(o["classes"], indent=1))
 

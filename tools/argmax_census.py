@@ -1,0 +1,132 @@
+#!/usr/bin/env python3
+"""Offline census (run on the GPU box) of north_star's "bit-exact argmax token calls" for the bf16 path at full depth.
+
+  part 1  N synthetic 512-bp windows through PlantCaduceus_l32 bf16 on the HIP engine vs the C oracle in fp32 and in its
+          bf16-emulating mode with the reference's operation order: how many 4-way calls at the masked index differ, the oracle's
+          top-2 probability margin of every differing window, and the histogram of all margins (a synthetic random-weight model
+          is far less confident than a trained one — reference notebooks/examples.ipynb:296 records p = 0.97 for its example).
+  part 2  the same model on checkpoint.harsh_state_dict (`stress=True` checkpoint with in_proj / x_proj x4, dt_proj x16): activations
+          large enough that a visible fraction of time steps take softplus's pass-through branch (delta + bias > 20), fp32 and
+          bf16, full depth, against the oracle.
+
+    python tools/argmax_census.py [--n 128] [--n-emul 64] [--model l32] > profiles/r03_argmax_census.txt
+"""
+import argparse
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+P = 255
+
+
+def softmax4(z):
+    import numpy as np
+    p = np.exp(z - z.max(1, keepdims=True))
+    return p / p.sum(1, keepdims=True)
+
+
+def first_layer_delta_fraction(sd, cfg, ids, thr):
+    """delta_raw + bias > thr in the first mixer (torch oracle's operators on the host: embedding of both strands -> RMSNorm ->
+    in_proj -> conv1d + SiLU -> x_proj -> dt_proj), both directions"""
+    import torch
+    from oracle import caduceus_oracle as O
+    P = O.params_from_state_dict(sd, cfg)
+    S = O.strands(torch.from_numpy(ids).long(), P.complement)
+    h = P.emb[S]
+    lp = P.layers[0]
+    u, _ = O.rms_norm_fn(h, lp.norm_w, residual=None, eps=P.eps, prenorm=True, residual_in_fp32=P.residual_in_fp32)
+    xz = torch.einsum("bld,ed->bel", u, lp.fwd.in_proj)
+    E = lp.fwd.conv_w.shape[0]
+    n = tot = 0
+    for p, rev in ((lp.fwd, False), (lp.rev, True)):
+        x = xz[:, :E].flip(dims=(2,)) if rev else xz[:, :E]
+        xc = O.causal_conv1d_fn(x, p.conv_w, p.conv_b, activation="silu")
+        R = p.dt_proj_w.shape[1]
+        x_dbl = torch.einsum("bel,re->blr", xc, p.x_proj)
+        delta = torch.einsum("blr,er->bel", x_dbl[..., :R], p.dt_proj_w) + p.dt_proj_b.float()[None, :, None]
+        n += int((delta > thr).sum())
+        tot += delta.numel()
+    return n / tot
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--n", type=int, default=128)
+    ap.add_argument("--n-emul", type=int, default=64)
+    ap.add_argument("--n-stress", type=int, default=8)
+    ap.add_argument("--model", default="l32")
+    args = ap.parse_args()
+    import numpy as np
+    import torch
+    from oracle.c_oracle import COracle
+    from plantcaduceus_amd.checkpoint import make_config, synthetic_state_dict
+    from plantcaduceus_amd.modeling_caduceus import CaduceusForMaskedLM
+
+    def hip(cfg, sd, dtype, ids, **kw):
+        m = CaduceusForMaskedLM(cfg)
+        m.load_state_dict(sd, strict=False)
+        m.tie_weights()
+        m = m.to(dtype).to("cuda:0")
+        out = m(input_ids=torch.from_numpy(ids).to("cuda:0"), positions=[P], **kw)
+        lg = out.logits[:, 0].float().cpu().numpy()
+        m.check_status()
+        del m
+        torch.cuda.empty_cache()
+        return lg
+
+    cfg = make_config(args.model)
+    sd = synthetic_state_dict(cfg, seed=1234, stress=False)             # the benchmark's checkpoint
+    rng = np.random.default_rng(0)
+    ids = rng.integers(3, 7, size=(args.n, 512)).astype(np.int32)
+    ids[:, P] = 1
+    print(f"== part 1: PlantCaduceus_{args.model} (d_model={cfg.d_model}, n_layer={cfg.n_layer}), {args.n} synthetic windows, mask index {P}, "
+          f"synthetic checkpoint seed 1234")
+    p_hip = softmax4(hip(cfg, sd, torch.bfloat16, ids)[:, 3:7])
+    t0 = time.time()
+    p_f32 = softmax4(COracle(sd, cfg, blas=True).forward(ids)[0][:, P, 3:7])
+    print(f"fp32 C oracle: {time.time() - t0:.0f} s")
+    ne = min(args.n_emul, args.n)
+    t0 = time.time()
+    p_ref = softmax4(COracle(sd, cfg, blas=True, dtype=torch.bfloat16, emulate_bf16=True, ref_order=True).forward(ids[:ne])[0][:, P, 3:7])
+    print(f"bf16-emulating C oracle, reference operation order, first {ne} windows: {time.time() - t0:.0f} s")
+    for name, q, n in (("fp32 oracle", p_f32, args.n), ("bf16 emulation (reference order)", p_ref, ne)):
+        a, b = p_hip[:n].argmax(1), q.argmax(1)
+        flips = np.nonzero(a != b)[0]
+        top2 = np.sort(q, 1)[:, -2:]
+        margin = top2[:, 1] - top2[:, 0]
+        print(f"-- HIP bf16 vs {name}: {n} windows, max |dp| {np.abs(p_hip[:n] - q).max():.3e}, calls that differ: {len(flips)}")
+        for i in flips:
+            print(f"   window {i}: oracle p = {np.round(q[i], 4).tolist()}  hip p = {np.round(p_hip[i], 4).tolist()}  oracle top-2 margin {margin[i]:.4f}")
+        edges = [0, 1e-3, 2e-3, 5e-3, 1e-2, 2e-2, 5e-2, 1e-1, 1.0]
+        h, _ = np.histogram(margin, bins=edges)
+        print("   top-2 probability margin of the oracle, windows per bin: " + ", ".join(f"[{edges[i]:g},{edges[i+1]:g}): {h[i]}" for i in range(len(h))))
+        print(f"   smallest margin among agreeing windows {margin[a == b].min():.2e}; largest margin among differing windows "
+              f"{(margin[flips].max() if len(flips) else 0.0):.2e}")
+    # the two oracles against each other: the noise floor that any bf16 implementation sits in
+    a, b = p_f32[:ne].argmax(1), p_ref.argmax(1)
+    print(f"-- fp32 oracle vs bf16 emulation (no GPU involved): calls that differ {int((a != b).sum())} of {ne}, max |dp| {np.abs(p_f32[:ne] - p_ref).max():.3e}")
+
+    print(f"\n== part 2: harsh checkpoint (stress seed 21, distinct fwd/rev parameters; in_proj and x_proj x4, dt_proj x16), {args.n_stress} windows, full depth")
+    from plantcaduceus_amd.checkpoint import harsh_state_dict
+    sd4 = harsh_state_dict(cfg)
+    ids4 = ids[:args.n_stress]
+    frac = first_layer_delta_fraction(sd4, cfg, ids4[:2], 20.0)
+    print(f"first layer, both directions, 2 windows: fraction of (t, channel) elements with dt_proj(x_dbl) + bias > 20 "
+          f"(softplus pass-through branch) = {frac:.4f}")
+    assert frac > 0.01, "the scaled checkpoint does not reach the softplus pass-through branch visibly"
+    lg32 = hip(cfg, sd4, torch.float32, ids4)
+    lgbf = hip(cfg, sd4, torch.bfloat16, ids4)
+    ref32 = COracle(sd4, cfg, blas=True).forward(ids4)[0][:, P]
+    refbf = COracle(sd4, cfg, blas=True, dtype=torch.bfloat16, emulate_bf16=True, ref_order=True).forward(ids4)[0][:, P]
+    e32 = np.abs(lg32 - ref32).max() / np.abs(ref32).max()
+    print(f"fp32 HIP vs fp32 oracle: logits rel err {e32:.2e}; argmax equal on {int((lg32[:, 3:7].argmax(1) == ref32[:, 3:7].argmax(1)).sum())} of {len(ids4)}")
+    pb, qb = softmax4(lgbf[:, 3:7]), softmax4(refbf[:, 3:7])
+    print(f"bf16 HIP vs bf16 emulation (reference order): max |dp| {np.abs(pb - qb).max():.3e}; argmax equal on "
+          f"{int((pb.argmax(1) == qb.argmax(1)).sum())} of {len(ids4)}; vs fp32 oracle max |dp| {np.abs(pb - softmax4(ref32[:, 3:7])).max():.3e}")
+    assert np.isfinite(lg32).all() and np.isfinite(lgbf).all()
+
+
+if __name__ == "__main__":
+    main()
