@@ -39,8 +39,13 @@ if ROOT not in sys.path:
 
 PEAK = {"bf16": 2500.0, "f32": 157.3}     # dense MFMA TFLOP/s, MI355X_MICROARCH.md chip-level table
 PEAK_HBM = 8000.0                          # GB/s spec
-# cycles per wave-instruction measured on gfx950 at 4 waves/SIMD (tools/valu_microbench.hip)
-CYC_EXP, CYC_PK = 8.48, 5.24
+# SIMD time per wave-instruction at 4 waves/SIMD, expressed in cycles of the 2.4 GHz NOMINAL clock (wall time x 2.4e9), measured
+# with tools/valu_microbench.hip and committed as profiles/r03_valu_microbench.txt: v_exp_f32 8.48, v_pk_mul_f32 5.21,
+# v_pk_fma_f32 5.35, and the scan's own state-pair mix (2 v_exp_f32 + 2 v_pk_mul_f32 + 2 v_pk_fma_f32) 34.73 per pair.  These are
+# TIME costs: the dense-VALU microbenchmark itself runs at an effective 1.5-1.6 GHz (power-limited), so the same numbers in
+# real shader cycles are 5.7 / 3.3 / 3.5 — what bounds the scan is the energy of its instruction stream, not issue slots.
+CYC_EXP, CYC_PK = 8.48, 5.28
+CYC_PAIR_MIX = 34.73
 SIMDS, CLOCK = 1024, 2.4e9
 
 
@@ -102,12 +107,12 @@ def algorithmic_work(cfg, rows, esz):
     # strand-layer -> 1.5*E per row per launch, plus the read half of the x_dbl term (R+2N per row per direction).
     # as executed: forward launch reads u, writes y (2E); reverse launch reads u, z, y_fwd, writes y (4E) -> 3.0*E average,
     # + dt_low (Rp) + fp32 B|C.  flops: dt_proj contraction on MFMA (2*R*E) + 6 per state update.
-    # VALU floor: per (t, 64-channel wave) 16 v_exp_f32 + 32 packed fp32 ops (2 pk_mul + 2 pk_fma per state pair) at the
-    # microbenchmarked issue costs — nothing else (no softplus, gate, conversions, I/O).
+    # VALU floor: per (t, 64-channel wave) 8 state pairs x (2 v_exp_f32 + 2 v_pk_mul_f32 + 2 v_pk_fma_f32) at the time the
+    # microbenchmark measured for exactly that mix at 4 waves/SIMD — nothing else (no softplus, gate, conversions, I/O).
     w["selective_scan"] = dict(flops=rows * E * (N * 6.0 + 2.0 * R),
                                bytes=esz * (rows * E * 3.0 + rows * Rp) + 4 * rows * 2 * N,
                                bytes_8d=esz * rows * (1.5 * E + X),
-                               valu_floor_cycles=rows * (E / 64.0) * (N * CYC_EXP + 2 * N * CYC_PK),
+                               valu_floor_cycles=rows * (E / 64.0) * (N / 2) * CYC_PAIR_MIX,
                                trans_cycles=rows * (E / 64.0) * N * CYC_EXP)
     w["final_head"] = dict(flops=0.0, bytes=0.0, bytes_8d=0.0)
     return w
@@ -337,8 +342,8 @@ def main():
                 if "valu_floor_cycles" in work[dom]:
                     # the contract's bound is hbm|mfma; this kernel's limiter is neither: VALU issue + the quarter-rate
                     # transcendental unit (PMC: VALU busy ~77 %, MFMA busy < 2 %).  Reported next to the HBM fraction:
-                    #   valu_floor_frac  = (16 v_exp_f32 + 32 packed fp32 ops per (t, 64-channel wave), microbenchmarked
-                    #                      issue costs, NOTHING else) / (launch time x 1024 SIMDs x 2.4 GHz)
+                    #   valu_floor_frac  = (16 v_exp_f32 + 32 packed fp32 ops per (t, 64-channel wave) at the microbenchmarked time
+                    #                      of that mix, NOTHING else) / (launch time x 1024 SIMDs x 2.4 GHz nominal)
                     #   trans_floor_frac = the 16 v_exp_f32 alone
                     cyc = avg_s * SIMDS * CLOCK
                     res["roofline"]["valu_floor_frac"] = work[dom]["valu_floor_cycles"] / cyc
@@ -346,7 +351,8 @@ def main():
                     res["roofline"]["note"] = ("frac = SURVEY.md §8(d) share (1.5*E*s + (R+2N)*s bytes per row per direction launch) / "
                                                "launch time / 8 TB/s; the kernel is VALU/transcendental-bound, not HBM-bound: "
                                                "valu_floor_frac / trans_floor_frac give its distance from the arithmetic floor "
-                                               "(16 v_exp_f32 at %.2f + 32 packed ops at %.2f cycles per wave-instruction)" % (CYC_EXP, CYC_PK))
+                                               "(8 state pairs x %.2f nominal-2.4-GHz cycles for 2 v_exp_f32 + 4 packed ops, profiles/r03_valu_microbench.txt; "
+                                               "v_exp_f32 alone %.2f)" % (CYC_PAIR_MIX, CYC_EXP))
             res["roofline"]["rows_per_launch"] = rows
             # HBM traffic per launch from the PMC counters (separate rocprofv3 --pmc passes; summary committed under profiles/).
             # Only filled when the committed profile was measured on THIS build of the kernels (source hash match).

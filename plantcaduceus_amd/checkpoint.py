@@ -83,11 +83,15 @@ def synthetic_state_dict(config: CaduceusConfig, seed: int = 1234, stress: bool 
     return sd
 
 
-def harsh_state_dict(config: CaduceusConfig, seed: int = 21, proj_scale: float = 4.0, dt_scale: float = 16.0) -> Dict[str, torch.Tensor]:
-    """The `stress` checkpoint (distinct fwd/rev parameters, perturbed A_log / D / norm weights) with every in_proj and x_proj
-    weight scaled by `proj_scale` and every dt_proj weight by `dt_scale`: activations |x| >> 1 through the whole stack and
-    time steps large enough that ~10 % of the (t, channel) elements take softplus's pass-through branch (delta + bias > 20) —
-    the regime the benign benchmark checkpoint never reaches (tools/argmax_census.py, tests/test_gpu_fulldepth.py)."""
+def harsh_state_dict(config: CaduceusConfig, seed: int = 21, proj_scale: float = 1.0, dt_scale: float = 256.0) -> Dict[str, torch.Tensor]:
+    """The `stress` checkpoint (distinct fwd/rev parameters, perturbed A_log / D / norm weights) with every dt_proj weight scaled
+    by `dt_scale` (and every in_proj / x_proj weight by `proj_scale`): time steps large enough that ~12 % of the (t, channel)
+    elements take softplus's pass-through branch (delta + bias > 20) — the regime the benign benchmark checkpoint never reaches
+    (tools/argmax_census.py, tests/test_gpu_fulldepth.py).  The defaults keep the 32-layer stack well conditioned: two fp32 CPU
+    restatements that differ only in summation order (oracle/c with and without BLAS) agree to 6e-8 on it, so north_star's 1e-4
+    is a meaningful bar.  Scaling the projections as well (proj_scale 4, dt_scale 16: |x| >> 1 through the stack) makes the
+    network amplify rounding noise ~1e5-fold — those two restatements then differ by 4e-2 — so on that variant a comparison can
+    only be read against that noise floor (profiles/r03_argmax_census.txt prints both)."""
     sd = synthetic_state_dict(config, seed=seed, stress=True)
     for k in list(sd):
         if k.endswith("in_proj.weight") or k.endswith("x_proj.weight"):

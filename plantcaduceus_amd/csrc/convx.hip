@@ -364,260 +364,6 @@ __global__ __launch_bounds__(CX_THREADS, 2) void convx_kernel(const T* __restric
     }
 }
 
-// ---- 16-wave form ---------------------------------------------------------------------------------------------------------
-// Same tile, LDS image, one-barrier software pipeline and DMA protocol as convx_kernel, on 16 waves (4 per SIMD) instead of 8:
-// the 8-wave kernel is latency-bound, not pipe-bound (PMC, DESIGN.md §8: 40 % of its wave-cycles parked at s_waitcnt / s_barrier,
-// 29 % stalled on dependent issue, VALU 42 % busy) with two waves per SIMD to hide each other's LDS round trips and
-// FMA -> exp -> rcp chains.  Here a thread convolves ONE 8-byte half of a 16-byte chunk for 4 rows (half the registers), a wave
-// multiplies 32 rows x 48 of the 96 x_dbl columns, and twice as many waves are in flight per SIMD.  The raw tile is staged with
-// rows 4..7 of every 8-row group pairwise swapped (a source-side permutation of the LDS-DMA lanes), so the four rows a 32-lane
-// group of `ds_read_b64` touches (q and q + 4, two halves each) fall on all 64 banks: no conflict (the 8-wave kernel loses 31 %
-// of its LDS cycles to a 4-way conflict there).
-constexpr int CX16_THREADS = 1024;
-#ifdef PCAD_CX16_NOSWZ
-constexpr bool CX16_SWZ = false;
-#else
-constexpr bool CX16_SWZ = true;
-#endif
-constexpr int CX16_LDS = CX_LDS + 1024;      // + a spare KiB: landing place of the idle DMA slot
-
-__device__ __forceinline__ int cx_rawpos(int q) { return q ^ ((q >> 2) & 1); }      // LDS row of raw row q (an involution within 8-row groups)
-
-template <typename T, bool ZFILL>
-__global__ __launch_bounds__(CX16_THREADS) void convx16_kernel(const T* __restrict__ x, const float* __restrict__ convw,
-                                                               ConvxDir d0, ConvxDir d1, int S, int L, int E) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int CPC = Chunk<T>::CPC;
-    constexpr int KC = CX_ROWB / (int)sizeof(T);
-    constexpr int HC = CPC / 2;
-    constexpr int CW_PIECES = (2 * 5 * KC * 4 + 1023) / 1024;
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);    // 0..15
-    const int tiles_per_strand = (L + CX_ROWS - 1) / CX_ROWS;
-    const int strand = blockIdx.x / tiles_per_strand;
-    const int t0 = (blockIdx.x - strand * tiles_per_strand) * CX_ROWS;
-    const int64_t row0 = (int64_t)strand * L;
-    const int nkt = E / KC;
-    const int64_t pieces = nkt;
-
-    // ---- staging: 17 raw groups + 24 Wx groups + CW_PIECES tap pieces per K-tile = 3 LDS-DMAs per wave, branch-free: ------------
-    //   slot A: raw group w;  slot B: Wx group w;  slot C: Wx group 16 + w (w < 8) | raw group 16 (w = 8) | tap piece w - 9
-    //   (w = 9 .. 9 + CW_PIECES - 1) | nothing (a zero-length descriptor: the DMA moves no bytes and lands zeros in a spare KiB).
-    const char* raw_base = reinterpret_cast<const char*>(x);
-    uint32_t raw_records = 0xfffffffcu;
-    if (ZFILL) {
-        raw_base += (row0 >> 3) * pieces * 1024;
-        raw_records = (uint32_t)((int64_t)(L >> 3) * pieces * 1024);
-    }
-    auto raw_off = [&](int grp) -> uint32_t {          // this lane's source offset for raw group grp (LDS row lane / 8 of the group)
-        const int q = grp * 8 + (CX16_SWZ ? cx_rawpos(lane >> 3) : (lane >> 3));   // raw row landing there: t = t0 - 3 + q
-        if (ZFILL) {
-            const int t = t0 - 3 + q;
-            return (uint32_t)((int64_t)(t >> 3) * pieces * 1024 + ((t & 7) << 7) + ((lane & 7) << 4));
-        }
-        const int t = min(max(t0 - 3 + q, 0), L - 1);
-        return (uint32_t)(blocked_off(row0 + t, 0, pieces) + ((lane & 7) << 4));
-    };
-    auto w_off = [&](int grp) -> uint32_t {            // Wx group grp (0..23): dir = grp / 12, rows 8 * (grp % 12) ..
-        const int g = grp % 12, r = g * 8 + (lane >> 3);
-        return (uint32_t)((int64_t)r * E * (int64_t)sizeof(T) + (((lane & 7) ^ cx_key(r)) << 4));
-    };
-    const uint32_t srcA = raw_off(wave), srcB = w_off(wave);
-    const void* baseB = wave >= 12 ? d1.Wx : d0.Wx;
-    const int dstB = (wave / 12) * CX_W_BYTES + (wave % 12) * 8 * CX_ROWB;               // inside a W stage
-    // slot C, all wave-uniform (SGPRs): base, lane source offset, records, K-tile stride, destination per parity
-    const void* baseC; uint32_t srcC, recC, strideC; int dstC0, dstC1; int tapC = 0;
-    if (wave < 8) {
-        baseC = wave + 16 >= 12 ? d1.Wx : d0.Wx; srcC = w_off(wave + 16); recC = 0xfffffffcu; strideC = CX_ROWB;
-        dstC0 = CX_OFF_W + ((wave + 16) / 12) * CX_W_BYTES + ((wave + 16) % 12) * 8 * CX_ROWB; dstC1 = dstC0 + 2 * CX_W_BYTES;
-    } else if (wave == 8) {
-        baseC = raw_base; srcC = raw_off(16); recC = raw_records; strideC = 1024u; tapC = 1;     // issued one K-tile ahead, like slot A
-        dstC0 = 16 * 8 * CX_ROWB; dstC1 = dstC0 + CX_RAW_BYTES;
-    } else if (wave - 9 < CW_PIECES) {
-        baseC = convw; srcC = (uint32_t)((wave - 9) * 1024 + lane * 16); recC = 0xfffffffcu; strideC = CX_CW_BYTES; tapC = 1;
-        dstC0 = CX_OFF_CW + (wave - 9) * 1024; dstC1 = dstC0 + CX_CW_BYTES;
-    } else {
-        baseC = convw; srcC = 0; recC = 0; strideC = 0; dstC0 = dstC1 = CX_LDS;                  // no-op into the spare KiB
-    }
-    // issue(it, P): slot B stages Wx(it) into W stage P; slot A raw(it + 1) into raw stage 1 - P; slot C whichever it carries
-    auto issue = [&](int it, int P) __attribute__((always_inline)) {
-        if (it >= 0 && it < nkt) cx_blds16(baseB, srcB, (uint32_t)it * (uint32_t)CX_ROWB, smem + CX_OFF_W + P * 2 * CX_W_BYTES + dstB);
-        if (it + 1 < nkt) cx_blds16(raw_base, srcA, (uint32_t)(it + 1) * 1024u, smem + (1 - P) * CX_RAW_BYTES + wave * 8 * CX_ROWB, raw_records);
-        const int kc = it + tapC;                       // taps / raw run one K-tile ahead of Wx
-        if (kc >= 0 && kc < nkt) cx_blds16(baseC, srcC, (uint32_t)kc * strideC, smem + ((tapC ? 1 - P : P) ? dstC1 : dstC0), recC);
-    };
-
-    // ---- roles: waves 0-7 causal, 8-15 anti-causal ------------------------------------------------------------------------------
-    const int cdir = __builtin_amdgcn_readfirstlane(tid >> 9);
-    const int td = tid & 511;
-    const int c8 = td & 7, hh = (td >> 3) & 1;
-    const int g4 = ((td >> 4) & 31) * 4;           // first output row (tile-relative) of this thread
-    const int qbase = g4 + (cdir ? 3 : 0);
-    // MFMA: per direction 8 waves = 4 row blocks of 32 x 2 column halves of 48
-    const int wq = wave & 7;
-    const int mq = wq >> 1, nh = wq & 1;
-    const int li = lane & 15, lg = lane >> 4;
-    // LDS addressing: every access is ONE per-thread base register (region start + this thread's part, made opaque so the
-    // compiler keeps exactly these registers) + a compile-time offset below 64 KiB that goes into the instruction.  Left to
-    // itself hipcc forms a separate base register for every (stage, region) combination beyond the 16-bit offset range, and at
-    // 128 registers per thread (4 waves per SIMD) those spill.
-#define PCAD_OPAQUE(v) asm volatile("" : "+v"(v))
-    int rbase = qbase * CX_ROWB + c8 * 16 + hh * 8;                                        // raw window (not swizzled)
-    int tbase = CX_OFF_CW + ((cdir ? 5 * KC : 0) + c8 * CPC + hh * HC) * 4;                // taps
-    int wr0 = CX_OFF_C + cdir * CX_TILE_BYTES + g4 * CX_ROWB + ((c8 ^ cx_key(g4)) << 4) + hh * 8;        // conv rows g4, g4+1
-    int wr1 = CX_OFF_C + cdir * CX_TILE_BYTES + (g4 + 2) * CX_ROWB + ((c8 ^ cx_key(g4 + 2)) << 4) + hh * 8;   // rows g4+2, g4+3
-    int ab0 = CX_OFF_C + cdir * CX_TILE_BYTES + mq * 32 * CX_ROWB + li * CX_ROWB + (((0 * 4 + lg) ^ cx_key(li)) << 4);    // A fragments, kk = 0
-    int ab1 = CX_OFF_C + cdir * CX_TILE_BYTES + mq * 32 * CX_ROWB + li * CX_ROWB + (((1 * 4 + lg) ^ cx_key(li)) << 4);
-    int wb0 = CX_OFF_W + cdir * CX_W_BYTES + nh * 3 * 16 * CX_ROWB + li * CX_ROWB + (((0 * 4 + lg) ^ cx_key(li)) << 4);    // W fragments
-    int wb1 = CX_OFF_W + cdir * CX_W_BYTES + nh * 3 * 16 * CX_ROWB + li * CX_ROWB + (((1 * 4 + lg) ^ cx_key(li)) << 4);
-    const int cr0 = wave * 8 + (lane >> 3);        // xc copy-out: wave w copies rows 8w .. 8w+7 of cf and of cr
-    int cob = CX_OFF_C + cr0 * CX_ROWB + (((lane & 7) ^ cx_key(cr0)) << 4);
-    PCAD_OPAQUE(rbase); PCAD_OPAQUE(tbase); PCAD_OPAQUE(wr0); PCAD_OPAQUE(wr1); PCAD_OPAQUE(ab0); PCAD_OPAQUE(ab1);
-    PCAD_OPAQUE(wb0); PCAD_OPAQUE(wb1); PCAD_OPAQUE(cob);
-#undef PCAD_OPAQUE
-    auto raw_lo = [&](int j) -> int { return CX16_SWZ ? (cx_rawpos(qbase + j) - qbase) * CX_ROWB : j * CX_ROWB; };   // + rbase
-    f32x4 acc[2][3];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 3; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    T* xcf = (T*)d0.xc;
-    T* xcr = (T*)d1.xc;
-    const bool full_tile = t0 + CX_ROWS <= L;
-
-    auto mfma_half = [&](int mpar, int kk) __attribute__((always_inline)) {
-        const char* at = smem + (kk ? ab1 : ab0) + mpar * 2 * CX_TILE_BYTES;
-        const char* wb = smem + (kk ? wb1 : wb0) + mpar * 2 * CX_W_BYTES;
-        u32x4 af[2], wfr[3];
-#pragma unroll
-        for (int i = 0; i < 2; ++i) af[i] = *reinterpret_cast<const u32x4*>(at + i * 16 * CX_ROWB);
-#pragma unroll
-        for (int j = 0; j < 3; ++j) wfr[j] = *reinterpret_cast<const u32x4*>(wb + j * 16 * CX_ROWB);
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 3; ++j) acc[i][j] = CxMma<T>::run(wfr[j], af[i], acc[i][j]);
-    };
-    const uint32_t xc_lo = (uint32_t)(blocked_off(row0 + t0 + cr0, 0, pieces) + ((lane & 7) << 4));
-    auto copy_out = [&](int mt, int mpar) __attribute__((always_inline)) {
-#pragma unroll
-        for (int d = 0; d < 2; ++d) {
-            const u32x4 v = *reinterpret_cast<const u32x4*>(smem + cob + mpar * 2 * CX_TILE_BYTES + d * CX_TILE_BYTES);
-            if (t0 + cr0 < L) {
-                char* dst = reinterpret_cast<char*>(d ? xcr : xcf) + (xc_lo + (uint32_t)mt * 1024u);
-                *reinterpret_cast<u32x4*>(dst) = v;
-            }
-        }
-    };
-    auto conv_pass = [&](int kt, int par, auto rev_tag, bool with_mfma) __attribute__((always_inline)) {
-        constexpr bool REVC = decltype(rev_tag)::value;
-        const char* raw = smem + rbase + par * CX_RAW_BYTES;
-        const float* cw = reinterpret_cast<const float*>(smem + tbase + par * CX_CW_BYTES);
-        if (with_mfma) mfma_half(1 - par, 0);
-        __builtin_amdgcn_sched_barrier(0);             // fragment registers are dead before the conv's window is loaded
-        const f32x2_t nl2e = {-kLog2e, -kLog2e}, one = {1.0f, 1.0f};
-        // the 7-row window stays packed (8 bytes per row); channel PAIRS are convolved one after the other, each with its own
-        // taps, so that only one pair's fp32 window and taps are live at a time (a spill here is reloaded through vmcnt, which the
-        // LDS-DMAs in flight share: far more expensive than its load)
-        u32x2 rw[7];
-#pragma unroll
-        for (int j = 0; j < 7; ++j) {
-            rw[j] = *reinterpret_cast<const u32x2*>(raw + raw_lo(j));
-            if (!ZFILL) {
-                const int t = t0 - 3 + qbase + j;
-                const unsigned keep = 0u - (unsigned)((unsigned)t < (unsigned)L);
-                rw[j] &= u32x2{keep, keep};
-            }
-        }
-        uint32_t pk0[4];                               // bf16: the first pair's packed outputs, waiting for the second
-#pragma unroll
-        for (int e = 0; e < HC / 2; ++e) {
-            f32x2_t wt[4], bias;
-#pragma unroll
-            for (int k = 0; k < 5; ++k) {
-                const f32x2_t v = *reinterpret_cast<const f32x2_t*>(cw + k * KC + 2 * e);
-                if (k < 4) wt[k] = v; else bias = v;
-            }
-            f32x2_t win[7];
-#pragma unroll
-            for (int j = 0; j < 7; ++j) {
-                if constexpr (sizeof(T) == 2) win[j] = f32x2_t{bf16lo_to_f32(rw[j][e]), bf16hi_to_f32(rw[j][e])};
-                else win[j] = f32x2_t{__uint_as_float(rw[j][0]), __uint_as_float(rw[j][1])};
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                f32x2_t a = bias;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) a = wt[k] * win[REVC ? (j + 3 - k) : (j + k)] + a;     // x[t+3-k] / x[t-3+k]
-                const f32x2_t x2 = a * nl2e;                                  // silu(a) = a / (1 + 2^(-a log2 e))
-                const f32x2_t den = f32x2_t{fast_exp2(x2[0]), fast_exp2(x2[1])} + one;
-                const f32x2_t sv = a * f32x2_t{fast_rcp(den[0]), fast_rcp(den[1])};
-                char* dst = smem + (j < 2 ? wr0 : wr1) + par * 2 * CX_TILE_BYTES + (j & 1) * CX_ROWB;
-                if constexpr (sizeof(T) == 2) {
-                    const uint32_t pk = pack_bf16x2(sv[0], sv[1]);
-                    if (e == 0) pk0[j] = pk;
-                    else *reinterpret_cast<u32x2*>(dst) = u32x2{pk0[j], pk};
-                } else {
-                    *reinterpret_cast<u32x2*>(dst) = u32x2{__float_as_uint(sv[0]), __float_as_uint(sv[1])};
-                }
-            }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        if (with_mfma) { mfma_half(1 - par, 1); __builtin_amdgcn_sched_barrier(0); copy_out(kt - 1, 1 - par); }
-    };
-
-    issue(-1, 1);                                   // prologue: raw(0) -> raw stage 0, taps(0) / raw group 16 of K-tile 0 -> stage 0
-    auto iteration = [&](int it, auto par_tag) __attribute__((always_inline)) {
-        constexpr int P = decltype(par_tag)::value;
-        // everything this wave issued in the previous iteration must have landed; younger are only that iteration's 2 xc stores
-        if (full_tile && it >= 2) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        issue(it, P);
-        if (it < nkt) {
-            if (cdir) conv_pass(it, P, std::true_type{}, it > 0);
-            else conv_pass(it, P, std::false_type{}, it > 0);
-        } else {
-            mfma_half(1 - P, 0);
-            mfma_half(1 - P, 1);
-            copy_out(it - 1, 1 - P);
-        }
-    };
-    for (int it = 0; it <= nkt; it += 2) {
-        iteration(it, std::integral_constant<int, 0>{});
-        if (it + 1 <= nkt) iteration(it + 1, std::integral_constant<int, 1>{});
-    }
-
-    // ---- epilogue: fragment jj = 3 * nh + j -> x_dbl columns jj*16 + lg*4 .. +3 (0..63 dt_low, 64..95 B | C) ----------------------
-    const ConvxDir dd = cdir ? d1 : d0;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int t = t0 + mq * 32 + i * 16 + li;
-        if (t >= L) continue;
-        const int64_t row = row0 + t;
-        T* dl = (T*)dd.dtl + row * 64;
-        float* bcr = dd.bc + row * 32;
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            const int jj = 3 * nh + j;                       // wave-uniform
-            if (jj < 4) {
-                if constexpr (sizeof(T) == 2) {
-                    u32x2 v = {pack_bf16x2(acc[i][j][0], acc[i][j][1]), pack_bf16x2(acc[i][j][2], acc[i][j][3])};
-                    *reinterpret_cast<u32x2*>(dl + jj * 16 + lg * 4) = v;
-                } else {
-                    *reinterpret_cast<f32x4*>(dl + jj * 16 + lg * 4) = acc[i][j];
-                }
-            } else {
-                f32x4 v = {Elem<T>::round(acc[i][j][0]), Elem<T>::round(acc[i][j][1]), Elem<T>::round(acc[i][j][2]),
-                           Elem<T>::round(acc[i][j][3])};
-                *reinterpret_cast<f32x4*>(bcr + (jj - 4) * 16 + lg * 4) = v;
-            }
-        }
-    }
-}
-
 // conv taps of both directions -> per K-tile [dir][tap 0..3, bias][KC] fp32 (CX_CW_BYTES per K-tile, zero padded)
 __global__ __launch_bounds__(256) void pack_convw_kernel(const float* __restrict__ wf, const float* __restrict__ bfw,
                                                          const float* __restrict__ wr, const float* __restrict__ brw,
@@ -659,20 +405,12 @@ hipError_t launch_convx(const void* x, const float* convw, const void* Wx0, void
     ConvxDir d0{Wx0, xc0, dtl0, bc0}, d1{Wx1, xc1, dtl1, bc1};
     const int tiles = S * ((L + CX_ROWS - 1) / CX_ROWS);
     const bool zfill = L % 8 == 0;
-    static const bool use8 = dev_env("PCAD_CONVX16") == nullptr;     // PCAD_DEV=1 PCAD_CONVX16=1: the 16-wave kernel (experiment)
 #define PCAD_CONVX(T, Z)                                                                                              \
     do {                                                                                                                \
-        if (use8) {                                                                                                     \
-            auto k = convx_kernel<T, Z>;                                                                                \
-            static bool attr = false;                                                                                   \
-            if (!attr) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, CX_LDS); attr = true; } \
-            hipLaunchKernelGGL(k, dim3((unsigned)tiles), dim3(CX_THREADS), CX_LDS, s, (const T*)x, convw, d0, d1, S, L, E);  \
-        } else {                                                                                                        \
-            auto k = convx16_kernel<T, Z>;                                                                              \
-            static bool attr = false;                                                                                   \
-            if (!attr) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, CX16_LDS); attr = true; } \
-            hipLaunchKernelGGL(k, dim3((unsigned)tiles), dim3(CX16_THREADS), CX16_LDS, s, (const T*)x, convw, d0, d1, S, L, E);  \
-        }                                                                                                               \
+        auto k = convx_kernel<T, Z>;                                                                                    \
+        static bool attr = false;                                                                                       \
+        if (!attr) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, CX_LDS); attr = true; } \
+        hipLaunchKernelGGL(k, dim3((unsigned)tiles), dim3(CX_THREADS), CX_LDS, s, (const T*)x, convw, d0, d1, S, L, E);  \
     } while (0)
     if (dt == BF16) { if (zfill) PCAD_CONVX(bf16_t, true); else PCAD_CONVX(bf16_t, false); }
     else { if (zfill) PCAD_CONVX(float, true); else PCAD_CONVX(float, false); }

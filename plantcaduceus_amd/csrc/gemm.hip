@@ -609,7 +609,7 @@ __global__ __launch_bounds__(GEMMQ_THREADS, 1) void gemm256q_kernel(const T* __r
                                                                     const T* __restrict__ W, int64_t ldw,
                                                                     OutT* __restrict__ C, int64_t ldc, int64_t M, int N,
                                                                     int K, int tiles_m, int tiles_n, int a_blocked,
-                                                                    OutT* __restrict__ C2, int nsplit, int out_blocked) {
+                                                                    OutT* __restrict__ C2, int nsplit, int out_blocked, int epi_swap, int stagger) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -618,6 +618,16 @@ __global__ __launch_bounds__(GEMMQ_THREADS, 1) void gemm256q_kernel(const T* __r
     const int nblk = tiles_m * tiles_n;
     const int nkt = (K * (int)sizeof(T)) / ROWB;
     if ((int)blockIdx.x >= nblk) return;
+    // Every block of this persistent launch walks the same number of equal tiles, so without a nudge all CUs reach their epilogue in
+    // the same instant and the whole output (32 MB per round of tiles at 256 CUs) hits HBM as one burst while the matrix pipes
+    // wait (tools/store_pattern_microbench.hip: 5.2 us per tile at the 6.4 TB/s write ceiling, any store pattern).  A start delay
+    // of phase / 8 of one tile's duration (phase = which of 8 groups the block is in on its XCD) spreads the stores of one group
+    // over the mainloops of the others.
+    if (stagger > 0) {
+        const int phase = ((int)blockIdx.x >> 3) & 7;
+        const long long until = __builtin_readcyclecounter() + (long long)phase * stagger * nkt;
+        while (__builtin_readcyclecounter() < until) __builtin_amdgcn_s_sleep(8);
+    }
     const int my_tiles = (nblk - (int)blockIdx.x + gstride - 1) / gstride;
     const int G = my_tiles * nkt;                                 // K-tiles this block walks
 
@@ -759,6 +769,9 @@ __global__ __launch_bounds__(GEMMQ_THREADS, 1) void gemm256q_kernel(const T* __r
     // lane: 2 x 16 consecutive columns (jg) of 8 rows (i).  Every destination is lane_base + i * row_step + jg * 128 bytes
     // (plain and blocked layouts alike; in the two-output form the 64-column group jg lies wholly in one output because
     // nsplit is a multiple of 64), so the address math is one 64-bit lane value per tile plus wave-uniform steps.
+    // byte correction of the lane's destination for the swapped epilogue: the lane's piece moves from column 16 lg to
+    // (lg & 1) * 16 + (lg >> 1) * 8 of the 64-column group (2-byte elements)
+    const int swap_fix = (((lg & 1) * 16 + (lg >> 1) * 8) - lg * 16) * 2;
     auto epilogue = [&](int64_t m0, int n0) {
         const int64_t mrow = m0 + wm * 128 + li;
 #pragma unroll
@@ -794,6 +807,25 @@ __global__ __launch_bounds__(GEMMQ_THREADS, 1) void gemm256q_kernel(const T* __r
                     hi[rr] = t2[rr]; hi[4 + rr] = t3[rr];
                 }
                 OutT* dst = reinterpret_cast<OutT*>(lane_dst + i * row_step);
+                if constexpr (sizeof(OutT) == 2) {
+                    if (epi_swap) {
+                        // lane group lg (= lane / 16) holds columns [16 lg, 16 lg + 16) of the 64-column group: `lo` of the four groups
+                        // are four separate 16-byte runs of a 128-byte line.  Exchanging the upper-half lanes of `lo` with the
+                        // lower-half lanes of `hi` (v_permlane32_swap) leaves `lo` with the line's first 64 bytes and `hi` with the
+                        // second (lane group -> 16-byte piece 0, 2, 1, 3), so each store instruction writes whole 64-byte halves.
+                        u32x4 L, H;
+#pragma unroll
+                        for (int d = 0; d < 4; ++d) {
+                            const auto sw = __builtin_amdgcn_permlane32_swap(pack_bf16x2(lo[2 * d], lo[2 * d + 1]), pack_bf16x2(hi[2 * d], hi[2 * d + 1]), false, false);
+                            L[d] = sw[0]; H[d] = sw[1];
+                        }
+                        char* db = reinterpret_cast<char*>(dst) + swap_fix;          // from column lg * 16 to ((lg & 1) * 16 + (lg >> 1) * 8)
+                        *reinterpret_cast<u32x4*>(db) = L;
+                        *reinterpret_cast<u32x4*>(db + 64) = H;
+                        __builtin_amdgcn_sched_barrier(0);
+                        continue;
+                    }
+                }
                 store8<OutT>(dst, lo);
                 store8<OutT>(dst + 8, hi);
                 __builtin_amdgcn_sched_barrier(0);      // keep the epilogue's register footprint at one 16-column group
@@ -921,6 +953,8 @@ static hipError_t launch_gemm256_t(const void* A, int64_t lda, const void* W, in
     const int tiles_m = (int)((M + BM2 - 1) / BM2), tiles_n = (N + BN2 - 1) / BN2;
     dim3 grid((unsigned)persistent_grid(tiles_m * tiles_n)), block(GEMM_THREADS);
     static const bool quad = dev_env("PCAD_GEMM_NOQUAD") == nullptr;   // PCAD_DEV=1 only: the 8-wave kernel for A/B runs
+    static const int stagger = dev_env("PCAD_GEMM_STAGGER") ? atoi(dev_env("PCAD_GEMM_STAGGER")) : 0;   // PCAD_DEV=1 only (experiment): shader cycles per K-tile and phase
+    static const bool epi_swap = dev_env("PCAD_GEMM_EPI_SWAP") != nullptr;   // PCAD_DEV=1 only (experiment): 64-byte-contiguous epilogue stores
     const int64_t esz_ = (int64_t)sizeof(T);
     if (quad && M % BM2 == 0 && N % BN2 == 0 && (C2 == nullptr || nsplit % 64 == 0) && M * lda * esz_ < ((int64_t)1 << 32) - 65536 &&
         (int64_t)N * ldw * esz_ < ((int64_t)1 << 32) - 65536) {     // unsigned 32-bit buffer offsets
@@ -932,7 +966,7 @@ static hipError_t launch_gemm256_t(const void* A, int64_t lda, const void* W, in
             attr_q = true;
         }
         hipLaunchKernelGGL(kq, grid, dim3(GEMMQ_THREADS), GEMM3_LDS, s, (const T*)A, lda, (const T*)W, ldw, (T*)C, ldc, M, N, K,
-                           tiles_m, tiles_n, (int)a_blocked, (T*)C2, nsplit, (int)out_blocked);
+                           tiles_m, tiles_n, (int)a_blocked, (T*)C2, nsplit, (int)out_blocked, (int)epi_swap, stagger);
         return hipGetLastError();
     }
     auto kr = gemm256r_kernel<T, T>;

