@@ -609,7 +609,7 @@ __global__ __launch_bounds__(GEMMQ_THREADS, 1) void gemm256q_kernel(const T* __r
                                                                     const T* __restrict__ W, int64_t ldw,
                                                                     OutT* __restrict__ C, int64_t ldc, int64_t M, int N,
                                                                     int K, int tiles_m, int tiles_n, int a_blocked,
-                                                                    OutT* __restrict__ C2, int nsplit, int out_blocked, int epi_swap, int stagger) {
+                                                                    OutT* __restrict__ C2, int nsplit, int out_blocked, int epi_swap) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -618,16 +618,6 @@ __global__ __launch_bounds__(GEMMQ_THREADS, 1) void gemm256q_kernel(const T* __r
     const int nblk = tiles_m * tiles_n;
     const int nkt = (K * (int)sizeof(T)) / ROWB;
     if ((int)blockIdx.x >= nblk) return;
-    // Every block of this persistent launch walks the same number of equal tiles, so without a nudge all CUs reach their epilogue in
-    // the same instant and the whole output (32 MB per round of tiles at 256 CUs) hits HBM as one burst while the matrix pipes
-    // wait (tools/store_pattern_microbench.hip: 5.2 us per tile at the 6.4 TB/s write ceiling, any store pattern).  A start delay
-    // of phase / 8 of one tile's duration (phase = which of 8 groups the block is in on its XCD) spreads the stores of one group
-    // over the mainloops of the others.
-    if (stagger > 0) {
-        const int phase = ((int)blockIdx.x >> 3) & 7;
-        const long long until = __builtin_readcyclecounter() + (long long)phase * stagger * nkt;
-        while (__builtin_readcyclecounter() < until) __builtin_amdgcn_s_sleep(8);
-    }
     const int my_tiles = (nblk - (int)blockIdx.x + gstride - 1) / gstride;
     const int G = my_tiles * nkt;                                 // K-tiles this block walks
 
@@ -953,8 +943,7 @@ static hipError_t launch_gemm256_t(const void* A, int64_t lda, const void* W, in
     const int tiles_m = (int)((M + BM2 - 1) / BM2), tiles_n = (N + BN2 - 1) / BN2;
     dim3 grid((unsigned)persistent_grid(tiles_m * tiles_n)), block(GEMM_THREADS);
     static const bool quad = dev_env("PCAD_GEMM_NOQUAD") == nullptr;   // PCAD_DEV=1 only: the 8-wave kernel for A/B runs
-    static const int stagger = dev_env("PCAD_GEMM_STAGGER") ? atoi(dev_env("PCAD_GEMM_STAGGER")) : 0;   // PCAD_DEV=1 only (experiment): shader cycles per K-tile and phase
-    static const bool epi_swap = dev_env("PCAD_GEMM_EPI_SWAP") != nullptr;   // PCAD_DEV=1 only (experiment): 64-byte-contiguous epilogue stores
+    static const bool epi_swap = dev_env("PCAD_GEMM_EPI_PLAIN") == nullptr;  // 64-byte-contiguous epilogue stores (PCAD_DEV=1 PCAD_GEMM_EPI_PLAIN=1: the interleaved form, for A/B)
     const int64_t esz_ = (int64_t)sizeof(T);
     if (quad && M % BM2 == 0 && N % BN2 == 0 && (C2 == nullptr || nsplit % 64 == 0) && M * lda * esz_ < ((int64_t)1 << 32) - 65536 &&
         (int64_t)N * ldw * esz_ < ((int64_t)1 << 32) - 65536) {     // unsigned 32-bit buffer offsets
@@ -966,7 +955,7 @@ static hipError_t launch_gemm256_t(const void* A, int64_t lda, const void* W, in
             attr_q = true;
         }
         hipLaunchKernelGGL(kq, grid, dim3(GEMMQ_THREADS), GEMM3_LDS, s, (const T*)A, lda, (const T*)W, ldw, (T*)C, ldc, M, N, K,
-                           tiles_m, tiles_n, (int)a_blocked, (T*)C2, nsplit, (int)out_blocked, (int)epi_swap, stagger);
+                           tiles_m, tiles_n, (int)a_blocked, (T*)C2, nsplit, (int)out_blocked, (int)epi_swap);
         return hipGetLastError();
     }
     auto kr = gemm256r_kernel<T, T>;
