@@ -9,7 +9,7 @@ import sys
 
 import pandas as pd
 
-NOTE_SRC = ("rocprofv3 --kernel-trace --pmc {FETCH_SIZE | WRITE_SIZE | SQ_*} (three separate passes) -- python3 bench.py --steps 1 "
+NOTE_SRC = ("rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE / SQ_* / TCC_EA0_RDREQ_* (separate passes) -- python3 bench.py --steps 1 "
             "--warmup 1 --cpu-seqs 0 --no-profile --batch {batch}  (l32 bf16, {rows} token-rows per launch)")
 NOTE_CORR = ("per MI355X_MICROARCH.md §HBM: FETCH_SIZE on gfx950 reports 1/2 of a wide coalesced read (checked: conv and add_rmsnorm raw "
              "values are 0.52x / 0.49x their algorithmic read bytes); WRITE_SIZE is 1:1 (scan = rows*E*2 exactly). traffic_bytes = "
