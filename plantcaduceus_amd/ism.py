@@ -82,7 +82,7 @@ def sweep_region_to_vcf(model, fasta, chrom: str, start: int, stop: int, tokeniz
     the chunk's rows appended to `out_path` in the layout `1_simulation.R:110-127` emits (one row per position x alt != ref,
     score in INFO).  Nothing larger than one chunk is ever held.  Under torch.distributed every rank computes its block of
     each chunk and rank 0 writes.  Returns the number of rows written."""
-    from .zero_shot import FastaIndex, window_from_index
+    from .zero_shot import FastaIndex
     fa = fasta if isinstance(fasta, FastaIndex) else FastaIndex(fasta)
     rank, _ = sharding.world()
     stop = min(stop, fa.length(chrom))
@@ -93,8 +93,8 @@ def sweep_region_to_vcf(model, fasta, chrom: str, start: int, stop: int, tokeniz
             out.write("##fileformat=VCFv4.2\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\n")
         for c0 in range(start, stop, chunk):
             c1 = min(stop, c0 + chunk)
-            seqs = [window_from_index(fa, chrom, p, tokenIdx) for p in range(c0, c1)]
-            probs = extract_logits(model, seqs, device, tokenIdx, tokenizer, batch_size)
+            ids = region_window_ids(fa, chrom, c0, c1, tokenizer, tokenIdx)      # [c1 - c0, 512] masked token ids, no per-window strings
+            probs = extract_logits(model, ids, device, tokenIdx, tokenizer, batch_size)
             refs = list(fa.fetch(chrom, c0, c1).upper())          # the reference base of each position, from the FASTA itself
             sc = ism_scores(probs, refs)
             if out:
@@ -106,6 +106,32 @@ def sweep_region_to_vcf(model, fasta, chrom: str, start: int, stop: int, tokeniz
         if fa is not fasta:
             fa.close()
     return rows
+
+
+def region_window_ids(fa, chrom: str, start: int, stop: int, tokenizer, tokenIdx: int = 255, length: int = 512) -> np.ndarray:
+    """The windows `window_for` / `window_from_index` cut for positions [start, stop) of `chrom` — [pos - tokenIdx,
+    pos + length - tokenIdx), upper-cased, N-padded at the chromosome ends (reference src/zero_shot_score.py:187-198) — as ONE
+    fetch of the covering bases, ONE pass of the tokeniser's byte -> id table and a sliding-window view: int32 [stop - start, length]
+    with column tokenIdx set to [MASK].  O(region) host work instead of O(region x length) string slicing and joining."""
+    n = stop - start
+    if n <= 0:
+        return np.zeros((0, length), dtype=np.int32)
+    lo, hi = start - tokenIdx, stop - 1 + (length - tokenIdx)               # bases [lo, hi) cover every window
+    seq = fa.fetch(chrom, max(lo, 0), hi)                                   # clipped to the chromosome
+    region = "N" * max(0, -lo) + seq.upper()
+    region = region + "N" * (hi - lo - len(region))
+    ids = tokenizer.encode_batch([region])[0] if hasattr(tokenizer, "encode_batch") else np.asarray(tokenizer(region)["input_ids"], dtype=np.int32)
+    win = np.lib.stride_tricks.sliding_window_view(np.ascontiguousarray(ids, dtype=np.int32), length)[:n].copy()
+    # the reference's quirk for a chromosome shorter than a window around the position: when BOTH ends overflow it pads the
+    # whole deficit on the left (`rjust`, :195-196), so the position is no longer at tokenIdx — those rows follow it literally
+    clen = fa.length(chrom)
+    add = length - tokenIdx
+    for p in range(start, min(stop, tokenIdx)):
+        if p + add > clen:
+            from .zero_shot import window_from_index
+            win[p - start] = tokenize_masked([window_from_index(fa, chrom, p, tokenIdx, length)], tokenizer, None)[0]
+    win[:, tokenIdx] = tokenizer.mask_token_id
+    return win
 
 
 def ism_scores(probs: np.ndarray, ref_bases: Sequence[str]) -> np.ndarray:

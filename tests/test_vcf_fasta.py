@@ -187,3 +187,27 @@ def test_cli_input_vcf_on_gpu(tmp_path):
             assert float(v) == pytest.approx(want, abs=5e-2)              # bf16 model (dtype policy), log-ratio
         else:
             assert v == "."
+
+
+def test_region_window_ids_equal_per_position_windows(tmp_path):
+    """the O(region) window builder of the ISM sweep (one fetch, one LUT pass, sliding-window view) equals tokenising the
+    reference's per-position windows (`window_for`: N padding at both chromosome ends, upper-casing, [MASK] at tokenIdx)."""
+    g = {"c": "".join(np.random.default_rng(5).choice(list("ACGTacgtN"), size=900))}
+    fa = tmp_path / "r.fa"
+    _write_fasta(fa, g)
+    tok = CaduceusTokenizer()
+    ix = zero_shot.FastaIndex(str(fa))
+    for a, b in ((0, 40), (250, 300), (860, 900), (0, 900)):
+        got = ism.region_window_ids(ix, "c", a, b, tok, 255)
+        want = zero_shot.tokenize_masked([zero_shot.window_for(g["c"], p, 255) for p in range(a, b)], tok, 255)
+        assert got.shape == (b - a, 512) and np.array_equal(got, want)
+    ix.close()
+    # a chromosome shorter than one window: both ends overflow and the reference pads the whole deficit on the LEFT (:195-196)
+    g2 = {"s": "ACGTTGCAAC" * 30}
+    fa2 = tmp_path / "s.fa"
+    _write_fasta(fa2, g2)
+    ix2 = zero_shot.FastaIndex(str(fa2))
+    got = ism.region_window_ids(ix2, "s", 0, 300, tok, 255)
+    want = zero_shot.tokenize_masked([zero_shot.window_for(g2["s"], p, 255) for p in range(300)], tok, 255)
+    assert np.array_equal(got, want)
+    ix2.close()

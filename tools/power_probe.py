@@ -1,0 +1,123 @@
+#!/usr/bin/env python3
+"""Developer tool (GPU box): board power and shader clock while ONE kernel class of the forward runs back to back, and during the
+whole forward — evidence for DESIGN.md's reading that the step is bound by the board's power budget.  Samples whatever the box lets
+an ordinary user read: hwmon `power1_average` / `power1_input` (microwatts), `pp_dpm_sclk` (current level marked '*'), else
+`rocm-smi --showpower --showclocks --json`.          python tools/power_probe.py > profiles/r03_power_probe.txt
+"""
+import glob
+import json
+import os
+import subprocess
+import sys
+import threading
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def find(pattern):
+    return sorted(glob.glob(pattern))
+
+
+POWER_FILES = find("/sys/class/drm/card*/device/hwmon/hwmon*/power1_average") + find("/sys/class/drm/card*/device/hwmon/hwmon*/power1_input")
+SCLK_FILES = find("/sys/class/drm/card*/device/pp_dpm_sclk")
+CAP_FILES = find("/sys/class/drm/card*/device/hwmon/hwmon*/power1_cap")
+
+
+def read_power():
+    for f in POWER_FILES:
+        try:
+            return float(open(f).read()) / 1e6
+        except Exception:
+            pass
+    return None
+
+
+def read_sclk():
+    for f in SCLK_FILES:
+        try:
+            for ln in open(f):
+                if "*" in ln:
+                    return ln.split(":")[1].replace("*", "").strip()
+        except Exception:
+            pass
+    return None
+
+
+def smi():
+    try:
+        r = subprocess.run(["rocm-smi", "--showpower", "--showclocks", "--json"], capture_output=True, text=True, timeout=20)
+        return json.loads(r.stdout)
+    except Exception as e:
+        return {"error": repr(e)}
+
+
+class Sampler(threading.Thread):
+    def __init__(self):
+        super().__init__(daemon=True)
+        self.p, self.c, self.stop = [], [], False
+
+    def run(self):
+        while not self.stop:
+            w = read_power()
+            if w is not None:
+                self.p.append(w)
+            c = read_sclk()
+            if c:
+                self.c.append(c)
+            time.sleep(0.02)
+
+
+def measure(name, fn, seconds=3.0):
+    import torch
+    fn(); torch.cuda.synchronize()
+    s = Sampler(); s.start()
+    t0 = time.perf_counter(); n = 0
+    while time.perf_counter() - t0 < seconds:
+        for _ in range(8):
+            fn()
+        torch.cuda.synchronize(); n += 8
+    dt = time.perf_counter() - t0
+    s.stop = True; s.join()
+    p = s.p[len(s.p) // 4:]                     # drop the ramp
+    pw = "%.0f W avg, %.0f max (%d samples)" % (sum(p) / len(p), max(p), len(p)) if p else "power: not readable"
+    clk = ("sclk levels seen: " + ", ".join(sorted(set(s.c)))) if s.c else "sclk: not readable"
+    extra = ""
+    if not p:
+        j = smi()
+        extra = "  rocm-smi: " + json.dumps(j)[:300]
+    print(f"{name:34s} {1e3 * dt / n:8.3f} ms per call   {pw}   {clk}{extra}", flush=True)
+
+
+def main():
+    import numpy as np
+    import torch
+    from plantcaduceus_amd import ops
+    from plantcaduceus_amd.checkpoint import make_config, synthetic_state_dict
+    from plantcaduceus_amd.engine import Engine
+    print("power files:", POWER_FILES, " cap:", [open(f).read().strip() for f in CAP_FILES], " sclk files:", SCLK_FILES)
+    print("rocm-smi idle:", json.dumps(smi())[:400])
+    dev = torch.device("cuda:0")
+    cfg = make_config("l32")
+    eng = Engine(cfg, synthetic_state_dict(cfg, seed=1234, stress=False), torch.bfloat16, dev)
+    ids = np.random.default_rng(0).integers(3, 7, size=(1024, 512), dtype=np.int32); ids[:, 255] = 1
+    ids = torch.from_numpy(ids).to(dev)
+    measure("idle (sleep)", lambda: time.sleep(0.05), 1.5)
+    measure("whole forward, 1024 windows", lambda: eng.forward(ids, positions=[255]), 6.0)
+    M = 262144
+    x = torch.randn(M, 1024, device=dev).bfloat16(); w_in = (torch.randn(4096, 1024, device=dev) / 32).bfloat16()
+    measure("in_proj GEMM 262144x4096x1024", lambda: ops.linear(x, w_in))
+    y = torch.randn(M, 2048, device=dev).bfloat16(); w_out = (torch.randn(1024, 2048, device=dev) / 45).bfloat16()
+    measure("out_proj GEMM 262144x1024x2048", lambda: ops.linear(y, w_out))
+    res = torch.randn(M, 1024, device=dev); nw = torch.ones(1024, device=dev)
+    measure("add + RMSNorm 262144 rows", lambda: ops.rms_norm_fn(x, nw, residual=res, eps=1e-5, prenorm=True, residual_in_fp32=True))
+    S, L, E, R = 256, 512, 2048, 64
+    u = torch.randn(S, E, L, device=dev).bfloat16(); z = torch.randn(S, E, L, device=dev).bfloat16()
+    dtl = (torch.randn(S, L, R, device=dev) * 0.1).bfloat16(); wdt = (torch.randn(E, R, device=dev) / 8).bfloat16()
+    A = -torch.rand(E, 16, device=dev) - 0.5; Bm = torch.randn(S, 16, L, device=dev).bfloat16(); Cm = torch.randn(S, 16, L, device=dev).bfloat16()
+    Dk = torch.ones(E, device=dev); db = torch.full((E,), -4.0, device=dev)
+    measure("selective scan + dt_proj, 131072 rows", lambda: ops.selective_scan_dtproj_fn(u, dtl, wdt, A, Bm, Cm, Dk, z=z, delta_bias=db))
+
+
+if __name__ == "__main__":
+    main()
