@@ -260,6 +260,20 @@ __global__ __launch_bounds__(CX_THREADS, 2) void convx_kernel(const T* __restric
         // registers: a spill here costs far more than its load - a scratch reload shares vmcnt with the LDS-DMAs in flight
         // and drains them).  Channel pairs go through the packed fp32 pipe: taps, bias and window as (e, e+1) pairs.
         constexpr int HC = CPC / 2;
+        // ZFILL (the engine's case): the 7-row window of BOTH halves in one 16-byte read per row (7 ds_read_b128 instead of 14
+        // ds_read_b64: half the LDS cycles of the window reads — a 2-way instead of a 4-way bank conflict between the rows a lane
+        // group touches — and one LDS round trip per K-tile instead of two), kept packed: 28 registers.  The masked (ragged
+        // length) form keeps the two 8-byte reads: with the masks it no longer fits the register file.
+#ifdef PCAD_CX_B64
+        constexpr bool B128 = false;
+#else
+        constexpr bool B128 = ZFILL;
+#endif
+        u32x4 rwin[7];
+        if constexpr (B128) {
+#pragma unroll
+            for (int j = 0; j < 7; ++j) rwin[j] = *reinterpret_cast<const u32x4*>(raw + (qbase + j) * CX_ROWB + c8 * 16);
+        }
         auto conv_half = [&](int h) __attribute__((always_inline)) {
             f32x2_t wt[4][HC / 2], bias[HC / 2];
 #pragma unroll
@@ -274,10 +288,15 @@ __global__ __launch_bounds__(CX_THREADS, 2) void convx_kernel(const T* __restric
             for (int j = 0; j < 7; ++j) {
                 const int q = qbase + j;
                 const int t = t0 - 3 + q;
-                u32x2 r = *reinterpret_cast<const u32x2*>(raw + q * CX_ROWB + c8 * 16 + h * 8);
-                if (!ZFILL) {
-                    const unsigned keep = 0u - (unsigned)((unsigned)t < (unsigned)L);   // zero padding at the sequence ends,
-                    r &= u32x2{keep, keep};                                              // branch-free (loads stay batched)
+                u32x2 r;
+                if constexpr (B128) {
+                    r = u32x2{rwin[j][2 * h], rwin[j][2 * h + 1]};
+                } else {
+                    r = *reinterpret_cast<const u32x2*>(raw + q * CX_ROWB + c8 * 16 + h * 8);
+                    if (!ZFILL) {
+                        const unsigned keep = 0u - (unsigned)((unsigned)t < (unsigned)L);   // zero padding at the sequence ends,
+                        r &= u32x2{keep, keep};                                              // branch-free (loads stay batched)
+                    }
                 }
                 float w1[HC];
                 Chunk<T>::unpack_half(r, w1);

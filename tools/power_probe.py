@@ -19,9 +19,31 @@ def find(pattern):
     return sorted(glob.glob(pattern))
 
 
-POWER_FILES = find("/sys/class/drm/card*/device/hwmon/hwmon*/power1_average") + find("/sys/class/drm/card*/device/hwmon/hwmon*/power1_input")
-SCLK_FILES = find("/sys/class/drm/card*/device/pp_dpm_sclk")
-CAP_FILES = find("/sys/class/drm/card*/device/hwmon/hwmon*/power1_cap")
+POWER_FILES, SCLK_FILES, CAP_FILES = [], [], []
+
+
+def select_card(bdf: str):
+    """sysfs files of the card whose PCI address is `bdf` (the node exposes every GPU's sysfs; only one is ours)"""
+    global POWER_FILES, SCLK_FILES, CAP_FILES
+    for card in find("/sys/class/drm/card*"):
+        try:
+            real = os.path.realpath(os.path.join(card, "device"))
+        except OSError:
+            continue
+        if bdf.lower() in real.lower():
+            POWER_FILES = find(card + "/device/hwmon/hwmon*/power1_average") + find(card + "/device/hwmon/hwmon*/power1_input")
+            SCLK_FILES = find(card + "/device/pp_dpm_sclk")
+            CAP_FILES = find(card + "/device/hwmon/hwmon*/power1_cap")
+            return card
+    return None
+
+
+def device_bdf() -> str:
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    buf = ctypes.create_string_buffer(64)
+    hip.hipDeviceGetPCIBusId(buf, 64, 0)
+    return buf.value.decode()
 
 
 def read_power():
@@ -81,7 +103,8 @@ def measure(name, fn, seconds=3.0):
     s.stop = True; s.join()
     p = s.p[len(s.p) // 4:]                     # drop the ramp
     pw = "%.0f W avg, %.0f max (%d samples)" % (sum(p) / len(p), max(p), len(p)) if p else "power: not readable"
-    clk = ("sclk levels seen: " + ", ".join(sorted(set(s.c)))) if s.c else "sclk: not readable"
+    mhz = sorted(float(c.lower().replace("mhz", "")) for c in s.c[len(s.c) // 4:] if c.lower().endswith("mhz"))
+    clk = ("sclk MHz min / median / max: %.0f / %.0f / %.0f" % (mhz[0], mhz[len(mhz) // 2], mhz[-1])) if mhz else "sclk: not readable"
     extra = ""
     if not p:
         j = smi()
@@ -95,7 +118,11 @@ def main():
     from plantcaduceus_amd import ops
     from plantcaduceus_amd.checkpoint import make_config, synthetic_state_dict
     from plantcaduceus_amd.engine import Engine
-    print("power files:", POWER_FILES, " cap:", [open(f).read().strip() for f in CAP_FILES], " sclk files:", SCLK_FILES)
+    torch.cuda.init()
+    bdf = device_bdf()
+    card = select_card(bdf)
+    print("device 0 PCI address:", bdf, " sysfs card:", card)
+    print("power files:", POWER_FILES, " cap (uW):", [open(f).read().strip() for f in CAP_FILES], " sclk files:", SCLK_FILES)
     print("rocm-smi idle:", json.dumps(smi())[:400])
     dev = torch.device("cuda:0")
     cfg = make_config("l32")
