@@ -46,21 +46,26 @@ typedef __attribute__((address_space(8))) void* rsrc_t;
 __device__ __forceinline__ auto make_rsrc(const void* base, uint32_t bytes) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
 }
+// every row of u / z / y is read or written exactly once per launch and the tensors (2 GiB each at the benchmark chunk) are far
+// larger than the caches: the accesses carry the streaming hint (slc / "nt"), which keeps them from displacing the dt_proj, B|C and
+// weight lines other waves re-use (+0.5 % end to end in two interleaved same-box pairs, and the GEMMs after the scan run
+// faster; loads-only or stores-only: no effect)
+constexpr int SCAN_AUX = 2;
 template <typename T> struct BufIO;
 template <> struct BufIO<bf16_t> {
     template <typename R> static __device__ __forceinline__ bf16_t load(R r, int voff, uint32_t soff) {
-        return (bf16_t)__builtin_amdgcn_raw_buffer_load_b16(r, voff, (int)soff, 0);
+        return (bf16_t)__builtin_amdgcn_raw_buffer_load_b16(r, voff, (int)soff, SCAN_AUX);
     }
     template <typename R> static __device__ __forceinline__ void store(bf16_t v, R r, int voff, uint32_t soff) {
-        __builtin_amdgcn_raw_buffer_store_b16(v, r, voff, (int)soff, 0);
+        __builtin_amdgcn_raw_buffer_store_b16(v, r, voff, (int)soff, SCAN_AUX);
     }
 };
 template <> struct BufIO<float> {
     template <typename R> static __device__ __forceinline__ float load(R r, int voff, uint32_t soff) {
-        return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, voff, (int)soff, 0));
+        return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, voff, (int)soff, SCAN_AUX));
     }
     template <typename R> static __device__ __forceinline__ void store(float v, R r, int voff, uint32_t soff) {
-        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, voff, (int)soff, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, voff, (int)soff, SCAN_AUX);
     }
 };
 
