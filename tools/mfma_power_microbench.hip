@@ -1,0 +1,114 @@
+// Developer tool (GPU box): what do the matrix pipes ALONE sustain under this board's power cap?  One wave per SIMD (256 blocks x
+// 256 threads) issues independent v_mfma_f32_16x16x32_bf16 on register-resident random operands for a few seconds - no LDS, no
+// DMA, no HBM traffic - while the host thread samples the card's own hwmon power1_input and pp_dpm_sclk.  Prints the sustained
+// TFLOP/s, the effective shader clock (s_memtime ticks / wall) and the power: the ceiling the GEMM kernels are to be read against.
+//   hipcc --offload-arch=gfx950 -O3 -o /tmp/mfma_power tools/mfma_power_microbench.hip && /tmp/mfma_power [zero]
+#include <hip/hip_runtime.h>
+#include <dirent.h>
+#include <limits.h>
+#include <stdlib.h>
+#include <unistd.h>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(256, 1) void mfma_only(float* out, long long* cyc, int iters, unsigned seed, int zero) {
+    u32x4 a[4], b[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        unsigned s = seed * 2654435761u + threadIdx.x * 40503u + i * 97u + blockIdx.x * 7919u;
+        for (int d = 0; d < 4; ++d) {
+            s = s * 1664525u + 1013904223u;
+            a[i][d] = zero ? 0u : ((s & 0x7fff7fffu) | 0x3c003c00u) & 0x3fff3fffu;      // bf16 pairs of moderate magnitude
+            s = s * 1664525u + 1013904223u;
+            b[i][d] = zero ? 0u : ((s & 0x7fff7fffu) | 0x3c003c00u) & 0x3fff3fffu;
+        }
+    }
+    f32x4 acc[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    long long t0 = __builtin_readcyclecounter();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[i * 4 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a[i]), __builtin_bit_cast(bf16x8_t, b[j]),
+                                                                         acc[i * 4 + j], 0, 0, 0);
+    }
+    long long t1 = __builtin_readcyclecounter();
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s += acc[i][0] + acc[i][3];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+    if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
+}
+
+static std::string find_card(const std::string& bdf) {
+    DIR* d = opendir("/sys/class/drm");
+    if (!d) return "";
+    std::string res;
+    while (dirent* e = readdir(d)) {
+        if (strncmp(e->d_name, "card", 4) || strchr(e->d_name, '-')) continue;
+        char real[PATH_MAX];
+        std::string p = std::string("/sys/class/drm/") + e->d_name + "/device";
+        if (realpath(p.c_str(), real) && strcasestr(real, bdf.c_str())) res = std::string("/sys/class/drm/") + e->d_name;
+    }
+    closedir(d);
+    return res;
+}
+static double read_power(const std::string& card) {
+    for (int h = 0; h < 32; ++h) {
+        std::string f = card + "/device/hwmon/hwmon" + std::to_string(h) + "/power1_input";
+        if (FILE* fp = fopen(f.c_str(), "r")) { double v = 0; int ok = fscanf(fp, "%lf", &v); fclose(fp); if (ok == 1) return v / 1e6; }
+    }
+    return -1;
+}
+static double read_sclk(const std::string& card) {
+    std::string f = card + "/device/pp_dpm_sclk";
+    FILE* fp = fopen(f.c_str(), "r");
+    if (!fp) return -1;
+    char line[128]; double mhz = -1;
+    while (fgets(line, sizeof(line), fp)) if (strchr(line, '*')) { const char* c = strchr(line, ':'); if (c) mhz = atof(c + 1); }
+    fclose(fp);
+    return mhz;
+}
+
+int main(int argc, char** argv) {
+    const int zero = argc > 1 && !strcmp(argv[1], "zero");
+    char bdf[64] = "";
+    (void)hipDeviceGetPCIBusId(bdf, sizeof(bdf), 0);
+    const std::string card = find_card(bdf);
+    float* out; long long* cyc;
+    (void)hipMalloc(&out, 256 * 256 * 4); (void)hipMalloc(&cyc, 256 * 8);
+    mfma_only<<<256, 256>>>(out, cyc, 1000, 1u, zero);
+    (void)hipDeviceSynchronize();
+    const int iters = 6000000;                                  // ~3 s
+    hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    (void)hipEventRecord(e0);
+    mfma_only<<<256, 256>>>(out, cyc, iters, 2u, zero);
+    (void)hipEventRecord(e1);
+    std::vector<double> pw, ck;
+    while (hipEventQuery(e1) == hipErrorNotReady) {
+        const double p = read_power(card), c = read_sclk(card);
+        if (p > 0) pw.push_back(p);
+        if (c > 0) ck.push_back(c);
+        usleep(20000);
+    }
+    (void)hipEventSynchronize(e1);
+    float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+    std::vector<long long> h(256); (void)hipMemcpy(h.data(), cyc, 256 * 8, hipMemcpyDeviceToHost);
+    double avg = 0; for (auto v : h) avg += v; avg /= 256;
+    const double flops = 2.0 * 16 * 16 * 32 * 16 * (double)iters * 256 * 4;      // 16 MFMAs per iteration per wave, 1024 waves
+    double pa = 0, pm = 0; size_t n0 = pw.size() / 4; for (size_t i = n0; i < pw.size(); ++i) { pa += pw[i]; if (pw[i] > pm) pm = pw[i]; }
+    double ca = 0; size_t c0 = ck.size() / 4; for (size_t i = c0; i < ck.size(); ++i) ca += ck[i];
+    printf("%s operands, 1 wave per SIMD, %d x 16 independent v_mfma_f32_16x16x32_bf16 per wave: %.1f ms -> %.0f TFLOP/s; effective clock %.2f GHz "
+           "(s_memtime / wall); card %s (%s): power %.0f W avg, %.0f max over %zu samples; sclk %.0f MHz avg\n",
+           zero ? "all-zero" : "random", iters, ms, flops / (ms * 1e-3) / 1e12, avg / (ms * 1e-3) / 1e9, card.c_str(), bdf,
+           pw.size() > n0 ? pa / (pw.size() - n0) : -1.0, pm, pw.size(), ck.size() > c0 ? ca / (ck.size() - c0) : -1.0);
+    return 0;
+}
