@@ -182,3 +182,21 @@ def test_bench_work_formulas_match_survey_8d():
                     + 2 * 2.0 * rows * cfg.dt_rank * cfg.d_inner)
         assert abs(fl_layer * cfg.n_layer / f - 1) < 1e-9
     assert len(bench.source_hash()) == 16
+
+
+def test_effective_batch_keeps_an_explicit_batch_size():
+    """`-batchSize` given by the user bounds memory as in the reference and is used as is; only the default is raised to the
+    model's preferred batch."""
+    from plantcaduceus_amd import zero_shot
+
+    class M:
+        def preferred_batch_size(self, L):
+            return 1024
+    assert zero_shot.effective_batch(M(), 128, 512) == 1024
+    assert zero_shot.effective_batch(M(), 128, 512, explicit=True) == 128
+    assert zero_shot.effective_batch(M(), 4096, 512) == 4096
+    assert zero_shot.effective_batch(object(), 128, 512) == 128
+    a = zero_shot.parse_args(["-input-table", "x.tsv"])
+    assert a.batchSize == 128 and a.batchExplicit is False
+    b = zero_shot.parse_args(["-input-table", "x.tsv", "-batchSize", "7"])
+    assert b.batchSize == 7 and b.batchExplicit is True

@@ -211,3 +211,17 @@ def test_region_window_ids_equal_per_position_windows(tmp_path):
     want = zero_shot.tokenize_masked([zero_shot.window_for(g2["s"], p, 255) for p in range(300)], tok, 255)
     assert np.array_equal(got, want)
     ix2.close()
+
+
+def test_fasta_index_rejects_blank_line_inside_record(tmp_path):
+    """a blank line inside a record shifts every later base under the uniform-line-width arithmetic of fetch(): the index
+    builder must refuse it (samtools faidx does), while a blank line at the END of a record is harmless."""
+    bad = tmp_path / "bad.fa"
+    bad.write_text(">c1\nACGTACGT\n\nACGTAC\n>c2\nAAAA\n")
+    with pytest.raises(ValueError, match="cannot index"):
+        zero_shot.FastaIndex(str(bad))
+    ok = tmp_path / "ok.fa"
+    ok.write_text(">c1\nACGTACGT\nACGTAC\n\n>c2\nAAAA\nCC\n\n")
+    ix = zero_shot.FastaIndex(str(ok))
+    assert ix.fetch("c1", 6, 12) == "GTACGT" and ix.fetch("c2", 2, 6) == "AACC" and ix.length("c1") == 14
+    ix.close()
