@@ -62,9 +62,20 @@ def extract_embeddings(model, sequences, device, tokenIdx: int, tokenizer=None, 
     return out
 
 
-def save_embedding_cache(path: str, **arrays):
-    """np.savez_compressed with the reference's keys (`train`, `valid`, `test`: src/train_XGBoost.py:186,199,221)."""
+def save_embedding_cache(path: str, compresslevel: int = 1, **arrays):
+    """The reference's cache file (`np.savez_compressed` with keys `train`, `valid`, `test`: src/train_XGBoost.py:186,199,221),
+    readable by `np.load` exactly as the reference reads it, written with a chosen deflate level (0 = stored).  fp32 embeddings
+    hardly compress (7 %) and deflate runs at ~20 MB/s on one core at any level (2.3 s at level 1, 2.8 s at numpy's default, for
+    the 51 MB of one rank's share of a chunk; 6 s on the GPU box's slower cores, profiles/r03_e2e_embed.json), so callers that
+    extract chunk after chunk write the file on a worker thread while the next chunk runs (xgb_predict.py)."""
+    import zipfile
     bad = set(arrays) - {"train", "valid", "test"}
     if bad:
         raise ValueError(f"unexpected cache keys {sorted(bad)}")
-    np.savez_compressed(path, **arrays)
+    if not path.endswith(".npz"):
+        path = path + ".npz"                       # np.savez_compressed appends the suffix the same way
+    comp = zipfile.ZIP_DEFLATED if compresslevel > 0 else zipfile.ZIP_STORED
+    with zipfile.ZipFile(path, "w", compression=comp, compresslevel=compresslevel if compresslevel > 0 else None, allowZip64=True) as zf:
+        for key, arr in arrays.items():
+            with zf.open(key + ".npy", "w", force_zip64=True) as f:
+                np.lib.format.write_array(f, np.asanyarray(arr), allow_pickle=False)

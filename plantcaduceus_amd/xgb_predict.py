@@ -83,11 +83,17 @@ def parse_args(argv: Optional[Sequence[str]] = None):
     p.add_argument("-classifier", type=str, help="The directory of trained XGBoost models")
     p.add_argument("-output", type=str, help="The directory of output")
     p.add_argument("-device", type=str, default="cuda:0", help="The device to run the model")
-    p.add_argument("-batchSize", type=int, default=128, help="The batch size for the model")
+    p.add_argument("-batchSize", type=int, default=None,
+                   help="The batch size for the model (default 128 as in the reference, raised to the engine's preferred batch; a "
+                        "value given here is used as is)")
     p.add_argument("-tokenIdx", type=int, default=255, help="The index of the nucleotide")
     p.add_argument("-save_memory", action="store_true", help="Flag to save memory, it only works for testing")
     p.add_argument("-chunk_size", type=int, default=100000, help="The chunk size for testing, with -save_memory")
-    return p.parse_args(argv)
+    args = p.parse_args(argv)
+    args.batchExplicit = args.batchSize is not None
+    if args.batchSize is None:
+        args.batchSize = 128
+    return args
 
 
 def main(argv: Optional[Sequence[str]] = None):
@@ -105,13 +111,18 @@ def main(argv: Optional[Sequence[str]] = None):
     prefix = os.path.basename(args.test).split(".")[0]
     rank, _ = sharding.world()
 
+    from concurrent.futures import ThreadPoolExecutor
+    from .embeddings import save_embedding_cache
+    writer = ThreadPoolExecutor(max_workers=1)          # cache files are written (deflate, one core) while the next chunk runs
+    pending = []
+
     def embeddings_for(seqs, cache):
         if os.path.exists(cache):
             logging.info(f"Found pre-computed embeddings, loading from file {cache}")
             return np.load(cache)["test"]
-        emb = extract_embeddings(model, seqs, args.device, args.tokenIdx, tokenizer, args.batchSize)
+        emb = extract_embeddings(model, seqs, args.device, args.tokenIdx, tokenizer, args.batchSize, args.batchExplicit)
         if rank == 0:
-            np.savez_compressed(cache, test=emb)
+            pending.append(writer.submit(save_embedding_cache, cache, test=emb))
         return emb
 
     if args.save_memory:
@@ -122,6 +133,9 @@ def main(argv: Optional[Sequence[str]] = None):
         predictions = np.concatenate(preds, axis=0) if preds else np.zeros(0, dtype=np.float32)
     else:
         predictions = infer_xgboost_model(clf, embeddings_for(test_sequences, os.path.join(args.output, prefix + "_embeddings.npz")))
+    for fut in pending:
+        fut.result()                                     # surface write errors; the files are complete before the run ends
+    writer.shutdown()
     if rank == 0:
         pd.DataFrame({"label": test_labels, "prediction": predictions}).to_csv(
             os.path.join(args.output, f"{prefix}_predictions.tsv"), sep="\t", index=False)
