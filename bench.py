@@ -24,7 +24,6 @@ Prints ONE JSON line on rank 0 (contract in the task statement) with extra objec
   cpu_baseline  the C/OpenMP oracle port (oracle/c) timed on this host's cores on a bounded sample.
 """
 import argparse
-import hashlib
 import json
 import os
 import subprocess

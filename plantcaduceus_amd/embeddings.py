@@ -16,6 +16,7 @@ scope; `save_embedding_cache` keeps the reference's .npz key
 from __future__ import annotations
 
 import logging
+import os
 
 import numpy as np
 import torch
@@ -75,7 +76,19 @@ def save_embedding_cache(path: str, compresslevel: int = 1, **arrays):
     if not path.endswith(".npz"):
         path = path + ".npz"                       # np.savez_compressed appends the suffix the same way
     comp = zipfile.ZIP_DEFLATED if compresslevel > 0 else zipfile.ZIP_STORED
-    with zipfile.ZipFile(path, "w", compression=comp, compresslevel=compresslevel if compresslevel > 0 else None, allowZip64=True) as zf:
-        for key, arr in arrays.items():
-            with zf.open(key + ".npy", "w", force_zip64=True) as f:
-                np.lib.format.write_array(f, np.asanyarray(arr), allow_pickle=False)
+    # written beside the final name and renamed once the archive is closed: a run that dies mid-write (the writer may be a
+    # background thread that lives for a whole chunk's compute time) leaves a .tmp file, never a truncated cache that the next
+    # run would find with os.path.exists() and fail to read
+    tmp = path + ".tmp"
+    try:
+        with zipfile.ZipFile(tmp, "w", compression=comp, compresslevel=compresslevel if compresslevel > 0 else None, allowZip64=True) as zf:
+            for key, arr in arrays.items():
+                with zf.open(key + ".npy", "w", force_zip64=True) as f:
+                    np.lib.format.write_array(f, np.asanyarray(arr), allow_pickle=False)
+        os.replace(tmp, path)
+    except BaseException:
+        try:
+            os.unlink(tmp)
+        except OSError:
+            pass
+        raise

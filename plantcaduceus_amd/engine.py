@@ -280,11 +280,18 @@ class Engine:
         if self._status_event.query() and int(self._status_host[0]) != 0:
             self._raise_status(int(self._status_host[0]))
 
-    def check_status(self):
-        """Blocking: waits for the forwards enqueued so far and raises IndexError if any of them saw an invalid token id or
-        position (the reference's nn.Embedding / indexing errors).  Host loops call this where they read results back."""
+    def status_bits(self) -> int:
+        """Blocking, non-raising: waits for the forwards enqueued so far and returns their accumulated status bits (0 = clean).
+        Distributed host loops reduce this over the ranks first, so that every rank raises together (zero_shot.check_model_inputs)."""
         self._status_event.synchronize()
-        bits = int(self._status_host[0])
+        return int(self._status_host[0])
+
+    def check_status(self, bits: Optional[int] = None):
+        """Blocking: waits for the forwards enqueued so far and raises IndexError if any of them saw an invalid token id or
+        position (the reference's nn.Embedding / indexing errors).  Host loops call this where they read results back.
+        bits: status bits already collected (e.g. OR-ed over the ranks of a process group) instead of this engine's own."""
+        if bits is None:
+            bits = self.status_bits()
         if bits:
             self._raise_status(bits)
 

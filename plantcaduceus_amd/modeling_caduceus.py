@@ -202,29 +202,33 @@ class CaduceusPreTrainedModel(PreTrainedModel):
         """Windows per forward call the host loops batch up to when the user gave no `-batchSize`: two chunks of 2^31 bytes per
         [rows, d_inner] tensor (1024 windows of 512 bp at l32 bf16 = the benchmark's batch, two 512-window chunks of the
         layer-stack walk sharing one 15.3 GB workspace; see csrc/api.hip — the engine's own cap per chunk is (2^32 - 2 MiB) bytes,
-        and it splits a batch evenly into the fewest chunks, so this batch never runs as ONE chunk of twice the workspace),
-        clamped to what fits in a third of the device's free memory (~30 MB of workspace per window at l32 bf16)."""
+        and it splits a batch evenly into the fewest chunks), halved until the workspace the engine would really allocate for it
+        (`pcad_workspace_bytes`, i.e. one chunk) fits in a third of the device's free memory."""
         p = self._backbone_owner().caduceus_param()
         L = max(1, int(seqlen))
         rows = (1 << 31) // (self.config.d_inner * p.element_size())
         want = max(1, 2 * (rows // (2 * L)))
-        cap_rows = (((1 << 32) - (2 << 20)) // (self.config.d_inner * p.element_size())) & ~7
-        if want <= cap_rows // (2 * L):                      # would fit ONE chunk (narrow models): keep it at two chunks' worth of rows
-            want = max(1, min(want, cap_rows // (2 * L)))
         if p.device.type == "cuda":
             try:
                 free, _ = torch.cuda.mem_get_info(p.device)
-                per_window = 2 * L * (self.config.d_inner * 6 + self.config.d_model * 4) * p.element_size() * 1.25
-                want = max(1, min(want, int(free / 3 / per_window) * 2))
+                eng = self._engine()
+                while want > 1 and eng.lib.pcad_workspace_bytes(eng._h, want, L) > free // 3:
+                    want //= 2
             except Exception:
                 pass
         return want
 
-    def check_status(self):
-        """Deferred input validation of the engine (token ids / positions outside their range raise IndexError here)."""
+    def check_status(self, bits=None):
+        """Deferred input validation of the engine (token ids / positions outside their range raise IndexError here).
+        bits: status bits to raise for instead of this engine's own (the OR over the ranks of a process group)."""
         eng = getattr(self._backbone_owner(), "_pcad_engine", None)
         if eng is not None:
-            eng.check_status()
+            eng.check_status(bits)
+
+    def status_bits(self) -> int:
+        """The engine's accumulated input-validation bits (blocking, non-raising; 0 when no forward ran yet)."""
+        eng = getattr(self._backbone_owner(), "_pcad_engine", None)
+        return eng.status_bits() if eng is not None else 0
 
     # -- engine plumbing ----------------------------------------------------------------------------
     def _backbone_owner(self):

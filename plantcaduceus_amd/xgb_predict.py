@@ -125,17 +125,22 @@ def main(argv: Optional[Sequence[str]] = None):
             pending.append(writer.submit(save_embedding_cache, cache, test=emb))
         return emb
 
-    if args.save_memory:
-        preds = []
-        for i in range(0, len(test_sequences), args.chunk_size):
-            emb = embeddings_for(test_sequences[i:i + args.chunk_size], os.path.join(args.output, f"{prefix}_chunk_{i}_embeddings.npz"))
-            preds.append(infer_xgboost_model(clf, emb))
-        predictions = np.concatenate(preds, axis=0) if preds else np.zeros(0, dtype=np.float32)
-    else:
-        predictions = infer_xgboost_model(clf, embeddings_for(test_sequences, os.path.join(args.output, prefix + "_embeddings.npz")))
-    for fut in pending:
-        fut.result()                                     # surface write errors; the files are complete before the run ends
-    writer.shutdown()
+    try:
+        if args.save_memory:
+            preds = []
+            for i in range(0, len(test_sequences), args.chunk_size):
+                emb = embeddings_for(test_sequences[i:i + args.chunk_size], os.path.join(args.output, f"{prefix}_chunk_{i}_embeddings.npz"))
+                preds.append(infer_xgboost_model(clf, emb))
+            predictions = np.concatenate(preds, axis=0) if preds else np.zeros(0, dtype=np.float32)
+        else:
+            predictions = infer_xgboost_model(clf, embeddings_for(test_sequences, os.path.join(args.output, prefix + "_embeddings.npz")))
+        # every rank leaves the process group after the last all-gather (rank 0's table writing below is host work; see
+        # zero_shot.main)
+        sharding.shutdown()
+        for fut in pending:
+            fut.result()                                     # surface write errors; the files are complete before the run ends
+    finally:
+        writer.shutdown(wait=True)
     if rank == 0:
         pd.DataFrame({"label": test_labels, "prediction": predictions}).to_csv(
             os.path.join(args.output, f"{prefix}_predictions.tsv"), sep="\t", index=False)

@@ -188,10 +188,25 @@ def iter_device_batches(sequences, start: int, stop: int, pad_to: int, batch_siz
 
 
 def check_model_inputs(model):
-    """Raise the engine's deferred IndexError (token id / position out of range, detected on the device) where results are read."""
+    """Raise the engine's deferred IndexError (token id / position out of range, detected on the device) where results are read.
+    Inside a process group the status bits are OR-ed over the ranks first, so that EVERY rank raises (a single rank raising
+    between two collectives would leave its peers waiting in the next one until the watchdog fires)."""
     chk = getattr(model, "check_status", None)
-    if callable(chk):
-        chk()
+    if not callable(chk):
+        return
+    rank, ws = sharding.world()
+    get = getattr(model, "status_bits", None)
+    if ws > 1 and callable(get):
+        import torch.distributed as dist
+        mine = int(get())
+        dev = torch.cuda.current_device() if dist.get_backend() == "nccl" else "cpu"
+        flags = torch.tensor([(mine >> b) & 1 for b in range(8)], dtype=torch.int32, device=dev)     # one flag per status bit
+        dist.all_reduce(flags, op=dist.ReduceOp.MAX)                                                  # = OR over the ranks
+        bits = sum(int(f) << b for b, f in enumerate(flags.tolist()))
+        if bits:
+            chk(bits)
+        return
+    chk()
 
 
 # ---- a3: batched forward -> [N, 4] probabilities ------------------------------------------------------
@@ -272,6 +287,7 @@ class FastaIndex:
     def __init__(self, path: str):
         self.path = path
         self._mem: Optional[Dict[str, str]] = None
+        self._irregular: Dict[str, str] = {}                        # records that cannot be offset-addressed, parsed on first use
         self.index: Dict[str, Tuple[int, int, int, int]] = {}       # name -> (length, offset, linebases, linewidth)
         if path.endswith(".gz"):
             self._mem = read_fasta(path)
@@ -291,37 +307,43 @@ class FastaIndex:
 
     @staticmethod
     def build_index(path: str) -> Dict[str, Tuple[int, int, int, int]]:
+        """One streaming pass -> {name: (length, offset, linebases, linewidth)}.  A record whose lines are not uniform (ragged line
+        lengths, a blank line inside it) cannot be addressed by offset arithmetic — `samtools faidx` rejects such a file, while
+        the reference's BioPython reader accepts it (src/zero_shot_score.py:176-180) — so it is entered as
+        (length, offset, -1, record bytes) and `fetch` parses THAT record into memory once, on first use."""
         idx: Dict[str, Tuple[int, int, int, int]] = {}
         name = None
         length = offset = linebases = linewidth = 0
-        short_seen = False
+        short_seen = irregular = False
         pos = 0
+
+        def close(end: int):
+            if name is not None:
+                idx[name] = (length, offset, -1, end - offset) if irregular else (length, offset, linebases, linewidth)
+
         with open(path, "rb") as f:
             for raw in f:
                 if raw.startswith(b">"):
-                    if name is not None:
-                        idx[name] = (length, offset, linebases, linewidth)
+                    close(pos)
                     w = raw[1:].split()
                     name = w[0].decode("latin-1") if w else ""
-                    length, offset, linebases, linewidth, short_seen = 0, pos + len(raw), 0, 0, False
+                    length, offset, linebases, linewidth, short_seen, irregular = 0, pos + len(raw), 0, 0, False, False
                 elif name is not None:
-                    body = raw.rstrip(b"\r\n")
+                    body = raw.strip()
                     if not body:
-                        # a blank line occupies bytes that the uniform-line-width arithmetic of fetch() does not know about: it is
-                        # only harmless at the very end of a record (samtools faidx rejects it elsewhere), so any later base raises
-                        short_seen = True
+                        short_seen = True            # harmless at the very end of a record only
                     elif linebases == 0 and not short_seen:
                         linebases, linewidth = len(body), len(raw)
+                        if len(raw.rstrip(b"\r\n")) != len(body):
+                            irregular = True         # leading / trailing blanks on a sequence line
                     else:
-                        if short_seen or len(body) > linebases:
-                            raise ValueError(f"{path}: sequence {name} has lines of unequal length (or a blank line inside "
-                                             "the record); cannot index")
+                        if short_seen or len(body) > linebases or len(raw.rstrip(b"\r\n")) != len(body):
+                            irregular = True
                         if len(body) < linebases:
                             short_seen = True        # only the last line of a record may be short
                     length += len(body)
                 pos += len(raw)
-        if name is not None:
-            idx[name] = (length, offset, linebases, linewidth)
+        close(pos)
         return idx
 
     def __contains__(self, name: str) -> bool:
@@ -336,6 +358,13 @@ class FastaIndex:
             return self._mem[name][max(0, start):max(0, stop)]
         length, offset, lb, lw = self.index[name]
         start, stop = max(0, start), min(stop, length)
+        if lb < 0:                                   # irregular record: parsed into memory once (build_index)
+            seq = self._irregular.get(name)
+            if seq is None:
+                self._fh.seek(offset)
+                seq = b"".join(ln.strip() for ln in self._fh.read(lw).splitlines()).decode("latin-1")
+                self._irregular[name] = seq
+            return seq[start:max(start, stop)]
         if stop <= start or lb == 0:
             return ""
         b0 = offset + (start // lb) * lw + start % lb
@@ -476,8 +505,10 @@ def main(argv: Optional[Sequence[str]] = None):
     if args.inputDF is None:
         logits = logits[np.asarray(inverse, dtype=np.int64)] if len(inverse) else logits[:0]      # fan back out per record
     rank, _ = sharding.world()
+    # every rank leaves the process group HERE, right after the last all-gather: rank 0's scoring and table / VCF writing below is
+    # host work that can take minutes on a large VCF, and peers parked in a barrier would hit the collective watchdog meanwhile
+    sharding.shutdown()
     if rank != 0:
-        sharding.shutdown()
         return
     if args.inputDF is not None:
         snpDF["zeroShotScore"] = zero_shot_score(snpDF, logits)
@@ -491,7 +522,6 @@ def main(argv: Optional[Sequence[str]] = None):
     else:
         zero_shot_score_vcf(args, recordIndices, logits)
     logging.info(f"Zero-shot scores saved to {args.output}")
-    sharding.shutdown()
 
 
 if __name__ == "__main__":

@@ -164,3 +164,46 @@ def test_two_processes_through_the_hip_engine_equal_single_process(tmp_path):
     tok = CaduceusTokenizer()
     np.testing.assert_array_equal(zero_shot.extract_logits(m, df["sequences"].tolist(), "cuda:0", 255, tok, batch_size=64), g0["p"])
     np.testing.assert_array_equal(embeddings.extract_embeddings(m, df["sequences"].tolist(), "cuda:0", 255, tok, batch_size=64), g0["e"])
+
+
+class _FlagModel:
+    """stand-in with the engine's deferred-validation surface: only `bad_rank` saw an invalid token id"""
+
+    def __init__(self, bits):
+        self.bits = bits
+
+    def status_bits(self):
+        return self.bits
+
+    def check_status(self, bits=None):
+        bits = self.bits if bits is None else bits
+        if bits:
+            raise IndexError(f"status bits {bits}")
+
+
+def _status_worker(rank, ws, port, outdir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=ws)
+    try:
+        from plantcaduceus_amd import zero_shot
+        zero_shot.check_model_inputs(_FlagModel(0))                 # clean on every rank: nobody raises
+        raised = ""
+        try:
+            zero_shot.check_model_inputs(_FlagModel(1 if rank == 1 else 0))
+        except IndexError as ex:
+            raised = str(ex)
+        t = torch.ones(1)
+        dist.all_reduce(t)                                          # the next collective still lines up on every rank
+        with open(os.path.join(outdir, f"s{rank}.txt"), "w") as f:
+            f.write(raised)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_deferred_input_error_raises_on_every_rank(tmp_path):
+    """a token-id error seen by ONE rank's shard must surface on all ranks together (the status bits are reduced over
+    the group before raising), otherwise the clean ranks walk on into the next collective and hang there."""
+    port = _free_port()
+    mp.spawn(_status_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    for r in range(2):
+        assert "status bits 1" in (tmp_path / f"s{r}.txt").read_text()

@@ -67,10 +67,16 @@ def test_fasta_index_gz_and_ragged(tmp_path):
         z.write(f.read())
     fz = zero_shot.FastaIndex(str(fa) + ".gz")
     assert fz.fetch("chr1", 10, 700) == g["chr1"][10:700] and fz.length("chr2") == 61
-    bad = tmp_path / "bad.fa"
-    bad.write_text(">a\nACGT\nAC\nACGT\n")
-    with pytest.raises(ValueError, match="unequal"):
-        zero_shot.FastaIndex(str(bad))
+    # ragged line lengths: not offset-addressable (samtools faidx refuses), but the reference's BioPython reader accepts the
+    # file (src/zero_shot_score.py:176-180) - such a record is parsed into memory on first use, the regular ones stay indexed
+    rag = tmp_path / "rag.fa"
+    rag.write_text(">a\nACGT\nAC\nACGT\n>b\nGGGG\nTT\n")
+    ix = zero_shot.FastaIndex(str(rag))
+    assert ix.index["a"][2] == -1 and ix.index["b"][2] == 4
+    assert ix.length("a") == 10 and ix.fetch("a", 3, 8) == "TACAC" and ix.fetch("a", 8, 50) == "GT"
+    assert ix.fetch("b", 1, 6) == "GGGTT"
+    assert ix.fetch("a", 0, 10) == zero_shot.read_fasta(str(rag))["a"]
+    ix.close()
 
 
 class _Counting:
@@ -213,15 +219,19 @@ def test_region_window_ids_equal_per_position_windows(tmp_path):
     ix2.close()
 
 
-def test_fasta_index_rejects_blank_line_inside_record(tmp_path):
+def test_fasta_index_blank_line_inside_record(tmp_path):
     """a blank line inside a record shifts every later base under the uniform-line-width arithmetic of fetch(): the index
-    builder must refuse it (samtools faidx does), while a blank line at the END of a record is harmless."""
+    builder marks such a record irregular (parsed into memory on first use, like BioPython would), while a blank line at
+    the END of a record is harmless and stays offset-addressed."""
     bad = tmp_path / "bad.fa"
     bad.write_text(">c1\nACGTACGT\n\nACGTAC\n>c2\nAAAA\n")
-    with pytest.raises(ValueError, match="cannot index"):
-        zero_shot.FastaIndex(str(bad))
+    ib = zero_shot.FastaIndex(str(bad))
+    assert ib.index["c1"][2] == -1 and ib.index["c2"][2] == 4
+    assert ib.fetch("c1", 6, 12) == "GTACGT" and ib.length("c1") == 14 and ib.fetch("c2", 0, 9) == "AAAA"
+    ib.close()
     ok = tmp_path / "ok.fa"
     ok.write_text(">c1\nACGTACGT\nACGTAC\n\n>c2\nAAAA\nCC\n\n")
     ix = zero_shot.FastaIndex(str(ok))
+    assert ix.index["c1"][2] == 8
     assert ix.fetch("c1", 6, 12) == "GTACGT" and ix.fetch("c2", 2, 6) == "AACC" and ix.length("c1") == 14
     ix.close()
