@@ -94,6 +94,14 @@ void   pcad_destroy(pcad_handle h);
  *   "gate_each"   1: SiLU(z) applied to each direction's scan output, each rounded, then summed — the reference's order
  *                 (two selective_scan_fn calls);  0 (default): applied once to the sum of both directions (same value in
  *                 exact arithmetic, one rounding fewer, faster).
+ *   "norm_fold"   1: the fused add + RMSNorm launch between two blocks is folded into the GEMMs around it: out_proj's epilogue
+ *                 adds its fp32 result to the fp32 residual stream in place and writes the rounded sum plus per-row partial sums of
+ *                 squares (deterministic, no atomics); in_proj runs on that un-normalised operand with W_in . diag(w_norm) (folded
+ *                 when the weights are bound) and multiplies by the row's rstd before it rounds.  Same value in exact arithmetic
+ *                 as rms_norm_fn(prenorm=True, residual_in_fp32=True); rounding points move (the mixer output is not rounded
+ *                 before it is added; in_proj's operand is round(res) instead of round(res * rstd * w)).  Used for chunks whose
+ *                 GEMMs are whole 256 x 256 tiles (d_model % 256 == 0, token-rows % 256 == 0) with an fp32 residual stream,
+ *                 never by pcad_forward_all_hidden;  0 (default): the reference's operation order.
  *   "scan_segments"  1 (default): for long sequences with few strands (PlantCAD2's 8 192-bp windows in small batches: at most 768 scan waves in a
  *                 launch and L >= 2 048) the scan of every strand is cut into up to 8 segments that run as separate workgroups
  *                 (zero-state pass, carry, real pass: ~1.8x the arithmetic for up to 8x the parallelism; results equal up to fp32
@@ -156,6 +164,8 @@ int    pcad_forward_all_hidden(pcad_handle h, const int32_t* ids, int B, int L,
 /* ---- measurement: per-kernel-class timing with HIP events on the caller's stream -------------------- */
 enum pcad_kernel_class {
     PCAD_K_NORM = 0, PCAD_K_GEMM_IN, PCAD_K_CONV, PCAD_K_GEMM_X, PCAD_K_SCAN, PCAD_K_GEMM_OUT, PCAD_K_HEAD,
+    PCAD_K_GEMM_OUT_RES,   /* "norm_fold": out_proj + residual add + row statistics in one launch */
+    PCAD_K_RSTD,           /* "norm_fold": layer-0 embedding + the per-layer reduction of the row statistics */
     PCAD_NUM_KERNEL_CLASSES
 };
 typedef struct pcad_kernel_stat {
@@ -228,6 +238,35 @@ int pcad_selective_scan_dtproj(const void* u, const void* dt_low, int64_t lddt, 
  * lda, ldw multiples of 16 bytes.  out_dtype: PCAD_F32 or `dtype`. */
 int pcad_gemm_nt(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc,
                  int64_t M, int N, int K, int dtype, int out_dtype, pcad_stream stream);
+
+/* out_proj of the "norm_fold" layer form as one operator (MFMA, 256 x 256 tiles only: M % 256 == 0, N % 256 == 0, K * elem a
+ * multiple of 128 bytes, every tensor < 4 GiB):
+ *   res [M, N] fp32 += A [M, K] . W [N, K]^T   (in place; the mixer output added to the fp32 residual stream)
+ *   C   [M, N] dtype  = round(res)              (bf16 model; ignored / may be NULL for the fp32 model)
+ *   ssq [M, N / 128]  = per-row sums of squares of the updated res over each 128-column slab (deterministic partials whose
+ *                       sum / N gives the next block's RMSNorm statistic)
+ * Replaces: out_proj (F.linear) + the residual add of rms_norm_fn(..., prenorm=True, residual_in_fp32=True). */
+int pcad_gemm_nt_residual(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, float* res, float* ssq,
+                          int64_t M, int N, int K, int dtype, pcad_stream stream);
+
+/* Rows of a [2B * L, E] activation tensor (plain rows) that a forward evaluated at positions p_0..p_{P-1} consumes after the
+ * last mixer: strand b row p_q and strand B + b row L - 1 - p_q  ->  out [(strand * P + q), E].  positions: HOST int32 [P],
+ * P <= PCAD_MAX_POSITIONS.  (The last-layer shortcut of pcad_forward; reference callers read one position:
+ * src/zero_shot_score.py:117, src/train_XGBoost.py:105.) */
+int pcad_gather_rows(const void* src, void* out, int B, int L, int E, const int32_t* positions, int P, int dtype,
+                     pcad_stream stream);
+
+/* The forward's last kernel as one operator: res + h -> norm_f -> RC re-assembly of hidden_states[-1] -> tied RCPS LM head, at
+ * the shared positions (HOST int32 [P], P = 0: all L) or one position per window (pos_per_seq, DEVICE int32 [B]; then
+ * positions must be NULL / P = 0).  h / res: [2B * L, D] (h: dtype, res: res_dtype); h_compact != 0: h holds only the evaluated
+ * rows as pcad_gather_rows orders them.  emb_f32: [vocab, D] fp32 (the dtype-rounded tied embedding / LM-head weight);
+ * hidden_out [B, Q, 2D] dtype and logits_out [B, Q, vocab] fp32, either may be NULL.  ids (DEVICE [B, L]) and status (DEVICE
+ * word) may be NULL: input validation as in pcad_set_status_buffer.
+ * Replaces: norm_f (rms_norm_fn) x2, the flips / cats of RCPSWrapper's output and RCPSLMHead. */
+int pcad_final_head(const void* h, const void* res, const float* norm_weight, const float* emb_f32, const int32_t* complement,
+                    void* hidden_out, float* logits_out, int B, int L, int D, float eps, const int32_t* positions, int P,
+                    const int32_t* pos_per_seq, int h_compact, const int32_t* ids, int32_t* status, int dtype, int res_dtype,
+                    pcad_stream stream);
 
 #ifdef __cplusplus
 }

@@ -52,6 +52,7 @@ struct LayerWeights {
     float* convw;    // conv taps of both directions packed per K-tile for the fused conv+x_proj kernel
     float* norm_w;   // [D]
     void* W_in;      // [2E, D]
+    void* W_in_f;    // [2E, D] = W_in . diag(norm_w), rounded once from the source precision: in_proj of the norm-folded form
     void* W_out;     // [D, E]
     DirWeights dir[2];
 };
@@ -71,6 +72,7 @@ struct pcad_engine {
     bool blocked;   // xc and y in the blocked layout (common.hpp::blocked_off); PCAD_PLAIN_LAYOUT=1 turns it off (A/B knob)
     bool segments = true;  // pcad_set_option("scan_segments", 0): never cut the scan of long strands into segments
     bool shortcut = true;  // pcad_set_option("last_layer_shortcut", 0): run the last layer in full even when only a few positions are evaluated
+    bool norm_fold = false; // pcad_set_option("norm_fold", 1): the add+RMSNorm pass folded into out_proj's epilogue / in_proj (forward_impl)
     bool poison = false;   // pcad_set_option("poison_workspace", 1): debug — fill the workspace with 0xFF (NaN patterns) before every forward
     bool bound = false;
     int32_t* status = nullptr;   // caller-owned device word for asynchronous input-validation flags (pcad_set_status_buffer)
@@ -114,6 +116,7 @@ void carve_weights(pcad_engine* e, Carver& c) {
         L.norm_w = (float*)c.take(D * 4);
         L.convw = (float*)c.take(convx_packed_bytes((int)E, e->cfg.dtype));
         L.W_in = c.take(2 * E * D * esz);
+        L.W_in_f = c.take(2 * E * D * esz);
         L.W_out = c.take(D * E * esz);
         for (int d = 0; d < 2; ++d) {
             DirWeights& w = L.dir[d];
@@ -131,6 +134,7 @@ void carve_weights(pcad_engine* e, Carver& c) {
 struct Workspace {
     void *res, *u, *h, *xz, *zb, *xc[2], *dtl[2], *y;
     float* bc[2];
+    float *rstd, *ssq;   // norm-folded form: rstd [rows]; partial sums of squares [rows, D / 128]
     float* seg;      // segmented-scan scratch (long sequences with few strands), or nullptr
     size_t bytes;
 };
@@ -155,6 +159,8 @@ Workspace carve_workspace(const pcad_engine* e, void* base, int Bc, int L) {
     w.bc[0] = (float*)c.take(rows * 2 * e->N * 4);   // B_t | C_t rows, fp32 (values rounded to the model dtype)
     w.bc[1] = (float*)c.take(rows * 2 * e->N * 4);
     w.y = c.take(rows8 * E * esz);
+    w.rstd = (float*)c.take(rows * 4);
+    w.ssq = (float*)c.take(rows * ((D + 127) / 128) * 4);
     const size_t segb = e->segments ? scan_segment_bytes(2 * Bc, L, (int)E) : 0;
     w.seg = segb ? (float*)c.take(segb) : nullptr;
     w.bytes = c.off;
@@ -162,7 +168,8 @@ Workspace carve_workspace(const pcad_engine* e, void* base, int Bc, int L) {
 }
 
 const char* const kClassNames[PCAD_NUM_KERNEL_CLASSES] = {
-    "add_rmsnorm", "gemm_in_proj", "conv1d_bidir", "gemm_x_proj", "selective_scan", "gemm_out_proj", "final_head"};
+    "add_rmsnorm", "gemm_in_proj", "conv1d_bidir", "gemm_x_proj", "selective_scan", "gemm_out_proj", "final_head",
+    "gemm_out_proj_res", "rstd_reduce"};
 
 constexpr size_t kProfCap = 1 << 16;
 
@@ -265,6 +272,8 @@ int pcad_set_option(pcad_handle h, const char* key, int64_t value) {
         h->chunk = (int)value;
     } else if (k == "gate_each") {
         h->gate_once = value == 0;
+    } else if (k == "norm_fold") {
+        h->norm_fold = value != 0;
     } else if (k == "poison_workspace") {
         h->poison = value != 0;
     } else if (k == "scan_segments") {
@@ -309,7 +318,7 @@ int pcad_bind_weights(pcad_handle h, const pcad_tensor* tensors, int n, void* ar
             return fail(PCAD_ERR_INVALID, "tensor %s: bad dtype", tensors[i].name);
         m[tensors[i].name] = &tensors[i];
     }
-    const int D = e->D, E = e->E, N = e->N, R = e->R, Rp = e->Rp, XP = e->XP, V = e->V, dt = e->cfg.dtype;
+    const int D = e->D, E = e->E, N = e->N, R = e->R, Rp = e->Rp, V = e->V, dt = e->cfg.dtype;
     const std::string pre = "caduceus.backbone.";
 
     auto need = [&](const std::string& k, int64_t expect) -> const pcad_tensor* {
@@ -343,6 +352,7 @@ int pcad_bind_weights(pcad_handle h, const pcad_tensor* tensors, int n, void* ar
         const std::string mf = lp + "mixer.submodule.mamba_fwd.";
         NEED(t_in, mf + "in_proj.weight", (int64_t)2 * E * D);
         HIP_TRY(launch_pack2d(t_in->data, t_in->dtype, D, L.W_in, dt, D, 2 * E, D, 2 * E, D, s));
+        HIP_TRY(launch_pack_scale_cols(t_in->data, t_in->dtype, D, L.norm_w, L.W_in_f, dt, D, 2 * E, D, s));
         NEED(t_out, mf + "out_proj.weight", (int64_t)D * E);
         HIP_TRY(launch_pack2d(t_out->data, t_out->dtype, E, L.W_out, dt, E, D, E, D, E, s));
         for (int d = 0; d < 2; ++d) {
@@ -427,17 +437,37 @@ static int forward_impl(pcad_handle h, const int32_t* ids, int B, int L, const i
     // the caller's stream.  (Multi-stream schedules were built and measured twice and removed: chunks alternating between two
     // streams gain nothing because the big kernels each fill the CUs, +1 %; the add+norm kernels on a side stream beside the other
     // chunk's GEMM are zero-sum, in_proj stretches by the norm's duration, -4 %: DESIGN.md §8.)
-    struct Lane { Workspace w; int b0, Bc; };
+    struct Lane { Workspace w; int b0, Bc; bool fold; };
     // debug aid (race / uninitialised-read screen): every byte of the workspace starts as 0xFF, so a kernel that consumes a
     // value no kernel of THIS forward produced turns the outputs into NaN instead of silently reusing the previous call's data
     if (e->poison) HIP_TRY(hipMemsetAsync(workspace, 0xFF, need, cs));
 
+    // Norm-folded layer form (pcad_set_option("norm_fold", 1)).  The reference's block is
+    //     res = h + res (fp32);  u = round(res * rstd(res) * w_norm);  xz = round(u . W_in^T);  ...;  h = round(y . W_out^T)
+    // (rms_norm_fn(..., prenorm=True, residual_in_fp32=True)).  Folded: out_proj's epilogue does
+    // res += y . W_out^T in fp32 (the accumulators start as the residual values), writes round(res) and per-row partial sums of
+    // squares; in_proj runs on round(res) with W_in . diag(w_norm) (folded at bind time) and multiplies by rstd[row] before it
+    // rounds.  The add + norm launch and its read of h / write of u disappear; what moves is rounding: h is not rounded before it
+    // is added, and the operand of in_proj is round(res) instead of round(res * rstd * w).  Used when every GEMM of the chunk
+    // runs on the 4-wave kernel (whole 256 x 256 tiles) and the residual stream is fp32; never for pcad_forward_all_hidden
+    // (hidden_states[i] are the mixer outputs h, which the folded form never materialises).
+    auto fold_for = [&](const Lane& c) -> bool {
+        return e->norm_fold && !all_hidden && rdt == F32 && e->xzsplit && e->blocked &&
+               gemm_fold_shapes_ok((int64_t)2 * c.Bc * L, D, E, dt) && ((int64_t)2 * c.Bc * L) * D * 4 < ((int64_t)1 << 32);
+    };
     auto phase_N = [&](Lane& c, int li) -> int {        // residual add + norm (layer 0: RCPS embedding + norm)
         hipStream_t s = cs;
         const LayerWeights& W = e->layers[li];
         const int S = 2 * c.Bc;
         const int64_t rows = (int64_t)S * L;
         const int32_t* ids_c = ids + (int64_t)c.b0 * L;
+        if (c.fold) {
+            if (li == 0) {      // res = Emb[token], u = the same rows in the model dtype (fp32 model: in_proj reads res), rstd
+                ProfScope ps(e, PCAD_K_RSTD, s);
+                HIP_TRY(launch_embed_rmsnorm(ids_c, e->emb, e->comp, W.norm_w, dt == BF16 ? c.w.u : nullptr, c.w.res, c.Bc, L, D, eps, dt, rdt, s, c.w.rstd));
+            }
+            return PCAD_OK;     // later layers: the previous out_proj's epilogue already produced res, round(res) and rstd
+        }
         if (li == 0) {
             if (all_hidden) {   // hidden_states[0] = RCPSEmbedding output
                 HIP_TRY(launch_embed_only(ids_c, e->emb, e->comp, c.w.h, c.Bc, L, D, dt, s));
@@ -458,7 +488,8 @@ static int forward_impl(pcad_handle h, const int32_t* ids, int B, int L, const i
         const int64_t rows = (int64_t)S * L;
         // in_proj (tied between directions: once per strand)
         { ProfScope ps(e, PCAD_K_GEMM_IN, s);
-        if (e->xzsplit) HIP_TRY(launch_gemm_nt_two(c.w.u, D, W.W_in, D, c.w.xz, c.w.zb, E, true, rows, 2 * E, D, dt, s));
+        if (c.fold) HIP_TRY(launch_gemm_nt_two(dt == BF16 ? c.w.u : c.w.res, D, W.W_in_f, D, c.w.xz, c.w.zb, E, true, rows, 2 * E, D, dt, s, c.w.rstd));
+        else if (e->xzsplit) HIP_TRY(launch_gemm_nt_two(c.w.u, D, W.W_in, D, c.w.xz, c.w.zb, E, true, rows, 2 * E, D, dt, s));
         else HIP_TRY(launch_gemm_nt(c.w.u, D, W.W_in, D, c.w.xz, 2 * E, rows, 2 * E, D, dt, dt, false, s)); }
         // conv1d + SiLU, causal and anti-causal from one read of x (fused with x_proj of both directions when possible)
         const bool convx = e->convx && ((int64_t)rows + 16) * E * esz < ((int64_t)1 << 32);      // the fused kernel's 32-bit offsets
@@ -515,6 +546,13 @@ static int forward_impl(pcad_handle h, const int32_t* ids, int B, int L, const i
             HIP_TRY(launch_gemm_nt(c.w.u, E, W.W_out, E, c.w.h, D, (int64_t)S * P, D, E, dt, dt, false, s, false));
             return PCAD_OK;
         }
+        if (c.fold && li + 1 < e->nl) {     // out_proj + residual add + the next block's norm statistics in one launch
+            { ProfScope ps(e, PCAD_K_GEMM_OUT_RES, s);
+            HIP_TRY(launch_gemm_nt_res(c.w.y, E, W.W_out, E, dt == BF16 ? c.w.u : nullptr, (float*)c.w.res, c.w.ssq, rows, D, E, dt, s, e->blocked)); }
+            ProfScope ps(e, PCAD_K_RSTD, s);
+            HIP_TRY(launch_rstd(c.w.ssq, c.w.rstd, rows, D / 128, D, eps, s));
+            return PCAD_OK;
+        }
         // out_proj on (y_fwd + y_rev): the two tied out_proj calls folded by linearity
         { ProfScope ps(e, PCAD_K_GEMM_OUT, s);
         HIP_TRY(launch_gemm_nt(c.w.y, E, W.W_out, E, c.w.h, D, rows, D, E, dt, dt, false, s, e->blocked)); }
@@ -541,6 +579,7 @@ static int forward_impl(pcad_handle h, const int32_t* ids, int B, int L, const i
         c.b0 = ck * chunk;
         c.Bc = (B - c.b0) < chunk ? (B - c.b0) : chunk;
         c.w = carve_workspace(e, workspace, c.Bc, L);
+        c.fold = fold_for(c);
         for (int li = 0; li < e->nl; ++li) {
             if (int rc = phase_N(c, li)) return rc;
             if (int rc = phase_P(c, li)) return rc;
@@ -692,6 +731,60 @@ int pcad_gemm_nt(const void* A, int64_t lda, const void* W, int64_t ldw, void* C
     if (err == hipErrorInvalidValue)
         return fail(PCAD_ERR_INVALID, "pcad_gemm_nt: K*elem must be a multiple of 128 bytes; A/W 16-byte aligned rows");
     if (err != hipSuccess) return fail(PCAD_ERR_HIP, "pcad_gemm_nt: %s", hipGetErrorString(err));
+    return PCAD_OK;
+}
+
+int pcad_gemm_nt_residual(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, float* res, float* ssq, int64_t M, int N,
+                          int K, int dtype, pcad_stream stream) {
+    if (!A || !W || !res || !ssq || (dtype == PCAD_BF16 && !C)) return fail(PCAD_ERR_INVALID, "pcad_gemm_nt_residual: null argument");
+    if (dtype != PCAD_F32 && dtype != PCAD_BF16) return fail(PCAD_ERR_INVALID, "pcad_gemm_nt_residual: bad dtype");
+    if (M < 0 || N <= 0 || K <= 0 || M % 256 || N % 256 || M * (int64_t)N * 4 >= ((int64_t)1 << 32))
+        return fail(PCAD_ERR_INVALID, "pcad_gemm_nt_residual: M and N must be multiples of 256 and M * N * 4 < 2^32");
+    hipError_t err = launch_gemm_nt_res(A, lda, W, ldw, C, res, ssq, M, N, K, dtype, (hipStream_t)stream, false);
+    if (err == hipErrorInvalidValue)
+        return fail(PCAD_ERR_INVALID, "pcad_gemm_nt_residual: K*elem must be a multiple of 128 bytes; 16-byte aligned rows; tensors < 4 GiB");
+    if (err != hipSuccess) return fail(PCAD_ERR_HIP, "pcad_gemm_nt_residual: %s", hipGetErrorString(err));
+    return PCAD_OK;
+}
+
+static int positions_arg(const char* who, const int32_t* positions, int P, int L, Positions* pos) {
+    if (P < 0 || P > PCAD_MAX_POSITIONS || (P > 0 && !positions)) return fail(PCAD_ERR_INVALID, "%s: bad positions (P=%d)", who, P);
+    pos->n = P;
+    for (int i = 0; i < 16; ++i) pos->p[i] = 0;
+    for (int i = 0; i < P; ++i) {
+        if (positions[i] < 0 || positions[i] >= L) return fail(PCAD_ERR_INVALID, "%s: position %d out of range [0,%d)", who, positions[i], L);
+        pos->p[i] = positions[i];
+    }
+    return PCAD_OK;
+}
+
+int pcad_gather_rows(const void* src, void* out, int B, int L, int E, const int32_t* positions, int P, int dtype, pcad_stream stream) {
+    if (!src || !out) return fail(PCAD_ERR_INVALID, "pcad_gather_rows: null argument");
+    if (dtype != PCAD_F32 && dtype != PCAD_BF16) return fail(PCAD_ERR_INVALID, "pcad_gather_rows: bad dtype");
+    if (B < 0 || L <= 0 || E <= 0 || (E * (dtype == PCAD_BF16 ? 2 : 4)) % 16 || P < 1)
+        return fail(PCAD_ERR_INVALID, "pcad_gather_rows: bad shape (E * elem must be a multiple of 16 bytes, P >= 1)");
+    Positions pos;
+    if (int rc = positions_arg("pcad_gather_rows", positions, P, L, &pos)) return rc;
+    if (B == 0) return PCAD_OK;
+    HIP_TRY(launch_gather_rows(src, out, B, L, E, pos, dtype, false, (hipStream_t)stream));
+    return PCAD_OK;
+}
+
+int pcad_final_head(const void* h, const void* res, const float* norm_weight, const float* emb_f32, const int32_t* complement,
+                    void* hidden_out, float* logits_out, int B, int L, int D, float eps, const int32_t* positions, int P,
+                    const int32_t* pos_per_seq, int h_compact, const int32_t* ids, int32_t* status, int dtype, int res_dtype,
+                    pcad_stream stream) {
+    if (!h || !res || !norm_weight || !emb_f32 || !complement) return fail(PCAD_ERR_INVALID, "pcad_final_head: null argument");
+    if ((dtype != PCAD_F32 && dtype != PCAD_BF16) || (res_dtype != PCAD_F32 && res_dtype != PCAD_BF16) || (dtype == PCAD_F32 && res_dtype != PCAD_F32))
+        return fail(PCAD_ERR_INVALID, "pcad_final_head: bad dtype / res_dtype");
+    if (B < 0 || L <= 0 || D <= 0 || D % 8 || D > 2048) return fail(PCAD_ERR_INVALID, "pcad_final_head: bad B / L / D");
+    if (pos_per_seq && (positions || P)) return fail(PCAD_ERR_INVALID, "pcad_final_head: positions and pos_per_seq are exclusive");
+    if (h_compact && (pos_per_seq || P == 0)) return fail(PCAD_ERR_INVALID, "pcad_final_head: h_compact needs a shared list of positions");
+    Positions pos;
+    if (int rc = positions_arg("pcad_final_head", positions, P, L, &pos)) return rc;
+    if (B == 0) return PCAD_OK;
+    HIP_TRY(launch_final_head(h, res, norm_weight, nullptr, emb_f32, complement, hidden_out, logits_out, B, L, D, eps, pos, pos_per_seq,
+                              dtype, res_dtype, (hipStream_t)stream, h_compact != 0, ids, status));
     return PCAD_OK;
 }
 

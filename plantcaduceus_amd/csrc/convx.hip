@@ -427,8 +427,7 @@ hipError_t launch_convx(const void* x, const float* convw, const void* Wx0, void
 #define PCAD_CONVX(T, Z)                                                                                              \
     do {                                                                                                                \
         auto k = convx_kernel<T, Z>;                                                                                    \
-        static bool attr = false;                                                                                       \
-        if (!attr) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, CX_LDS); attr = true; } \
+        if (hipError_t ae = ensure_dynamic_lds((const void*)k, CX_LDS)) return ae;                                      \
         hipLaunchKernelGGL(k, dim3((unsigned)tiles), dim3(CX_THREADS), CX_LDS, s, (const T*)x, convw, d0, d1, S, L, E);  \
     } while (0)
     if (dt == BF16) { if (zfill) PCAD_CONVX(bf16_t, true); else PCAD_CONVX(bf16_t, false); }

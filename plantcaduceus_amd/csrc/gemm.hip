@@ -41,7 +41,6 @@ constexpr int STAGE_BYTES = A_BYTES + W_BYTES;
 constexpr int NSTAGE = 3;
 constexpr int GEMM_LDS = NSTAGE * STAGE_BYTES;         // 144 KiB
 constexpr int GEMM_THREADS = 512;
-constexpr int GROUP_M = 8;
 
 __device__ __forceinline__ int key_a(int r) { return (r >> 1) & 7; }
 __device__ __forceinline__ int key_w(int r) { return (((r >> 4) & 3) << 1) | ((r >> 1) & 1); }
@@ -73,7 +72,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_kernel(const T* __res
                                                                   OutT* __restrict__ C, int64_t ldc, int64_t M, int N,
                                                                   int K, int tiles_m, int tiles_n,
                                                                   float* __restrict__ C2, int64_t ldc2, int nsplit,
-                                                                  int a_blocked) {
+                                                                  int a_blocked, int walk) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -87,10 +86,17 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_kernel(const T* __res
         const int xcd = tile & 7, idx = tile >> 3;
         const int q = nblk >> 3, r = nblk & 7;
         const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-        const int gsz = GROUP_M * tiles_n;
+        if (walk & 256) {                  // n-fastest: the tiles an XCD runs at one time share as few A panels as possible
+            const int tm = logical / tiles_n;
+            m0 = (int64_t)tm * BM;
+            n0 = (logical - tm * tiles_n) * BN;
+            return;
+        }
+        const int group_m = walk & 255;
+        const int gsz = group_m * tiles_n;
         const int g = logical / gsz;
-        const int first_m = g * GROUP_M;
-        const int gm = min(GROUP_M, tiles_m - first_m);
+        const int first_m = g * group_m;
+        const int gm = min(group_m, tiles_m - first_m);
         const int in_g = logical - g * gsz;
         m0 = (int64_t)(first_m + in_g % gm) * BM;
         n0 = (in_g / gm) * BN;
@@ -318,7 +324,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm256r_kernel(const T* __re
                                                                    const T* __restrict__ W, int64_t ldw,
                                                                    OutT* __restrict__ C, int64_t ldc, int64_t M, int N,
                                                                    int K, int tiles_m, int tiles_n, int a_blocked,
-                                                                   OutT* __restrict__ C2, int nsplit, int out_blocked) {
+                                                                   OutT* __restrict__ C2, int nsplit, int out_blocked, int walk) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -334,10 +340,17 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm256r_kernel(const T* __re
         const int xcd = tile & 7, idx = tile >> 3;
         const int q = nblk >> 3, r = nblk & 7;
         const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-        const int gsz = GROUP_M * tiles_n;
+        if (walk & 256) {                  // n-fastest: the tiles an XCD runs at one time share as few A panels as possible
+            const int tm = logical / tiles_n;
+            m0 = (int64_t)tm * BM2;
+            n0 = (logical - tm * tiles_n) * BN2;
+            return;
+        }
+        const int group_m = walk & 255;
+        const int gsz = group_m * tiles_n;
         const int g = logical / gsz;
-        const int first_m = g * GROUP_M;
-        const int gm = min(GROUP_M, tiles_m - first_m);
+        const int first_m = g * group_m;
+        const int gm = min(group_m, tiles_m - first_m);
         const int in_g = logical - g * gsz;
         m0 = (int64_t)(first_m + in_g % gm) * BM2;
         n0 = (in_g / gm) * BN2;
@@ -604,12 +617,40 @@ template <> struct MmaAcc<float> {
     }
 };
 
-template <typename T, typename OutT>
+// loads with a hand-managed wait: 16 bytes per lane straight into an accumulator-file register / 4 bytes into a VGPR, address =
+// 64-bit scalar base + 32-bit lane offset + immediate.  The compiler does not know these are memory operations: every consumer
+// sits behind an explicit s_waitcnt (see the call sites).
+template <int OFF> __device__ __forceinline__ void gload_a128(f32x4& dst, uint32_t vo, const float* sb) {
+    asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=a"(dst) : "v"(vo), "s"(sb), "n"(OFF));
+}
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+template <int OFF> __device__ __forceinline__ void gload_v32(float& dst, uint32_t vo, const float* sb) {
+    asm volatile("global_load_dword %0, %1, %2 offset:%3" : "=v"(dst) : "v"(vo), "s"(sb), "n"(OFF));
+}
+
+// Fused epilogues of the 4-wave kernel (the norm-folded layer form, api.hip "norm_fold"; reference semantics: rms_norm_fn(...,
+// prenorm=True, residual_in_fp32=True) between out_proj of one block and in_proj of the next):
+//   EPI_SCALE  C = (A . W^T) * rscale[row]                 in_proj on the UN-normalised residual with W_in . diag(w_norm) folded at
+//              bind time: rscale = rstd of the row.  The 8 factors a lane needs are fetched when the tile starts.
+//   EPI_RES    res += A . W^T (fp32, in place);  C = round(res);  ssq[row][n / 128] = sum of res^2 over the wave's 128 columns.
+//              The accumulators START as the tile's residual values (loaded straight into the accumulator-file registers when
+//              the tile begins; the first k-step waits row by row), so the read-modify-write of the fp32 stream costs no
+//              register and no separate pass; the per-row partial sums of squares are written without atomics
+//              (deterministic), one per 128-column wave tile, and reduced by rstd_kernel (norm.hip).
+enum { EPI_NONE = 0, EPI_SCALE = 1, EPI_RES = 2 };
+struct GemmEpi {
+    const float* rscale;    // EPI_SCALE: [M]
+    float* res;             // EPI_RES: [M, N] fp32, row stride N
+    float* ssq;             // EPI_RES: [M, N / 128]
+};
+
+template <typename T, typename OutT, int EPI>
 __global__ __launch_bounds__(GEMMQ_THREADS, 1) void gemm256q_kernel(const T* __restrict__ A, int64_t lda,
                                                                     const T* __restrict__ W, int64_t ldw,
                                                                     OutT* __restrict__ C, int64_t ldc, int64_t M, int N,
                                                                     int K, int tiles_m, int tiles_n, int a_blocked,
-                                                                    OutT* __restrict__ C2, int nsplit, int out_blocked, int epi_swap) {
+                                                                    OutT* __restrict__ C2, int nsplit, int out_blocked, int epi_swap, int walk,
+                                                                    GemmEpi epi) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -625,10 +666,17 @@ __global__ __launch_bounds__(GEMMQ_THREADS, 1) void gemm256q_kernel(const T* __r
         const int xcd = tile & 7, idx = tile >> 3;
         const int q = nblk >> 3, r = nblk & 7;
         const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-        const int gsz = GROUP_M * tiles_n;
+        if (walk & 256) {                  // n-fastest: the tiles an XCD runs at one time share as few A panels as possible
+            const int tm = logical / tiles_n;
+            m0 = (int64_t)tm * BM2;
+            n0 = (logical - tm * tiles_n) * BN2;
+            return;
+        }
+        const int group_m = walk & 255;
+        const int gsz = group_m * tiles_n;
         const int g = logical / gsz;
-        const int first_m = g * GROUP_M;
-        const int gm = min(GROUP_M, tiles_m - first_m);
+        const int first_m = g * group_m;
+        const int gm = min(group_m, tiles_m - first_m);
         const int in_g = logical - g * gsz;
         m0 = (int64_t)(first_m + in_g % gm) * BM2;
         n0 = (in_g / gm) * BN2;
@@ -725,13 +773,23 @@ __global__ __launch_bounds__(GEMMQ_THREADS, 1) void gemm256q_kernel(const T* __r
     //   issued at least 8 MFMAs before the k-step ends.
     auto kstep = [&](const u32x4 (&ac)[8], const u32x4 (&wc)[8], u32x4 (&an)[8], u32x4 (&wn)[8], int nsa, int nsw, int nkk,
                      bool dma_a, int dma_stage, auto first_tag) {
-        constexpr bool FIRST = decltype(first_tag)::value;          // first k-step of an output tile: acc = product
+        constexpr int MODE = (int)decltype(first_tag)::value;       // 1: first k-step of an output tile: acc = product;
+        constexpr bool FIRST = MODE == 1;                           // 2 (EPI_RES): the accumulators are arriving from memory (row waits)
         const int abn = nsa * A2_BYTES, wbn = nsw * W2_BYTES, kx = nkk << 6;
         auto lda = [&](int f) { an[f] = *reinterpret_cast<const u32x4*>(smem + ((abn + a_fo[f]) ^ kx)); };
         auto ldw = [&](int f) { wn[f] = *reinterpret_cast<const u32x4*>(smem + ((wbn + w_fo[f]) ^ kx)); };
         auto dma = [&](int p) { if (dma_a) a_piece(dma_stage, p); else w_piece(dma_stage, p); };
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
+            if constexpr (MODE == 2) {
+                // row r multiplies into acc[r][0..7], whose 8 residual loads were issued in row order just before this k-step:
+                // younger than them are the loads of rows r+1..7 (8 each) and this k-step's DMA pieces 0..r-1
+                switch (r) {
+                    case 0: wait_vmcnt<56>(); break; case 1: wait_vmcnt<49>(); break; case 2: wait_vmcnt<42>(); break;
+                    case 3: wait_vmcnt<35>(); break; case 4: wait_vmcnt<28>(); break; case 5: wait_vmcnt<21>(); break;
+                    case 6: wait_vmcnt<14>(); break; default: wait_vmcnt<7>(); break;
+                }
+            }
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
 #pragma unroll
@@ -762,8 +820,35 @@ __global__ __launch_bounds__(GEMMQ_THREADS, 1) void gemm256q_kernel(const T* __r
     // byte correction of the lane's destination for the swapped epilogue: the lane's piece moves from column 16 lg to
     // (lg & 1) * 16 + (lg >> 1) * 8 of the 64-column group (2-byte elements)
     const int swap_fix = (((lg & 1) * 16 + (lg >> 1) * 8) - lg * 16) * 2;
+    // ---- fused-epilogue state -------------------------------------------------------------------------------------------
+    float rs[8];                                            // EPI_SCALE: row factors of the current tile (rows mrow + 16 i)
+    auto load_rscale = [&](int64_t m0) {
+        if constexpr (EPI == EPI_SCALE) {
+            // asm loads: the values are consumed a whole tile later, behind >= 1 counted "s_waitcnt vmcnt(8)" with 8 younger
+            // DMAs in flight, so they have landed by construction and no wait is ever issued for them
+            const float* sb = epi.rscale + (m0 + wm * 128);
+            const uint32_t vo = (uint32_t)li * 4u;
+            gload_v32<0>(rs[0], vo, sb);   gload_v32<64>(rs[1], vo, sb);  gload_v32<128>(rs[2], vo, sb); gload_v32<192>(rs[3], vo, sb);
+            gload_v32<256>(rs[4], vo, sb); gload_v32<320>(rs[5], vo, sb); gload_v32<384>(rs[6], vo, sb); gload_v32<448>(rs[7], vo, sb);
+        }
+    };
+    // EPI_RES: residual values of tile (m0, n0) -> accumulator group (i, jg): 4 x 16 bytes per lane, straight into the AGPRs
+    const uint32_t res_vo = ((uint32_t)li * (uint32_t)N + (uint32_t)lg * 16u) * 4u;
+    auto res_tile_base = [&](int64_t m0, int n0) -> const float* {
+        return epi.res + ((m0 + wm * 128) * (int64_t)N + n0 + wn * 128);
+    };
+    auto load_res_group = [&](const float* tb, int i, int jg) {
+        const float* sb = tb + ((int64_t)i * 16 * N + jg * 64);
+        gload_a128<0>(acc[i][jg * 4 + 0], res_vo, sb);  gload_a128<16>(acc[i][jg * 4 + 1], res_vo, sb);
+        gload_a128<32>(acc[i][jg * 4 + 2], res_vo, sb); gload_a128<48>(acc[i][jg * 4 + 3], res_vo, sb);
+    };
     auto epilogue = [&](int64_t m0, int n0) {
         const int64_t mrow = m0 + wm * 128 + li;
+        float ss[8];
+        if constexpr (EPI == EPI_RES) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) ss[i] = 0.f;
+        }
 #pragma unroll
         for (int jg = 0; jg < 2; ++jg) {
             const int nbase = n0 + wn * 128 + jg * 64;                 // wave-uniform
@@ -790,6 +875,20 @@ __global__ __launch_bounds__(GEMMQ_THREADS, 1) void gemm256q_kernel(const T* __r
                 // the AGPR -> VGPR copies of this group only, here (otherwise all 256 are hoisted to the top of the epilogue)
                 f32x4 t0 = acc[i][jg * 4 + 0], t1 = acc[i][jg * 4 + 1], t2 = acc[i][jg * 4 + 2], t3 = acc[i][jg * 4 + 3];
                 asm volatile("" : "+v"(t0), "+v"(t1), "+v"(t2), "+v"(t3));
+                if constexpr (EPI == EPI_RES) {
+                    float* rdst = epi.res + (mrow * (int64_t)N + n0 + wn * 128 + lg * 16) + ((int64_t)i * 16 * N + jg * 64);
+                    *reinterpret_cast<f32x4*>(rdst) = t0;       *reinterpret_cast<f32x4*>(rdst + 4) = t1;
+                    *reinterpret_cast<f32x4*>(rdst + 8) = t2;   *reinterpret_cast<f32x4*>(rdst + 12) = t3;
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr)
+                        ss[i] = __builtin_fmaf(t0[rr], t0[rr], __builtin_fmaf(t1[rr], t1[rr], __builtin_fmaf(t2[rr], t2[rr], __builtin_fmaf(t3[rr], t3[rr], ss[i]))));
+                    asm volatile("" : "+v"(ss[i]));             // computed HERE (otherwise the chain is sunk to the end of the epilogue and every group's values stay live: spills)
+                    if constexpr (sizeof(OutT) == 4) {          // fp32 model: the next in_proj reads the residual stream itself
+                        __builtin_amdgcn_sched_barrier(0);
+                        continue;
+                    }
+                }
+                if constexpr (EPI == EPI_SCALE) { t0 *= rs[i]; t1 *= rs[i]; t2 *= rs[i]; t3 *= rs[i]; }
                 float lo[8], hi[8];
 #pragma unroll
                 for (int rr = 0; rr < 4; ++rr) {
@@ -821,6 +920,17 @@ __global__ __launch_bounds__(GEMMQ_THREADS, 1) void gemm256q_kernel(const T* __r
                 __builtin_amdgcn_sched_barrier(0);      // keep the epilogue's register footprint at one 16-column group
             }
         }
+        if constexpr (EPI == EPI_RES) {
+            // sum of squares of the wave's 128 columns of row mrow + 16 i: the four 16-lane groups hold 32 columns each
+            const int np = N >> 7;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                float v = ss[i];
+                v += __shfl_xor(v, 16, 64);
+                v += __shfl_xor(v, 32, 64);
+                if (lg == 0) epi.ssq[(mrow + i * 16) * np + (n0 >> 7) + wn] = v;
+            }
+        }
     };
 
     int tile = blockIdx.x;
@@ -828,6 +938,7 @@ __global__ __launch_bounds__(GEMMQ_THREADS, 1) void gemm256q_kernel(const T* __r
     tile_coords(tile, m0, n0);
     set_pa(m0);
     set_pw(n0);
+    load_rscale(m0);
     // prologue: A(0) W(0) A(1) W(1); wait for the first 16 pieces
     a_issue(0); a_advance();
     w_issue(0); w_advance();
@@ -843,14 +954,27 @@ __global__ __launch_bounds__(GEMMQ_THREADS, 1) void gemm256q_kernel(const T* __r
         const int sa_n = sa == 2 ? 0 : sa + 1;
         const int sa_f = sa == 0 ? 2 : sa - 1;          // stage of K-tile g-1 == stage of K-tile g+2
         // k-step 0: MFMAs on (g, k-step 0); reads (g, k-step 1); DMAs A(g+2)
-        if (kt == 0) kstep(fa0, fw0, fa1, fw1, sa, sw, 1, true, sa_f, std::true_type{});
-        else kstep(fa0, fw0, fa1, fw1, sa, sw, 1, true, sa_f, std::false_type{});
+        if constexpr (EPI == EPI_RES) {
+            if (kt == 0) {
+                // the accumulators START as the tile's residual values: 64 loads of 16 bytes per lane straight into the accumulator
+                // registers, row by row, and the first k-step waits for each row's eight just before it multiplies into them
+                const float* tb = res_tile_base(m0, n0);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) { load_res_group(tb, i, 0); load_res_group(tb, i, 1); }
+                kstep(fa0, fw0, fa1, fw1, sa, sw, 1, true, sa_f, std::integral_constant<int, 2>{});
+            } else {
+                kstep(fa0, fw0, fa1, fw1, sa, sw, 1, true, sa_f, std::integral_constant<int, 0>{});
+            }
+        } else {
+            if (kt == 0) kstep(fa0, fw0, fa1, fw1, sa, sw, 1, true, sa_f, std::integral_constant<int, 1>{});
+            else kstep(fa0, fw0, fa1, fw1, sa, sw, 1, true, sa_f, std::integral_constant<int, 0>{});
+        }
         a_advance();
         asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         // k-step 1: MFMAs on (g, k-step 1); reads (g+1, k-step 0); DMAs W(g+2) into the W stage just freed
-        kstep(fa1, fw1, fa0, fw0, sa_n, sw ^ 1, 0, false, sw, std::false_type{});
+        kstep(fa1, fw1, fa0, fw0, sa_n, sw ^ 1, 0, false, sw, std::integral_constant<int, 0>{});
         w_advance();
         sa = sa_n;
         sw ^= 1;
@@ -861,22 +985,27 @@ __global__ __launch_bounds__(GEMMQ_THREADS, 1) void gemm256q_kernel(const T* __r
             tile += gstride;
             if (tile >= nblk) break;
             tile_coords(tile, m0, n0);
+            load_rscale(m0);
             kt = 0;
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // trailing (unused) DMAs must not outlive the block's LDS
 }
 
-// persistent launch: 1 resident block of 8 waves per CU (LDS-limited), a multiple of 8 so block b stays on XCD b & 7
+// Tile walk of the persistent kernels (kernel argument `walk`): every XCD walks a contiguous range of the logical tile order, its
+// 32 CUs running 32 consecutive tiles at a time.  Bits 0-7: GROUP_M, the logical order is m-fastest inside groups of GROUP_M
+// m-panels (a "round" of 32 tiles = GROUP_M A panels x 32 / GROUP_M W panels);  bit 8: n-fastest instead (a round = the fewest A
+// panels, every W panel).  PCAD_DEV=1 PCAD_GEMM_WALK=<int> overrides (A/B sweeps: profiles/r04_gemm_walk.txt).
+static int tile_walk(int tiles_m, int tiles_n) {
+    static const char* ov = dev_env("PCAD_GEMM_WALK");
+    if (ov) { const int w = atoi(ov); if ((w & 256) || (w & 255) > 0) return w; }
+    (void)tiles_m; (void)tiles_n;
+    return 8;
+}
+
+// persistent launch: 1 resident block per CU (LDS-limited), a multiple of 8 so block b stays on XCD b & 7
 static int persistent_grid(int nblk) {
-    static int cus = 0;
-    if (!cus) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
-        if (cus <= 0) cus = 256;
-    }
-    const int cap = cus / 8 * 8;
+    const int cap = device_cu_count() / 8 * 8;
     return nblk < cap ? nblk : cap;
 }
 
@@ -886,23 +1015,16 @@ static hipError_t launch_gemm_t(const void* A, int64_t lda, const void* W, int64
     const int tiles_m = (int)((M + BM - 1) / BM), tiles_n = (N + BN - 1) / BN;
     const bool vec = ((ldc * (int64_t)sizeof(OutT)) % 16 == 0) && (((uintptr_t)C) % 16 == 0);
     dim3 grid((unsigned)persistent_grid(tiles_m * tiles_n)), block(GEMM_THREADS);
-    static bool attr_done_v = false, attr_done_s = false;
     if (vec) {
         auto kfn = gemm_nt_kernel<T, OutT, ROUND, true, false>;
-        if (!attr_done_v) {
-            (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
-            attr_done_v = true;
-        }
+        if (hipError_t ae = ensure_dynamic_lds((const void*)kfn, GEMM_LDS)) return ae;
         hipLaunchKernelGGL(kfn, grid, block, GEMM_LDS, s, (const T*)A, lda, (const T*)W, ldw, (OutT*)C, ldc, M, N, K,
-                           tiles_m, tiles_n, (float*)nullptr, (int64_t)0, 0, (int)a_blocked);
+                           tiles_m, tiles_n, (float*)nullptr, (int64_t)0, 0, (int)a_blocked, tile_walk(tiles_m, tiles_n));
     } else {
         auto kfn = gemm_nt_kernel<T, OutT, ROUND, false, false>;
-        if (!attr_done_s) {
-            (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
-            attr_done_s = true;
-        }
+        if (hipError_t ae = ensure_dynamic_lds((const void*)kfn, GEMM_LDS)) return ae;
         hipLaunchKernelGGL(kfn, grid, block, GEMM_LDS, s, (const T*)A, lda, (const T*)W, ldw, (OutT*)C, ldc, M, N, K,
-                           tiles_m, tiles_n, (float*)nullptr, (int64_t)0, 0, (int)a_blocked);
+                           tiles_m, tiles_n, (float*)nullptr, (int64_t)0, 0, (int)a_blocked, tile_walk(tiles_m, tiles_n));
     }
     return hipGetLastError();
 }
@@ -914,13 +1036,9 @@ static hipError_t launch_gemm_split_t(const void* A, int64_t lda, const void* W,
     const int tiles_m = (int)((M + BM - 1) / BM), tiles_n = (N + BN - 1) / BN;
     dim3 grid((unsigned)persistent_grid(tiles_m * tiles_n)), block(GEMM_THREADS);
     auto kfn = gemm_nt_kernel<T, T, false, true, true>;
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
-        attr_done = true;
-    }
+    if (hipError_t ae = ensure_dynamic_lds((const void*)kfn, GEMM_LDS)) return ae;
     hipLaunchKernelGGL(kfn, grid, block, GEMM_LDS, s, (const T*)A, lda, (const T*)W, ldw, (T*)C, ldc, M, N, K, tiles_m,
-                       tiles_n, C2, ldc2, nsplit, (int)a_blocked);
+                       tiles_n, C2, ldc2, nsplit, (int)a_blocked, tile_walk(tiles_m, tiles_n));
     return hipGetLastError();
 }
 
@@ -936,52 +1054,79 @@ hipError_t launch_gemm_nt_split(const void* A, int64_t lda, const void* W, int64
     return launch_gemm_split_t<float>(A, lda, W, ldw, C, ldc, C2, ldc2, nsplit, M, N, K, s, a_blocked);
 }
 
+// shapes the 4-wave kernel takes: whole 256 x 256 tiles, unsigned 32-bit buffer offsets
+template <typename T>
+static bool quad_ok(int64_t lda, int64_t ldw, int64_t M, int N, bool two, int nsplit) {
+    const int64_t esz_ = (int64_t)sizeof(T);
+    return M % BM2 == 0 && N % BN2 == 0 && (!two || nsplit % 64 == 0) && M * lda * esz_ < ((int64_t)1 << 32) - 65536 &&
+           (int64_t)N * ldw * esz_ < ((int64_t)1 << 32) - 65536;
+}
+
 template <typename T>
 static hipError_t launch_gemm256_t(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc, int64_t M,
                                    int N, int K, hipStream_t s, bool a_blocked, void* C2 = nullptr, int nsplit = 0,
-                                   bool out_blocked = false) {
+                                   bool out_blocked = false, int epi_kind = EPI_NONE, GemmEpi epi = GemmEpi{nullptr, nullptr, nullptr}) {
     const int tiles_m = (int)((M + BM2 - 1) / BM2), tiles_n = (N + BN2 - 1) / BN2;
     dim3 grid((unsigned)persistent_grid(tiles_m * tiles_n)), block(GEMM_THREADS);
     static const bool quad = dev_env("PCAD_GEMM_NOQUAD") == nullptr;   // PCAD_DEV=1 only: the 8-wave kernel for A/B runs
     static const bool epi_swap = dev_env("PCAD_GEMM_EPI_PLAIN") == nullptr;  // 64-byte-contiguous epilogue stores (PCAD_DEV=1 PCAD_GEMM_EPI_PLAIN=1: the interleaved form, for A/B)
-    const int64_t esz_ = (int64_t)sizeof(T);
-    if (quad && M % BM2 == 0 && N % BN2 == 0 && (C2 == nullptr || nsplit % 64 == 0) && M * lda * esz_ < ((int64_t)1 << 32) - 65536 &&
-        (int64_t)N * ldw * esz_ < ((int64_t)1 << 32) - 65536) {     // unsigned 32-bit buffer offsets
-        auto kq = gemm256q_kernel<T, T>;
-        static bool attr_q = false;
-        if (!attr_q) {
-            hipError_t e = hipFuncSetAttribute((const void*)kq, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM3_LDS);
-            if (e != hipSuccess) return e;
-            attr_q = true;
-        }
-        hipLaunchKernelGGL(kq, grid, dim3(GEMMQ_THREADS), GEMM3_LDS, s, (const T*)A, lda, (const T*)W, ldw, (T*)C, ldc, M, N, K,
-                           tiles_m, tiles_n, (int)a_blocked, (T*)C2, nsplit, (int)out_blocked, (int)epi_swap);
-        return hipGetLastError();
-    }
+    const bool qok = quad_ok<T>(lda, ldw, M, N, C2 != nullptr, nsplit);
+    if (epi_kind != EPI_NONE && !qok) return hipErrorInvalidValue;             // the fused epilogues exist on the 4-wave kernel only
+#define PCAD_LAUNCH_Q(EPIK)                                                                                                     \
+    do {                                                                                                                        \
+        auto kq = gemm256q_kernel<T, T, EPIK>;                                                                                  \
+        if (hipError_t ae = ensure_dynamic_lds((const void*)kq, GEMM3_LDS)) return ae;                                          \
+        hipLaunchKernelGGL(kq, grid, dim3(GEMMQ_THREADS), GEMM3_LDS, s, (const T*)A, lda, (const T*)W, ldw, (T*)C, ldc, M, N, K, \
+                           tiles_m, tiles_n, (int)a_blocked, (T*)C2, nsplit, (int)out_blocked, (int)epi_swap,                   \
+                           tile_walk(tiles_m, tiles_n), epi);                                                                   \
+        return hipGetLastError();                                                                                               \
+    } while (0)
+    if (epi_kind == EPI_SCALE) PCAD_LAUNCH_Q(EPI_SCALE);
+    if (epi_kind == EPI_RES) PCAD_LAUNCH_Q(EPI_RES);
+    if (quad && qok) PCAD_LAUNCH_Q(EPI_NONE);
+#undef PCAD_LAUNCH_Q
     auto kr = gemm256r_kernel<T, T>;
-    static bool attr_r = false;
-    if (!attr_r) {
-        hipError_t e = hipFuncSetAttribute((const void*)kr, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM3_LDS);
-        if (e != hipSuccess) return e;
-        attr_r = true;
-    }
+    if (hipError_t ae = ensure_dynamic_lds((const void*)kr, GEMM3_LDS)) return ae;
     hipLaunchKernelGGL(kr, grid, block, GEMM3_LDS, s, (const T*)A, lda, (const T*)W, ldw, (T*)C, ldc, M, N, K, tiles_m,
-                       tiles_n, (int)a_blocked, (T*)C2, nsplit, (int)out_blocked);
+                       tiles_n, (int)a_blocked, (T*)C2, nsplit, (int)out_blocked, tile_walk(tiles_m, tiles_n));
     return hipGetLastError();
 }
 
 // in_proj form on the 256x256 kernel: columns [0, nsplit) -> C1, [nsplit, N) -> C2: two separate tensors of nsplit and
 // N - nsplit columns, plain (contiguous rows) or both in the blocked layout.
 hipError_t launch_gemm_nt_two(const void* A, int64_t lda, const void* W, int64_t ldw, void* C1, void* C2, int nsplit,
-                              bool out_blocked, int64_t M, int N, int K, int dt, hipStream_t s) {
+                              bool out_blocked, int64_t M, int N, int K, int dt, hipStream_t s, const float* rscale) {
     if (M <= 0 || N <= 0) return hipSuccess;
     const int esz = dt == BF16 ? 2 : 4;
     if (K <= 0 || (K * esz) % ROWB || nsplit % 16 || N % 16 || nsplit <= 0 || nsplit >= N) return hipErrorInvalidValue;
     if ((lda * esz) % 16 || (ldw * esz) % 16 || ((uintptr_t)A) % 16 || ((uintptr_t)W) % 16) return hipErrorInvalidValue;
     if (((uintptr_t)C1) % 16 || ((uintptr_t)C2) % 16) return hipErrorInvalidValue;
     if (out_blocked && ((nsplit * esz) % 128 || ((N - nsplit) * esz) % 128)) return hipErrorInvalidValue;
-    if (dt == BF16) return launch_gemm256_t<bf16_t>(A, lda, W, ldw, C1, nsplit, M, N, K, s, false, C2, nsplit, out_blocked);
-    return launch_gemm256_t<float>(A, lda, W, ldw, C1, nsplit, M, N, K, s, false, C2, nsplit, out_blocked);
+    const int ek = rscale ? EPI_SCALE : EPI_NONE;
+    const GemmEpi epi{rscale, nullptr, nullptr};
+    if (dt == BF16) return launch_gemm256_t<bf16_t>(A, lda, W, ldw, C1, nsplit, M, N, K, s, false, C2, nsplit, out_blocked, ek, epi);
+    return launch_gemm256_t<float>(A, lda, W, ldw, C1, nsplit, M, N, K, s, false, C2, nsplit, out_blocked, ek, epi);
+}
+
+bool gemm_fold_shapes_ok(int64_t M, int D, int E, int dt) {
+    const int64_t esz = dt == BF16 ? 2 : 4;
+    // in_proj [M, D] x [2E, D]^T (two blocked outputs), out_proj [M, E] x [D, E]^T; the fp32 residual [M, D] and the lane
+    // offsets of its accesses stay below 2^32 bytes
+    const bool in_ok = dt == BF16 ? quad_ok<bf16_t>(D, D, M, 2 * E, true, E) : quad_ok<float>(D, D, M, 2 * E, true, E);
+    const bool out_ok = dt == BF16 ? quad_ok<bf16_t>(E, E, M, D, false, 0) : quad_ok<float>(E, E, M, D, false, 0);
+    return in_ok && out_ok && (D * esz) % ROWB == 0 && (E * esz) % ROWB == 0 && D % 128 == 0 && (int64_t)16 * D * 4 < ((int64_t)1 << 31);
+}
+
+hipError_t launch_gemm_nt_res(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, float* res, float* ssq, int64_t M,
+                              int N, int K, int dt, hipStream_t s, bool a_blocked) {
+    if (M <= 0 || N <= 0) return hipSuccess;
+    const int esz = dt == BF16 ? 2 : 4;
+    if (K <= 0 || (K * esz) % ROWB || !res || !ssq || (dt == BF16 && !C)) return hipErrorInvalidValue;
+    if ((lda * esz) % 16 || (ldw * esz) % 16 || ((uintptr_t)A) % 16 || ((uintptr_t)W) % 16 || ((uintptr_t)res) % 16) return hipErrorInvalidValue;
+    if (a_blocked && (lda * esz) % 128) return hipErrorInvalidValue;
+    const GemmEpi epi{nullptr, res, ssq};
+    if (dt == BF16) return launch_gemm256_t<bf16_t>(A, lda, W, ldw, C, N, M, N, K, s, a_blocked, nullptr, 0, false, EPI_RES, epi);
+    return launch_gemm256_t<float>(A, lda, W, ldw, C, N, M, N, K, s, a_blocked, nullptr, 0, false, EPI_RES, epi);
 }
 
 hipError_t launch_gemm_nt(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc, int64_t M,

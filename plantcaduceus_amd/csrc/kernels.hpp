@@ -15,6 +15,12 @@ inline const char* dev_env(const char* name) {
     return dev ? getenv(name) : nullptr;
 }
 
+// Per-device launch state.  A handle is bound to the device that was current when it was created and several handles on several
+// devices may live in one process (include/pcad.h "Threading / streams"), so nothing about a device is cached process-wide:
+// the CU count and the "this kernel may use > 64 KiB of dynamic LDS" attribute are kept per (device ordinal[, kernel]).
+hipError_t ensure_dynamic_lds(const void* kernel, int bytes);   // hipFuncSetAttribute once per (current device, kernel)
+int device_cu_count();                                          // multiProcessorCount of the current device (256 on MI355X)
+
 struct Positions {            // by-value kernel argument: the positions evaluated by the head kernel
     int n;                    // 0 => all L positions
     int p[16];
@@ -25,9 +31,12 @@ struct Positions {            // by-value kernel argument: the positions evaluat
 hipError_t launch_add_rmsnorm(const void* x, const void* res_in, const float* w, void* y, void* res_out,
                               int64_t rows, int D, float eps, int dt, int rdt, hipStream_t s);
 // layer-0 variant: x = Emb[strand token] gathered on the fly (RCPS strands by index arithmetic).
+// rstd_out != nullptr: the norm-folded form - y (may be nullptr) = the un-normalised embedding row, rstd_out[row] = its rstd.
 hipError_t launch_embed_rmsnorm(const int32_t* ids, const void* emb, const int32_t* comp8, const float* w,
                                 void* y, void* res_out, int B, int L, int D, float eps, int dt, int rdt,
-                                hipStream_t s);
+                                hipStream_t s, float* rstd_out = nullptr);
+// rstd[row] = rsqrt(sum of the np partial sums of squares of the row / D + eps)   (np % 4 == 0)
+hipError_t launch_rstd(const float* ssq, float* rstd, int64_t rows, int np, int D, float eps, hipStream_t s);
 // final add + norm_f + RC re-assembly + tied RCPS LM head, only at the requested positions (a shared list `pos`,
 // or one position per window from the device array `pos_per_seq` [B]).  h_compact: h holds only the evaluated rows,
 // [(strand * P + q), D] as launch_gather_rows orders them (the residual stream `res` is always the full tensor).
@@ -56,8 +65,17 @@ hipError_t launch_gemm_nt_split(const void* A, int64_t lda, const void* W, int64
 
 // in_proj form on the 256x256 kernel: columns [0, nsplit) -> C1, [nsplit, N) -> C2 (separate tensors of nsplit and
 // N - nsplit columns; both plain or both blocked).
+// rscale (or nullptr): per-row factor [M] applied to the result before it is rounded (the norm-folded in_proj: rstd of the row).
 hipError_t launch_gemm_nt_two(const void* A, int64_t lda, const void* W, int64_t ldw, void* C1, void* C2, int nsplit,
-                              bool out_blocked, int64_t M, int N, int K, int dt, hipStream_t s);
+                              bool out_blocked, int64_t M, int N, int K, int dt, hipStream_t s, const float* rscale = nullptr);
+
+// out_proj of the norm-folded layer form, on the 4-wave kernel only (gemm_fold_shapes_ok):
+//   res [M, N] fp32 += A . W^T (in place);  C [M, N] (dtype dt; unused for fp32) = round(res);  ssq [M, N / 128] = per-row partial
+//   sums of squares of the updated residual, one per 128-column wave tile (deterministic; reduced by launch_rstd).
+hipError_t launch_gemm_nt_res(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, float* res, float* ssq, int64_t M,
+                              int N, int K, int dt, hipStream_t s, bool a_blocked);
+// whether a chunk of M token-rows of a (D, E) model can run the folded form (whole 256 x 256 tiles for both projections)
+bool gemm_fold_shapes_ok(int64_t M, int D, int E, int dt);
 
 // conv.hip --------------------------------------------------------------------------------------
 // out_blocked: yf / yr in the blocked layout (common.hpp::blocked_off), buffers padded to a multiple of 8 rows.
@@ -122,6 +140,9 @@ hipError_t launch_gather_rows(const void* src, void* out, int B, int L, int E, P
 // generic 2-D copy/convert with zero padding: dst[r, c] (dst_dt, ld = dst_ld) = src[r, c] for r < rows, c < cols else 0
 hipError_t launch_pack2d(const void* src, int src_dt, int64_t src_ld, void* dst, int dst_dt, int64_t dst_ld,
                          int rows, int cols, int dst_rows, int dst_cols, hipStream_t s);
+// dst[r, c] (dst_dt) = src[r, c] * scale[c]: in_proj weight with the RMSNorm weight folded into its columns (norm-folded form)
+hipError_t launch_pack_scale_cols(const void* src, int src_dt, int64_t src_ld, const float* scale, void* dst, int dst_dt,
+                                  int64_t dst_ld, int rows, int cols, hipStream_t s);
 // A2[e, n] = -exp(A_log[e, n]) * log2(e)   (A_log read through its storage dtype)
 hipError_t launch_pack_A(const void* A_log, int src_dt, float* A2, int64_t n, float scale, hipStream_t s);
 

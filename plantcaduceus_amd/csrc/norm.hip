@@ -14,12 +14,15 @@ namespace pcad {
 
 constexpr int PCAD_STATUS_BAD_TOKEN_BIT = 1, PCAD_STATUS_BAD_POSITION_BIT = 2;     // = pcad.h PCAD_STATUS_*
 
-template <typename T, typename RT, int MAXC, bool EMBED>
+// FOLD (norm-folded layer form, api.hip): y = the UN-normalised sum rounded to the model dtype and rstd_out[row] = its rstd; the
+// norm weight lives in the in_proj weight (folded at bind time) and rstd is applied by in_proj's epilogue.
+template <typename T, typename RT, int MAXC, bool EMBED, bool FOLD = false>
 __global__ __launch_bounds__(256) void add_rmsnorm_kernel(const T* __restrict__ x, const RT* __restrict__ res_in,
                                                           const float* __restrict__ w, T* __restrict__ y,
                                                           RT* __restrict__ res_out, int64_t rows, int D, float eps,
                                                           const int32_t* __restrict__ ids,
-                                                          const int32_t* __restrict__ comp8, int B, int L) {
+                                                          const int32_t* __restrict__ comp8, int B, int L,
+                                                          float* __restrict__ rstd_out = nullptr) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -54,6 +57,15 @@ __global__ __launch_bounds__(256) void add_rmsnorm_kernel(const T* __restrict__ 
     }
     ss = wave_sum(ss);
     const float rstd = rsqrtf(ss / (float)D + eps);
+    if constexpr (FOLD) {
+        if (lane == 0) rstd_out[row] = rstd;
+#pragma unroll
+        for (int j = 0; j < MAXC; ++j) {
+            const int c = lane + 64 * j;
+            if (y != nullptr && c < nchunk) store8<T>(y + row * D + c * 8, v[j]);
+        }
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < MAXC; ++j) {
         const int c = lane + 64 * j;
@@ -67,11 +79,45 @@ __global__ __launch_bounds__(256) void add_rmsnorm_kernel(const T* __restrict__ 
     }
 }
 
+// rstd[row] = rsqrt(sum_p ssq[row][p] / D + eps): the per-wave-tile partial sums of squares the folded out_proj epilogue wrote
+// (gemm.hip EPI_RES), summed in a fixed order (deterministic)
+__global__ __launch_bounds__(256) void rstd_kernel(const float* __restrict__ ssq, float* __restrict__ rstd, int64_t rows, int np,
+                                                   float inv_d, float eps) {
+    const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= rows) return;
+    const float* p = ssq + row * np;
+    float acc = 0.f;
+    for (int i = 0; i < np; i += 4) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(p + i);
+        acc += (v[0] + v[1]) + (v[2] + v[3]);
+    }
+    rstd[row] = rsqrtf(acc * inv_d + eps);
+}
+
+hipError_t launch_rstd(const float* ssq, float* rstd, int64_t rows, int np, int D, float eps, hipStream_t s) {
+    if (rows <= 0) return hipSuccess;
+    if (np <= 0 || np % 4) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(rstd_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, s, ssq, rstd, rows, np, 1.0f / (float)D, eps);
+    return hipGetLastError();
+}
+
 template <typename T, typename RT, bool EMBED>
 static hipError_t launch_norm_t(const T* x, const RT* res_in, const float* w, T* y, RT* res_out, int64_t rows, int D,
-                                float eps, const int32_t* ids, const int32_t* comp8, int B, int L, hipStream_t s) {
+                                float eps, const int32_t* ids, const int32_t* comp8, int B, int L, hipStream_t s,
+                                float* rstd_out = nullptr) {
     if (rows <= 0) return hipSuccess;
     dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+    if constexpr (EMBED) {
+        if (rstd_out != nullptr) {            // layer 0 of the norm-folded form
+            if (D <= 512)
+                hipLaunchKernelGGL((add_rmsnorm_kernel<T, RT, 1, true, true>), grid, block, 0, s, x, res_in, w, y, res_out, rows, D, eps, ids, comp8, B, L, rstd_out);
+            else if (D <= 1024)
+                hipLaunchKernelGGL((add_rmsnorm_kernel<T, RT, 2, true, true>), grid, block, 0, s, x, res_in, w, y, res_out, rows, D, eps, ids, comp8, B, L, rstd_out);
+            else
+                hipLaunchKernelGGL((add_rmsnorm_kernel<T, RT, 4, true, true>), grid, block, 0, s, x, res_in, w, y, res_out, rows, D, eps, ids, comp8, B, L, rstd_out);
+            return hipGetLastError();
+        }
+    }
     if (D <= 512)
         hipLaunchKernelGGL((add_rmsnorm_kernel<T, RT, 1, EMBED>), grid, block, 0, s, x, res_in, w, y, res_out, rows, D,
                            eps, ids, comp8, B, L);
@@ -87,17 +133,17 @@ static hipError_t launch_norm_t(const T* x, const RT* res_in, const float* w, T*
 template <bool EMBED>
 static hipError_t dispatch_norm(const void* x, const void* res_in, const float* w, void* y, void* res_out,
                                 int64_t rows, int D, float eps, int dt, int rdt, const int32_t* ids,
-                                const int32_t* comp8, int B, int L, hipStream_t s) {
+                                const int32_t* comp8, int B, int L, hipStream_t s, float* rstd_out = nullptr) {
     if (D % 8 || D > 2048) return hipErrorInvalidValue;
     if (dt == BF16 && rdt == F32)
         return launch_norm_t<bf16_t, float, EMBED>((const bf16_t*)x, (const float*)res_in, w, (bf16_t*)y,
-                                                    (float*)res_out, rows, D, eps, ids, comp8, B, L, s);
+                                                    (float*)res_out, rows, D, eps, ids, comp8, B, L, s, rstd_out);
     if (dt == BF16 && rdt == BF16)
         return launch_norm_t<bf16_t, bf16_t, EMBED>((const bf16_t*)x, (const bf16_t*)res_in, w, (bf16_t*)y,
-                                                     (bf16_t*)res_out, rows, D, eps, ids, comp8, B, L, s);
+                                                     (bf16_t*)res_out, rows, D, eps, ids, comp8, B, L, s, rstd_out);
     if (dt == F32 && rdt == F32)
         return launch_norm_t<float, float, EMBED>((const float*)x, (const float*)res_in, w, (float*)y,
-                                                   (float*)res_out, rows, D, eps, ids, comp8, B, L, s);
+                                                   (float*)res_out, rows, D, eps, ids, comp8, B, L, s, rstd_out);
     return hipErrorInvalidValue;
 }
 
@@ -107,8 +153,8 @@ hipError_t launch_add_rmsnorm(const void* x, const void* res_in, const float* w,
 }
 
 hipError_t launch_embed_rmsnorm(const int32_t* ids, const void* emb, const int32_t* comp8, const float* w, void* y,
-                                void* res_out, int B, int L, int D, float eps, int dt, int rdt, hipStream_t s) {
-    return dispatch_norm<true>(emb, nullptr, w, y, res_out, (int64_t)2 * B * L, D, eps, dt, rdt, ids, comp8, B, L, s);
+                                void* res_out, int B, int L, int D, float eps, int dt, int rdt, hipStream_t s, float* rstd_out) {
+    return dispatch_norm<true>(emb, nullptr, w, y, res_out, (int64_t)2 * B * L, D, eps, dt, rdt, ids, comp8, B, L, s, rstd_out);
 }
 
 // ------------------------------------------------------------------------------------------------

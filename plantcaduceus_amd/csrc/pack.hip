@@ -1,4 +1,8 @@
 // Weight packing (run once at bind time): dtype conversion, zero padding, pre-exponentiated A.
+#include <mutex>
+#include <set>
+#include <utility>
+
 #include "common.hpp"
 #include "kernels.hpp"
 
@@ -46,6 +50,32 @@ __global__ __launch_bounds__(256) void pack_A_kernel(const SrcT* __restrict__ A_
     if (i < n) A2[i] = -expf(Elem<SrcT>::load(A_log + i)) * scale;
 }
 
+template <typename SrcT, typename DstT>
+__global__ __launch_bounds__(256) void pack_scale_cols_kernel(const SrcT* __restrict__ src, int64_t src_ld, const float* __restrict__ scale,
+                                                              DstT* __restrict__ dst, int64_t dst_ld, int rows, int cols) {
+    const int64_t total = (int64_t)rows * cols;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int r = (int)(i / cols), c = (int)(i - (int64_t)r * cols);
+        Elem<DstT>::store(dst + (int64_t)r * dst_ld + c, Elem<SrcT>::load(src + (int64_t)r * src_ld + c) * scale[c]);
+    }
+}
+
+hipError_t launch_pack_scale_cols(const void* src, int src_dt, int64_t src_ld, const float* scale, void* dst, int dst_dt,
+                                  int64_t dst_ld, int rows, int cols, hipStream_t s) {
+    const int64_t total = (int64_t)rows * cols;
+    if (total <= 0) return hipSuccess;
+    int64_t nb = (total + 255) / 256;
+    if (nb > 4096) nb = 4096;
+    dim3 grid((unsigned)nb), block(256);
+#define PCAD_PSC(ST, DT) hipLaunchKernelGGL((pack_scale_cols_kernel<ST, DT>), grid, block, 0, s, (const ST*)src, src_ld, scale, (DT*)dst, dst_ld, rows, cols)
+    if (src_dt == F32 && dst_dt == F32) PCAD_PSC(float, float);
+    else if (src_dt == F32 && dst_dt == BF16) PCAD_PSC(float, bf16_t);
+    else if (src_dt == BF16 && dst_dt == F32) PCAD_PSC(bf16_t, float);
+    else PCAD_PSC(bf16_t, bf16_t);
+#undef PCAD_PSC
+    return hipGetLastError();
+}
+
 hipError_t launch_pack_A(const void* A_log, int src_dt, float* A2, int64_t n, float scale, hipStream_t s) {
     if (n <= 0) return hipSuccess;
     dim3 grid((unsigned)((n + 255) / 256)), block(256);
@@ -87,6 +117,33 @@ hipError_t launch_gather_rows(const void* src, void* out, int B, int L, int E, P
     if (dt == BF16) hipLaunchKernelGGL(gather_rows_kernel<bf16_t>, grid, block, 0, s, (const bf16_t*)src, (bf16_t*)out, B, L, E, pos, (int)blocked);
     else hipLaunchKernelGGL(gather_rows_kernel<float>, grid, block, 0, s, (const float*)src, (float*)out, B, L, E, pos, (int)blocked);
     return hipGetLastError();
+}
+
+// ---- per-device launch state (kernels.hpp) -----------------------------------------------------------------------------
+hipError_t ensure_dynamic_lds(const void* kernel, int bytes) {
+    static std::mutex mu;
+    static std::set<std::pair<int, const void*>> done;        // (device ordinal, kernel)
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    std::lock_guard<std::mutex> lock(mu);
+    if (done.count({dev, kernel})) return hipSuccess;
+    e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess) done.insert({dev, kernel});
+    return e;
+}
+
+int device_cu_count() {
+    static std::mutex mu;
+    static int cus[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    std::lock_guard<std::mutex> lock(mu);
+    if (!cus[dev]) {
+        hipDeviceProp_t prop;
+        cus[dev] = hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    return cus[dev];
 }
 
 }  // namespace pcad

@@ -71,6 +71,13 @@ SIGNATURES = {
                                              C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "pcad_gemm_nt": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64,
                                C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "pcad_gemm_nt_residual": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
+                                        C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "pcad_gather_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int32), C.c_int, C.c_int,
+                                   C.c_void_p]),
+    "pcad_final_head": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                  C.c_int, C.c_int, C.c_int, C.c_float, C.POINTER(C.c_int32), C.c_int, C.c_void_p, C.c_int,
+                                  C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
 }
 
 _lib = None
@@ -297,7 +304,8 @@ class Engine:
 
     def set_option(self, key: str, value: int):
         """`pcad_set_option` (include/pcad.h): "chunk_seqs" (windows per pass through the stack), "gate_each" (reference-order
-        SiLU gate), "scan_segments" (segmented scan of long strands), "last_layer_shortcut", "poison_workspace" (debug)."""
+        SiLU gate), "norm_fold" (add + RMSNorm folded into out_proj's epilogue / in_proj), "scan_segments" (segmented scan of long
+        strands), "last_layer_shortcut", "poison_workspace" (debug)."""
         _check(self.lib.pcad_set_option(self._h, key.encode(), int(value)), "pcad_set_option")
         self._ws = None
 

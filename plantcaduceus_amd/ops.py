@@ -215,3 +215,68 @@ def linear(x, weight, out_dtype: Optional[torch.dtype] = None):
         _check(lib.pcad_gemm_nt(xf.data_ptr(), K, wf.data_ptr(), K, out.data_ptr(), N, xf.shape[0], N, K, _dt(xf),
                                 _DT[od], _stream_ptr()), "pcad_gemm_nt")
     return out.view(*x.shape[:-1], N)
+
+
+def linear_residual(x, weight, residual):
+    """The "norm_fold" out_proj as an operator (include/pcad.h pcad_gemm_nt_residual): residual (fp32 [M, N], updated IN PLACE)
+    += x [M, K] @ weight [N, K]^T; returns (round(residual) in x.dtype [M, N] (None for fp32), ssq [M, N/128] per-row partial
+    sums of squares of the updated residual)."""
+    _require_gpu(x, "x")
+    lib = load_library()
+    M, K = x.shape
+    N = weight.shape[0]
+    if residual.dtype != torch.float32 or not residual.is_contiguous() or tuple(residual.shape) != (M, N):
+        raise ValueError("residual must be a contiguous fp32 [M, N] tensor")
+    xf = x.contiguous()
+    wf = weight.to(x.dtype).contiguous()
+    out = torch.empty((M, N), dtype=x.dtype, device=x.device) if x.dtype != torch.float32 else None
+    ssq = torch.empty((M, N // 128), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        _check(lib.pcad_gemm_nt_residual(xf.data_ptr(), K, wf.data_ptr(), K, out.data_ptr() if out is not None else None,
+                                         residual.data_ptr(), ssq.data_ptr(), M, N, K, _dt(xf), _stream_ptr()),
+               "pcad_gemm_nt_residual")
+    return out, ssq
+
+
+def gather_rows(src, B: int, L: int, positions):
+    """src [2B*L, E] -> [2B*P, E]: strand b row p_q, strand B+b row L-1-p_q (include/pcad.h pcad_gather_rows)."""
+    import ctypes as C
+    _require_gpu(src, "src")
+    lib = load_library()
+    E = src.shape[-1]
+    P = len(positions)
+    srcf = src.contiguous()
+    out = torch.empty((2 * B * P, E), dtype=src.dtype, device=src.device)
+    arr = (C.c_int32 * max(P, 1))(*[int(p) for p in positions])
+    with torch.cuda.device(src.device):
+        _check(lib.pcad_gather_rows(srcf.data_ptr(), out.data_ptr(), B, L, E, arr, P, _dt(srcf), _stream_ptr()), "pcad_gather_rows")
+    return out
+
+
+def final_head(h, res, norm_weight, emb, complement, B: int, L: int, eps: float, positions=None, pos_per_seq=None,
+               h_compact: bool = False, want_hidden: bool = True, want_logits: bool = True, ids=None, status=None):
+    """norm_f + RC re-assembly + tied RCPS LM head at the requested positions (include/pcad.h pcad_final_head).
+    h [2B*L, D] (or the gathered rows when h_compact), res [2B*L, D] (fp32 or h.dtype), emb [V, D] (rounded to h.dtype here, as the
+    tied lm_head weight is).  -> (hidden [B, Q, 2D] | None, logits fp32 [B, Q, V] | None)."""
+    import ctypes as C
+    _require_gpu(h, "h")
+    lib = load_library()
+    D = h.shape[-1]
+    V = emb.shape[0]
+    P = 0 if positions is None else len(positions)
+    Q = 1 if pos_per_seq is not None else (P if P else L)
+    hf, rf = h.contiguous(), res.contiguous()
+    w = norm_weight.float().contiguous()
+    e32 = emb.to(h.dtype).float().contiguous()
+    comp = torch.as_tensor(list(complement), dtype=torch.int32, device=h.device)
+    hid = torch.empty((B, Q, 2 * D), dtype=h.dtype, device=h.device) if want_hidden else None
+    lg = torch.empty((B, Q, V), dtype=torch.float32, device=h.device) if want_logits else None
+    arr = (C.c_int32 * max(P, 1))(*[int(p) for p in (positions or [])]) if P else None
+    pps = pos_per_seq.to(torch.int32).contiguous() if pos_per_seq is not None else None
+    with torch.cuda.device(h.device):
+        _check(lib.pcad_final_head(hf.data_ptr(), rf.data_ptr(), w.data_ptr(), e32.data_ptr(), comp.data_ptr(),
+                                   hid.data_ptr() if hid is not None else None, lg.data_ptr() if lg is not None else None,
+                                   B, L, D, float(eps), arr, P, pps.data_ptr() if pps is not None else None, int(bool(h_compact)),
+                                   ids.data_ptr() if ids is not None else None, status.data_ptr() if status is not None else None,
+                                   _dt(hf), _DT[rf.dtype], _stream_ptr()), "pcad_final_head")
+    return hid, lg

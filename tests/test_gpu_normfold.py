@@ -1,0 +1,149 @@
+"""-m gpu: the "norm_fold" layer form (include/pcad.h pcad_set_option): the add + RMSNorm launch between two blocks folded into
+out_proj's epilogue (fp32 residual read-modify-write + rounded copy + per-row partial sums of squares) and in_proj (norm weight
+folded into W_in at bind time, rstd applied before rounding).  Same value in exact arithmetic as the reference's
+rms_norm_fn(..., prenorm=True, residual_in_fp32=True) between out_proj and in_proj, so: the fp32
+model must meet north_star's 1e-4 against the oracle exactly like the reference-order path, the bf16 model must sit inside the
+same bf16 rounding noise, and the usual engine invariants (determinism, no read of stale workspace, shortcut == full layer)
+must hold with the option on."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import caduceus_oracle as O
+from plantcaduceus_amd.checkpoint import make_config, synthetic_state_dict
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def build(cfg, sd, dtype, **engine_options):
+    from plantcaduceus_amd.modeling_caduceus import CaduceusForMaskedLM
+    cfg.engine_options = dict(engine_options)
+    m = CaduceusForMaskedLM(cfg)
+    m.load_state_dict(sd, strict=False)
+    m.tie_weights()
+    return m.to(dtype).to(DEV)
+
+
+def rand_ids(B, L, seed, mask=None):
+    g = torch.Generator().manual_seed(seed)
+    ids = torch.randint(3, 7, (B, L), generator=g)
+    ids[0, 0] = 2
+    if mask is not None:
+        ids[:, mask] = 1
+    return ids
+
+
+def folded_launches(m, ids, **kw):
+    """-> (output, {kernel class: launches}) of one forward with per-launch HIP events on"""
+    eng = m._engine()
+    eng.profile(1)
+    out = m(input_ids=ids, **kw)
+    torch.cuda.synchronize()
+    st = eng.profile_read()
+    eng.profile(False)
+    return out, {k: v[0] for k, v in st.items()}
+
+
+# rows = 2 * B * L must be whole 256-row tiles and d_model % 256 == 0 for the folded form to engage
+@pytest.mark.parametrize("D,nl,B,L", [(256, 3, 2, 64), (512, 2, 1, 128), (256, 4, 3, 128), (1024, 2, 1, 512), (768, 2, 2, 192)])
+def test_norm_fold_fp32_matches_oracle(D, nl, B, L):
+    cfg = make_config("x", d_model=D, n_layer=nl)
+    sd = synthetic_state_dict(cfg, seed=D + nl, stress=True)          # non-unit norm weights: the W_in fold is exercised
+    ids = rand_ids(B, L, 5, mask=L // 2 - 1)
+    ref = O.forward_strands(ids, O.params_from_state_dict(sd, cfg))
+    m = build(cfg, sd, torch.float32, norm_fold=1)
+    out, n = folded_launches(m, ids.to(DEV), output_hidden_states=True)
+    assert n["gemm_out_proj_res"] == nl - 1 and n["add_rmsnorm"] == 0 and n["rstd_reduce"] == nl, n
+    lg, hid = out.logits.cpu(), out.hidden_states[-1].cpu()
+    scale = ref["logits"].abs().max()
+    e_l = ((lg - ref["logits"]).abs().max() / scale).item()
+    e_h = ((hid - ref["hidden"]).abs().max() / ref["hidden"].abs().max()).item()
+    print(f"norm_fold fp32 D={D} nl={nl}: logits {e_l:.2e} hidden {e_h:.2e}")
+    assert e_l < 1e-4 and e_h < 1e-4
+    p = L // 2 - 1
+    assert torch.equal(lg[:, p, 3:7].argmax(-1), ref["logits"][:, p, 3:7].argmax(-1))
+    # the positions path (last-layer shortcut) == slicing the full output, with the option on
+    out_p = m(input_ids=ids.to(DEV), output_hidden_states=True, positions=[p, 0, L - 1])
+    assert torch.equal(out_p.logits.cpu(), lg[:, [p, 0, L - 1]])
+    assert torch.equal(out_p.hidden_states[-1].cpu(), hid[:, [p, 0, L - 1]])
+    # and it is as close to the oracle as the reference-order path is (same order of magnitude)
+    m0 = build(cfg, sd, torch.float32)
+    lg0 = m0(input_ids=ids.to(DEV)).logits.cpu()
+    e0 = ((lg0 - ref["logits"]).abs().max() / scale).item()
+    assert e_l < 10 * e0 + 1e-6
+
+
+def test_norm_fold_falls_back_on_partial_tiles_and_all_hidden():
+    """rows % 256 != 0 or d_model % 256 != 0: the reference-order launches run (results equal the option-off engine bit for bit);
+    materialising every hidden level needs the mixer outputs, so that call never folds either."""
+    for D, B, L in ((256, 3, 45), (384, 2, 64)):
+        cfg = make_config("x", d_model=D, n_layer=2)
+        sd = synthetic_state_dict(cfg, seed=3, stress=True)
+        ids = rand_ids(B, L, 1).to(DEV)
+        out, n = folded_launches(build(cfg, sd, torch.bfloat16, norm_fold=1), ids)
+        assert n["gemm_out_proj_res"] == 0 and n["add_rmsnorm"] == 2
+        assert torch.equal(out.logits, build(cfg, sd, torch.bfloat16)(input_ids=ids).logits)
+    cfg = make_config("x", d_model=256, n_layer=3)
+    sd = synthetic_state_dict(cfg, seed=4, stress=True)
+    ids = rand_ids(2, 64, 2).to(DEV)
+    cfg.materialize_all_hidden_states = True
+    a = build(cfg, sd, torch.float32, norm_fold=1)(input_ids=ids, output_hidden_states=True).hidden_states
+    b = build(cfg, sd, torch.float32)(input_ids=ids, output_hidden_states=True).hidden_states
+    assert len(a) == len(b) == 4 and all(torch.equal(x, y) for x, y in zip(a, b))
+
+
+@pytest.mark.parametrize("L", [128, 512])
+def test_norm_fold_bf16_inside_rounding_noise(L):
+    """bf16: against the bf16-emulating oracle (reference rounding points) the folded engine must be no further away than the
+    same 3e-2-of-range bar the reference-order engine is held to, make the same confident calls, and differ from the
+    reference-order engine by bf16 noise only."""
+    cfg = make_config("x", d_model=256, n_layer=4)
+    sd = synthetic_state_dict(cfg, seed=3, stress=True)
+    ids = rand_ids(4, L, 9, mask=63)
+    ref = O.forward_strands(ids, O.params_from_state_dict(sd, cfg, dtype=torch.bfloat16), rnd=O.round_bf16)
+    ref32 = O.forward_strands(ids, O.params_from_state_dict(sd, cfg))
+    out, n = folded_launches(build(cfg, sd, torch.bfloat16, norm_fold=1), ids.to(DEV), output_hidden_states=True)
+    assert n["gemm_out_proj_res"] == 3
+    lg = out.logits.cpu()
+    lg0 = build(cfg, sd, torch.bfloat16)(input_ids=ids.to(DEV)).logits.cpu()
+    scale = ref["logits"].abs().max()
+    e_fold, e_plain = ((lg - ref["logits"]).abs().max() / scale).item(), ((lg0 - ref["logits"]).abs().max() / scale).item()
+    e_f32 = ((lg - ref32["logits"]).abs().max() / scale).item()
+    print(f"norm_fold bf16 L={L}: vs emulation {e_fold:.3e} (reference-order engine {e_plain:.3e}), vs fp32 {e_f32:.3e}")
+    assert e_fold < 3e-2 and e_fold < 3 * e_plain + 5e-3
+    top2 = ref["logits"][:, 63, 3:7].topk(2, dim=-1).values
+    conf = (top2[:, 0] - top2[:, 1]) > 3e-2 * scale
+    assert torch.equal(lg[:, 63, 3:7].argmax(-1)[conf], ref["logits"][:, 63, 3:7].argmax(-1)[conf])
+    assert out.hidden_states[-1].dtype == torch.bfloat16
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_norm_fold_deterministic_and_poison_proof(dtype):
+    """six forwards of one batch: same bits (the partial sums of squares are written, never accumulated atomically, and the
+    residual tile is waited for row by row); with every workspace byte preset to 0xFF: same bits again (nothing stale is read:
+    res / rstd / ssq are all produced inside the forward); the last-layer shortcut equals the full last layer."""
+    cfg = make_config("l32", n_layer=3)
+    sd = synthetic_state_dict(cfg, seed=9, stress=True)
+    ids = rand_ids(96, 512, 5, mask=255).to(DEV)
+    m = build(cfg, sd, dtype, norm_fold=1)
+    ref = None
+    for _ in range(6):
+        out = m(input_ids=ids, output_hidden_states=True, positions=[255, 3, 508])
+        cur = (out.logits.clone(), out.hidden_states[-1].clone())
+        assert torch.isfinite(cur[0]).all()
+        if ref is None:
+            ref = cur
+        else:
+            assert torch.equal(cur[0], ref[0]) and torch.equal(cur[1], ref[1])
+    mp = build(cfg, sd, dtype, norm_fold=1, poison_workspace=1)
+    for _ in range(2):
+        out = mp(input_ids=ids, output_hidden_states=True, positions=[255, 3, 508])
+        assert torch.equal(out.logits, ref[0]) and torch.equal(out.hidden_states[-1], ref[1])
+    moff = build(cfg, sd, dtype, norm_fold=1, last_layer_shortcut=0)
+    out = moff(input_ids=ids, output_hidden_states=True, positions=[255, 3, 508])
+    assert torch.equal(out.logits, ref[0]) and torch.equal(out.hidden_states[-1], ref[1])
+    # chunking does not change the folded result either (rows are independent)
+    mc = build(cfg, sd, dtype, norm_fold=1, chunk_seqs=32)
+    out = mc(input_ids=ids, output_hidden_states=True, positions=[255, 3, 508])
+    assert torch.equal(out.logits, ref[0]) and torch.equal(out.hidden_states[-1], ref[1])

@@ -54,6 +54,30 @@ def test_abi_create_validates_config_without_gpu(lib):
     assert lib.pcad_create(None, None) == -1
 
 
+def test_two_handles_share_no_state(lib):
+    """include/pcad.h: distinct handles are independent.  Options, geometry and sizing of one handle never leak into another
+    (the per-device launch state - CU count, dynamic-LDS attribute - is keyed by device ordinal inside the library, csrc/pack.hip)."""
+    def mk(D, R):
+        c = engine.PcadConfig(d_model=D, n_layer=2, d_state=16, d_conv=4, expand=2, dt_rank=R, vocab=8, eps=1e-5, dtype=1,
+                              residual_in_fp32=1, complement=(C.c_int32 * 8)(0, 1, 2, 6, 5, 4, 3, 7))
+        h = C.c_void_p()
+        assert lib.pcad_create(C.byref(c), C.byref(h)) == 0
+        return h
+    a, b = mk(256, 16), mk(1024, 64)
+    wa, wb = lib.pcad_workspace_bytes(a, 64, 512), lib.pcad_workspace_bytes(b, 64, 512)
+    ar_a, ar_b = lib.pcad_weight_arena_bytes(a), lib.pcad_weight_arena_bytes(b)
+    assert wb > 3 * wa and ar_b > 3 * ar_a
+    assert lib.pcad_set_option(a, b"chunk_seqs", 8) == 0              # smaller chunks on handle a only
+    assert lib.pcad_workspace_bytes(a, 64, 512) < wa
+    assert lib.pcad_workspace_bytes(b, 64, 512) == wb
+    assert lib.pcad_set_option(b, b"gate_each", 1) == 0 and lib.pcad_set_option(b, b"norm_fold", 0) == 0
+    assert lib.pcad_workspace_bytes(a, 64, 512) < wa and lib.pcad_weight_arena_bytes(a) == ar_a
+    lib.pcad_destroy(b)                                                 # destroying one leaves the other usable
+    assert lib.pcad_workspace_bytes(a, 8, 512) > 0
+    assert lib.pcad_forward(a, None, 1, 8, None, 0, None, None, None, 0, None) == -2
+    lib.pcad_destroy(a)
+
+
 def test_config_derived_dims_and_support_check():
     for name, (D, nl, R) in {"l20": (384, 20, 24), "l24": (512, 24, 32), "l28": (768, 28, 48), "l32": (1024, 32, 64)}.items():
         c = make_config(name)
