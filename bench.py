@@ -113,8 +113,26 @@ def algorithmic_work(cfg, rows, esz):
                                bytes_8d=esz * rows * (1.5 * E + X),
                                valu_floor_cycles=rows * (E / 64.0) * (N / 2) * CYC_PAIR_MIX,
                                trans_cycles=rows * (E / 64.0) * N * CYC_EXP)
+    # "norm_fold": out_proj + fp32 residual read-modify-write + rounded copy + row statistics in ONE launch (§8(d) shares: the
+    # out_proj term LE + LD plus the add+norm term 4LD, of which the u read moves to in_proj's operand)
+    w["gemm_out_proj_res"] = dict(flops=2.0 * rows * E * D, bytes=esz * (rows * E + rows * D + E * D) + 8.0 * rows * D,
+                                  bytes_8d=esz * rows * (E + D) + esz * rows * 4 * D)
+    w["rstd_reduce"] = dict(flops=0.0, bytes=4.0 * rows * (D / 128 + 1), bytes_8d=0.0)
     w["final_head"] = dict(flops=0.0, bytes=0.0, bytes_8d=0.0)
     return w
+
+
+def executed_fraction_last_layer(cfg, L, p, shortcut: bool):
+    """What the last-layer shortcut (pcad_forward with a list of positions; bit-identical on the consumed rows) does NOT execute,
+    as (flops, bytes) per window to subtract from SURVEY.md §8(d)'s counts: the last layer's out_proj except 2 rows, and the part
+    of its two scans (with their dt_proj) beyond the furthest evaluated row (walk of max(p + 1, L - p) rounded up to 8 steps)."""
+    if not shortcut:
+        return 0.0, 0.0
+    D, E, N, R = cfg.d_model, cfg.d_inner, cfg.d_state, cfg.dt_rank
+    walk = min(L, (max(p + 1, L - p) + 7) // 8 * 8)
+    skip = 1.0 - walk / float(L)
+    flops = 2.0 * (2.0 * L * E * D) + 2.0 * 2.0 * (2.0 * L * R * E) * skip          # both strands; both directions
+    return flops, skip
 
 
 def source_hash():
@@ -144,12 +162,17 @@ def host_timings(n, L, device, torch, np):
     blk = torch.from_numpy(np.ascontiguousarray(ids[:1024]))
     pin = blk.pin_memory()
     for name, src in (("h2d_pageable_ms_per_1024", blk), ("h2d_pinned_ms_per_1024", pin)):
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(20):
-            d = src.to(device, non_blocking=True)
-        torch.cuda.synchronize()
-        out[name] = 1e3 * (time.perf_counter() - t0) / 20
+        best = None
+        for rep in range(4):                       # first repetition = warm-up (allocator, first-touch of the pinned pages); best of 3
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(200):
+                d = src.to(device, non_blocking=True)
+            torch.cuda.synchronize()
+            t = 1e3 * (time.perf_counter() - t0) / 200
+            if rep and (best is None or t < best):
+                best = t
+        out[name] = best
     # writers: the -input-table TSV (pandas, as the reference does) and the ISM VCF rows (ism._write_rows)
     import pandas as pd
     from plantcaduceus_amd import ism
@@ -166,6 +189,37 @@ def host_timings(n, L, device, torch, np):
     t0 = time.perf_counter()
     rows = ism._write_rows(buf, "1", 0, refs, sc)
     out["ism_vcf_rows_per_s"] = rows / (time.perf_counter() - t0)
+    return out
+
+
+def box_state(torch):
+    """Board power (W) and shader clock as sysfs reports them right now for THIS process's GPU, plus the power cap: printed next
+    to the headline so that numbers from different boxes can be compared (same build: +-3 % box to box)."""
+    import ctypes
+    import glob
+    out = {}
+    try:
+        hip = ctypes.CDLL("libamdhip64.so")
+        buf = ctypes.create_string_buffer(64)
+        hip.hipDeviceGetPCIBusId(buf, 64, torch.cuda.current_device())
+        bdf = buf.value.decode().lower()
+        for card in sorted(glob.glob("/sys/class/drm/card*")):
+            if bdf and bdf in os.path.realpath(os.path.join(card, "device")).lower():
+                for key, pat, scale in (("power_W", "/device/hwmon/hwmon*/power1_average", 1e-6), ("power_W", "/device/hwmon/hwmon*/power1_input", 1e-6),
+                                        ("power_cap_W", "/device/hwmon/hwmon*/power1_cap", 1e-6)):
+                    for f in glob.glob(card + pat):
+                        try:
+                            out.setdefault(key, round(float(open(f).read()) * scale, 1))
+                        except Exception:
+                            pass
+                for f in glob.glob(card + "/device/pp_dpm_sclk"):
+                    try:
+                        out["sclk"] = [ln.split(":")[1].replace("*", "").strip() for ln in open(f) if "*" in ln][0]
+                    except Exception:
+                        pass
+                break
+    except Exception as ex:
+        out["error"] = repr(ex)
     return out
 
 
@@ -250,6 +304,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    box = {"idle": box_state(torch)} if rank == 0 else {}
     for _ in range(args.warmup):
         out = step()
     if not args.no_profile:
@@ -258,6 +313,8 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step()
+    if rank == 0:
+        box["end_of_timed_region"] = box_state(torch)          # read while the last step is still running (before the fence)
     fence()
     dt = time.perf_counter() - t0
     eng.profile(False)
@@ -295,12 +352,22 @@ def main():
         }
         # ---- whole step against the chip peaks, from SURVEY.md §8(d)'s per-sequence counts ----------------------
         fl_seq, by_seq = per_sequence_work(cfg, L, esz)
+        opts = dict(kv.split("=", 1) for kv in args.opt)
+        shortcut = args.workload != "ism" and opts.get("last_layer_shortcut", "1") != "0"
+        fl_skip, scan_skip = executed_fraction_last_layer(cfg, L, p, shortcut)
+        # bytes the shortcut skips: the last layer's out_proj term (LE + LD) and scan_skip of its scan term (3LE), both strands
+        by_skip = 2.0 * esz * ((L * cfg.d_inner + L * cfg.d_model) + 3.0 * L * cfg.d_inner * scan_skip) if shortcut else 0.0
+        fl_exec, by_exec = fl_seq - fl_skip, by_seq - by_skip
         res["whole_step"] = {"flops_per_seq": fl_seq, "hbm_bytes_per_seq": by_seq,
-                             "TFLOP/s": fl_seq * total / dt / 1e12 / world, "GB/s": by_seq * total / dt / 1e9 / world,
-                             "mfma_frac": fl_seq * total / dt / 1e12 / world / PEAK[args.dtype],
-                             "hbm_frac": by_seq * total / dt / 1e9 / world / PEAK_HBM,
-                             "note": "per GPU; SURVEY.md §8(d) algorithmic flops (tie-folded) and bytes (GEMM-boundary fusion) "
-                                     "per window x windows / timed wall clock"}
+                             "flops_per_seq_executed": fl_exec, "hbm_bytes_per_seq_executed": by_exec,
+                             "TFLOP/s": fl_exec * total / dt / 1e12 / world, "GB/s": by_exec * total / dt / 1e9 / world,
+                             "mfma_frac": fl_exec * total / dt / 1e12 / world / PEAK[args.dtype],
+                             "hbm_frac": by_exec * total / dt / 1e9 / world / PEAK_HBM,
+                             "note": "per GPU; SURVEY.md §8(d) algorithmic flops (tie-folded) and bytes (GEMM-boundary fusion) per "
+                                     "window MINUS what the last-layer shortcut does not execute (last out_proj except the evaluated "
+                                     "rows, the scans beyond the furthest evaluated row: %.2f %% of the flops), x windows / timed wall clock"
+                                     % (100.0 * fl_skip / fl_seq)}
+        res["box"] = box
         chunk_max = max(1, ((((1 << 32) - (2 << 20)) // (cfg.d_inner * esz)) & ~7) // (2 * L))   # as api.hip
         if args.chunk_seqs:
             chunk_max = args.chunk_seqs
@@ -321,10 +388,15 @@ def main():
                               "GB/s": round(work[name]["bytes_8d"] / (avg * 1e-3) / 1e9, 1),
                               "executed_GB/s": round(work[name]["bytes"] / (avg * 1e-3) / 1e9, 1)}
         if kern:
-            per_step = {"add_rmsnorm": 1, "gemm_in_proj": 1, "conv1d_bidir": 1, "conv_xproj_fused": 1, "gemm_x_proj": 2, "selective_scan": 2,
-                        "gemm_out_proj": 1, "final_head": 0}     # launches per layer and chunk
+            nl = cfg.n_layer
+            full_out = nl - 1 if shortcut else nl                # full-size out_proj launches per chunk (the shortcut's is a 2B-row GEMM)
+            folded = "gemm_out_proj_res" in kern
+            per_chunk = {"add_rmsnorm": 0 if folded else nl, "rstd_reduce": nl if folded else 0, "gemm_in_proj": nl, "conv1d_bidir": nl,
+                         "conv_xproj_fused": nl, "gemm_x_proj": 2 * nl, "selective_scan": 2 * nl,
+                         "gemm_out_proj": (0 if shortcut else 1) if folded else full_out,
+                         "gemm_out_proj_res": nl - 1 if folded else 0, "final_head": 0}     # launches per chunk
             for name in kern:
-                kern[name]["est_ms_per_step"] = round(kern[name]["avg_ms"] * per_step.get(name, 0) * cfg.n_layer * nchunks, 2)
+                kern[name]["est_ms_per_step"] = round(kern[name]["avg_ms"] * per_chunk.get(name, 0) * nchunks, 2)
             dom = max(kern, key=lambda k: kern[k]["est_ms_per_step"])
             avg_s = kern[dom]["avg_ms"] * 1e-3
             if dom.startswith("gemm"):
