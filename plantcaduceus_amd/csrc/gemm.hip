@@ -41,6 +41,20 @@ constexpr int STAGE_BYTES = A_BYTES + W_BYTES;
 constexpr int NSTAGE = 3;
 constexpr int GEMM_LDS = NSTAGE * STAGE_BYTES;         // 144 KiB
 constexpr int GEMM_THREADS = 512;
+// Tile walk of the persistent kernels: every XCD walks a contiguous range of the logical tile order, its 32 CUs running 32
+// consecutive tiles at a time.  Bits 0-7: GROUP_M - the logical order is m-fastest inside groups of GROUP_M m-panels (a "round" of
+// 32 tiles = GROUP_M A panels x 32 / GROUP_M W panels); bit 8: n-fastest instead (a round = the fewest A panels, every W panel).
+// A COMPILE-TIME constant: as a run-time kernel argument it cost the 4-wave kernel 12 % (863 / 1013 vs 988 / 1135 TF, same box).
+// Swept in round 4 at the benchmark's launch size (tools/gemm_walk.sh, one build per walk: profiles/r04_gemm_walk.txt):
+//   in_proj  ms / L2->fabric read GB:  2: 3.86 / 10.0   4: 3.72 / 6.8   8: 3.72 / 6.5   16: 3.78 / 9.7   32: 4.07 / 17.7   n-fastest: 3.82 / 10.1
+//   out_proj                         :  2: 1.70 / 3.2    4: 1.69 / 3.2   8: 1.70 / 3.2   16: 1.73 / 4.8   32: 1.95 / 8.9    n-fastest: 1.70 / 3.2
+// 8 is the minimum of both for in_proj (a round's 8 A panels + 4 W panels = 6 MB per 32 tiles is the least a 32-tile round can
+// fetch: (gm + gn) x 0.5 MB with gm x gn = 32; the 4 MiB L2 keeps nothing across rounds, the re-reads are served by the
+// Infinity Cache) and out_proj has only 4 n-tiles, which every walk <= 8 covers in one round.
+#ifndef PCAD_WALK_CONST
+#define PCAD_WALK_CONST 8
+#endif
+constexpr int walk = PCAD_WALK_CONST;
 
 __device__ __forceinline__ int key_a(int r) { return (r >> 1) & 7; }
 __device__ __forceinline__ int key_w(int r) { return (((r >> 4) & 3) << 1) | ((r >> 1) & 1); }
@@ -72,7 +86,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_kernel(const T* __res
                                                                   OutT* __restrict__ C, int64_t ldc, int64_t M, int N,
                                                                   int K, int tiles_m, int tiles_n,
                                                                   float* __restrict__ C2, int64_t ldc2, int nsplit,
-                                                                  int a_blocked, int walk) {
+                                                                  int a_blocked) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -324,7 +338,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm256r_kernel(const T* __re
                                                                    const T* __restrict__ W, int64_t ldw,
                                                                    OutT* __restrict__ C, int64_t ldc, int64_t M, int N,
                                                                    int K, int tiles_m, int tiles_n, int a_blocked,
-                                                                   OutT* __restrict__ C2, int nsplit, int out_blocked, int walk) {
+                                                                   OutT* __restrict__ C2, int nsplit, int out_blocked) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -649,7 +663,7 @@ __global__ __launch_bounds__(GEMMQ_THREADS, 1) void gemm256q_kernel(const T* __r
                                                                     const T* __restrict__ W, int64_t ldw,
                                                                     OutT* __restrict__ C, int64_t ldc, int64_t M, int N,
                                                                     int K, int tiles_m, int tiles_n, int a_blocked,
-                                                                    OutT* __restrict__ C2, int nsplit, int out_blocked, int epi_swap, int walk,
+                                                                    OutT* __restrict__ C2, int nsplit, int out_blocked, int epi_swap,
                                                                     GemmEpi epi) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -992,17 +1006,6 @@ __global__ __launch_bounds__(GEMMQ_THREADS, 1) void gemm256q_kernel(const T* __r
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // trailing (unused) DMAs must not outlive the block's LDS
 }
 
-// Tile walk of the persistent kernels (kernel argument `walk`): every XCD walks a contiguous range of the logical tile order, its
-// 32 CUs running 32 consecutive tiles at a time.  Bits 0-7: GROUP_M, the logical order is m-fastest inside groups of GROUP_M
-// m-panels (a "round" of 32 tiles = GROUP_M A panels x 32 / GROUP_M W panels);  bit 8: n-fastest instead (a round = the fewest A
-// panels, every W panel).  PCAD_DEV=1 PCAD_GEMM_WALK=<int> overrides (A/B sweeps: profiles/r04_gemm_walk.txt).
-static int tile_walk(int tiles_m, int tiles_n) {
-    static const char* ov = dev_env("PCAD_GEMM_WALK");
-    if (ov) { const int w = atoi(ov); if ((w & 256) || (w & 255) > 0) return w; }
-    (void)tiles_m; (void)tiles_n;
-    return 8;
-}
-
 // persistent launch: 1 resident block per CU (LDS-limited), a multiple of 8 so block b stays on XCD b & 7
 static int persistent_grid(int nblk) {
     const int cap = device_cu_count() / 8 * 8;
@@ -1019,12 +1022,12 @@ static hipError_t launch_gemm_t(const void* A, int64_t lda, const void* W, int64
         auto kfn = gemm_nt_kernel<T, OutT, ROUND, true, false>;
         if (hipError_t ae = ensure_dynamic_lds((const void*)kfn, GEMM_LDS)) return ae;
         hipLaunchKernelGGL(kfn, grid, block, GEMM_LDS, s, (const T*)A, lda, (const T*)W, ldw, (OutT*)C, ldc, M, N, K,
-                           tiles_m, tiles_n, (float*)nullptr, (int64_t)0, 0, (int)a_blocked, tile_walk(tiles_m, tiles_n));
+                           tiles_m, tiles_n, (float*)nullptr, (int64_t)0, 0, (int)a_blocked);
     } else {
         auto kfn = gemm_nt_kernel<T, OutT, ROUND, false, false>;
         if (hipError_t ae = ensure_dynamic_lds((const void*)kfn, GEMM_LDS)) return ae;
         hipLaunchKernelGGL(kfn, grid, block, GEMM_LDS, s, (const T*)A, lda, (const T*)W, ldw, (OutT*)C, ldc, M, N, K,
-                           tiles_m, tiles_n, (float*)nullptr, (int64_t)0, 0, (int)a_blocked, tile_walk(tiles_m, tiles_n));
+                           tiles_m, tiles_n, (float*)nullptr, (int64_t)0, 0, (int)a_blocked);
     }
     return hipGetLastError();
 }
@@ -1038,7 +1041,7 @@ static hipError_t launch_gemm_split_t(const void* A, int64_t lda, const void* W,
     auto kfn = gemm_nt_kernel<T, T, false, true, true>;
     if (hipError_t ae = ensure_dynamic_lds((const void*)kfn, GEMM_LDS)) return ae;
     hipLaunchKernelGGL(kfn, grid, block, GEMM_LDS, s, (const T*)A, lda, (const T*)W, ldw, (T*)C, ldc, M, N, K, tiles_m,
-                       tiles_n, C2, ldc2, nsplit, (int)a_blocked, tile_walk(tiles_m, tiles_n));
+                       tiles_n, C2, ldc2, nsplit, (int)a_blocked);
     return hipGetLastError();
 }
 
@@ -1077,8 +1080,8 @@ static hipError_t launch_gemm256_t(const void* A, int64_t lda, const void* W, in
         auto kq = gemm256q_kernel<T, T, EPIK>;                                                                                  \
         if (hipError_t ae = ensure_dynamic_lds((const void*)kq, GEMM3_LDS)) return ae;                                          \
         hipLaunchKernelGGL(kq, grid, dim3(GEMMQ_THREADS), GEMM3_LDS, s, (const T*)A, lda, (const T*)W, ldw, (T*)C, ldc, M, N, K, \
-                           tiles_m, tiles_n, (int)a_blocked, (T*)C2, nsplit, (int)out_blocked, (int)epi_swap,                   \
-                           tile_walk(tiles_m, tiles_n), epi);                                                                   \
+                           tiles_m, tiles_n, (int)a_blocked, (T*)C2, nsplit, (int)out_blocked, (int)epi_swap, epi);            \
+                                                                                             \
         return hipGetLastError();                                                                                               \
     } while (0)
     if (epi_kind == EPI_SCALE) PCAD_LAUNCH_Q(EPI_SCALE);
@@ -1088,7 +1091,7 @@ static hipError_t launch_gemm256_t(const void* A, int64_t lda, const void* W, in
     auto kr = gemm256r_kernel<T, T>;
     if (hipError_t ae = ensure_dynamic_lds((const void*)kr, GEMM3_LDS)) return ae;
     hipLaunchKernelGGL(kr, grid, block, GEMM3_LDS, s, (const T*)A, lda, (const T*)W, ldw, (T*)C, ldc, M, N, K, tiles_m,
-                       tiles_n, (int)a_blocked, (T*)C2, nsplit, (int)out_blocked, tile_walk(tiles_m, tiles_n));
+                       tiles_n, (int)a_blocked, (T*)C2, nsplit, (int)out_blocked);
     return hipGetLastError();
 }
 

@@ -35,7 +35,7 @@ hipError_t launch_add_rmsnorm(const void* x, const void* res_in, const float* w,
 hipError_t launch_embed_rmsnorm(const int32_t* ids, const void* emb, const int32_t* comp8, const float* w,
                                 void* y, void* res_out, int B, int L, int D, float eps, int dt, int rdt,
                                 hipStream_t s, float* rstd_out = nullptr);
-// rstd[row] = rsqrt(sum of the np partial sums of squares of the row / D + eps)   (np % 4 == 0)
+// rstd[row] = rsqrt(sum of the np partial sums of squares of the row / D + eps)
 hipError_t launch_rstd(const float* ssq, float* rstd, int64_t rows, int np, int D, float eps, hipStream_t s);
 // final add + norm_f + RC re-assembly + tied RCPS LM head, only at the requested positions (a shared list `pos`,
 // or one position per window from the device array `pos_per_seq` [B]).  h_compact: h holds only the evaluated rows,

@@ -87,16 +87,19 @@ __global__ __launch_bounds__(256) void rstd_kernel(const float* __restrict__ ssq
     if (row >= rows) return;
     const float* p = ssq + row * np;
     float acc = 0.f;
-    for (int i = 0; i < np; i += 4) {
-        const f32x4 v = *reinterpret_cast<const f32x4*>(p + i);
-        acc += (v[0] + v[1]) + (v[2] + v[3]);
-    }
+    int i = 0;
+    if ((np & 3) == 0)
+        for (; i < np; i += 4) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(p + i);
+            acc += (v[0] + v[1]) + (v[2] + v[3]);
+        }
+    for (; i < np; ++i) acc += p[i];
     rstd[row] = rsqrtf(acc * inv_d + eps);
 }
 
 hipError_t launch_rstd(const float* ssq, float* rstd, int64_t rows, int np, int D, float eps, hipStream_t s) {
     if (rows <= 0) return hipSuccess;
-    if (np <= 0 || np % 4) return hipErrorInvalidValue;
+    if (np <= 0) return hipErrorInvalidValue;
     hipLaunchKernelGGL(rstd_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, s, ssq, rstd, rows, np, 1.0f / (float)D, eps);
     return hipGetLastError();
 }

@@ -239,7 +239,7 @@ def test_linear_residual(ops, M, N, K, dtype):
     ref = res.double() + x.double() @ w.double().t()
     r_dev = res.to(DEV).clone()
     out, ssq = ops.linear_residual(x.to(DEV), w.to(DEV), r_dev)
-    tol = 2e-6 if dtype == torch.float32 else 1e-5          # bf16 products are exact in fp32: only the accumulation order differs
+    tol = 5e-6 if dtype == torch.float32 else 1e-5          # fp32: exact products, only the accumulation order differs (K up to 2048, |res| ~ 3 sigma 9); bf16 products are exact in fp32
     assert relerr(r_dev, ref) < tol
     if dtype == torch.bfloat16:
         assert torch.equal(out.cpu(), r_dev.cpu().bfloat16())            # C is the updated residual rounded once
