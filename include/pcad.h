@@ -241,8 +241,14 @@ int pcad_gemm_nt(const void* A, int64_t lda, const void* W, int64_t ldw, void* C
 
 /* out_proj of the "norm_fold" layer form as one operator (MFMA, 256 x 256 tiles only: M % 256 == 0, N % 256 == 0, K * elem a
  * multiple of 128 bytes, every tensor < 4 GiB):
- *   res [M, N] fp32 += A [M, K] . W [N, K]^T   (in place; the mixer output added to the fp32 residual stream)
- *   C   [M, N] dtype  = round(res)              (bf16 model; ignored / may be NULL for the fp32 model)
+ *   res [M, N] fp32 += A [M, K] . W [N, K]^T   (in place; the mixer output added to the fp32 residual stream).  res is in the
+ *                       kernel's FRAGMENT layout - the order in which the GEMM's lanes hold a 256 x 256 tile, so that the
+ *                       read-modify-write moves whole cache lines: element (row, col) lives at float offset
+ *                         ((((tile * 4 + wave) * 8 + i) * 2 + jg) * 4 + k) * 256 + (16 lg + li) * 4 + r     with
+ *                         tile = (row / 256) * (N / 256) + col / 256, wave = 2 ((row / 128) % 2) + (col / 128) % 2,
+ *                         i = (row / 16) % 8, li = row % 16, jg = (col / 64) % 2, lg = (col / 16) % 4, k = (col / 4) % 4, r = col % 4
+ *                       (csrc/common.hpp res_frag_off; plantcaduceus_amd.ops.to_res_fragment / from_res_fragment)
+ *   C   [M, N] dtype  = round(res)              (plain rows: the next in_proj's operand)
  *   ssq [M, N / 128]  = per-row sums of squares of the updated res over each 128-column slab (deterministic partials whose
  *                       sum / N gives the next block's RMSNorm statistic)
  * Replaces: out_proj (F.linear) + the residual add of rms_norm_fn(..., prenorm=True, residual_in_fp32=True). */
@@ -259,14 +265,14 @@ int pcad_gather_rows(const void* src, void* out, int B, int L, int E, const int3
 /* The forward's last kernel as one operator: res + h -> norm_f -> RC re-assembly of hidden_states[-1] -> tied RCPS LM head, at
  * the shared positions (HOST int32 [P], P = 0: all L) or one position per window (pos_per_seq, DEVICE int32 [B]; then
  * positions must be NULL / P = 0).  h / res: [2B * L, D] (h: dtype, res: res_dtype); h_compact != 0: h holds only the evaluated
- * rows as pcad_gather_rows orders them.  emb_f32: [vocab, D] fp32 (the dtype-rounded tied embedding / LM-head weight);
+ * rows as pcad_gather_rows orders them; res_fragment_layout != 0: res (fp32) is in the fragment layout of pcad_gemm_nt_residual.  emb_f32: [vocab, D] fp32 (the dtype-rounded tied embedding / LM-head weight);
  * hidden_out [B, Q, 2D] dtype and logits_out [B, Q, vocab] fp32, either may be NULL.  ids (DEVICE [B, L]) and status (DEVICE
  * word) may be NULL: input validation as in pcad_set_status_buffer.
  * Replaces: norm_f (rms_norm_fn) x2, the flips / cats of RCPSWrapper's output and RCPSLMHead. */
 int pcad_final_head(const void* h, const void* res, const float* norm_weight, const float* emb_f32, const int32_t* complement,
                     void* hidden_out, float* logits_out, int B, int L, int D, float eps, const int32_t* positions, int P,
                     const int32_t* pos_per_seq, int h_compact, const int32_t* ids, int32_t* status, int dtype, int res_dtype,
-                    pcad_stream stream);
+                    int res_fragment_layout, pcad_stream stream);
 
 #ifdef __cplusplus
 }

@@ -448,7 +448,10 @@ static int forward_impl(pcad_handle h, const int32_t* ids, int B, int L, const i
     // res += y . W_out^T in fp32 (the accumulators start as the residual values), writes round(res) and per-row partial sums of
     // squares; in_proj runs on round(res) with W_in . diag(w_norm) (folded at bind time) and multiplies by rstd[row] before it
     // rounds.  The add + norm launch and its read of h / write of u disappear; what moves is rounding: h is not rounded before it
-    // is added, and the operand of in_proj is round(res) instead of round(res * rstd * w).  Used when every GEMM of the chunk
+    // is added, and the operand of in_proj is round(res) instead of round(res * rstd * w).  While a chunk runs in this form its
+    // fp32 residual tensor is kept in the GEMM's fragment layout (common.hpp res_frag_off) so that the epilogue's
+    // read-modify-write moves whole lines; only the embedding kernel, the folded out_proj and the head kernel touch it.
+    // Used when every GEMM of the chunk
     // runs on the 4-wave kernel (whole 256 x 256 tiles) and the residual stream is fp32; never for pcad_forward_all_hidden
     // (hidden_states[i] are the mixer outputs h, which the folded form never materialises).
     auto fold_for = [&](const Lane& c) -> bool {
@@ -462,9 +465,9 @@ static int forward_impl(pcad_handle h, const int32_t* ids, int B, int L, const i
         const int64_t rows = (int64_t)S * L;
         const int32_t* ids_c = ids + (int64_t)c.b0 * L;
         if (c.fold) {
-            if (li == 0) {      // res = Emb[token], u = the same rows in the model dtype (fp32 model: in_proj reads res), rstd
+            if (li == 0) {      // res = Emb[token] (fp32, fragment layout), u = the same rows in the model dtype (plain), rstd
                 ProfScope ps(e, PCAD_K_RSTD, s);
-                HIP_TRY(launch_embed_rmsnorm(ids_c, e->emb, e->comp, W.norm_w, dt == BF16 ? c.w.u : nullptr, c.w.res, c.Bc, L, D, eps, dt, rdt, s, c.w.rstd));
+                HIP_TRY(launch_embed_rmsnorm(ids_c, e->emb, e->comp, W.norm_w, c.w.u, c.w.res, c.Bc, L, D, eps, dt, rdt, s, c.w.rstd));
             }
             return PCAD_OK;     // later layers: the previous out_proj's epilogue already produced res, round(res) and rstd
         }
@@ -488,7 +491,7 @@ static int forward_impl(pcad_handle h, const int32_t* ids, int B, int L, const i
         const int64_t rows = (int64_t)S * L;
         // in_proj (tied between directions: once per strand)
         { ProfScope ps(e, PCAD_K_GEMM_IN, s);
-        if (c.fold) HIP_TRY(launch_gemm_nt_two(dt == BF16 ? c.w.u : c.w.res, D, W.W_in_f, D, c.w.xz, c.w.zb, E, true, rows, 2 * E, D, dt, s, c.w.rstd));
+        if (c.fold) HIP_TRY(launch_gemm_nt_two(c.w.u, D, W.W_in_f, D, c.w.xz, c.w.zb, E, true, rows, 2 * E, D, dt, s, c.w.rstd));
         else if (e->xzsplit) HIP_TRY(launch_gemm_nt_two(c.w.u, D, W.W_in, D, c.w.xz, c.w.zb, E, true, rows, 2 * E, D, dt, s));
         else HIP_TRY(launch_gemm_nt(c.w.u, D, W.W_in, D, c.w.xz, 2 * E, rows, 2 * E, D, dt, dt, false, s)); }
         // conv1d + SiLU, causal and anti-causal from one read of x (fused with x_proj of both directions when possible)
@@ -548,7 +551,7 @@ static int forward_impl(pcad_handle h, const int32_t* ids, int B, int L, const i
         }
         if (c.fold && li + 1 < e->nl) {     // out_proj + residual add + the next block's norm statistics in one launch
             { ProfScope ps(e, PCAD_K_GEMM_OUT_RES, s);
-            HIP_TRY(launch_gemm_nt_res(c.w.y, E, W.W_out, E, dt == BF16 ? c.w.u : nullptr, (float*)c.w.res, c.w.ssq, rows, D, E, dt, s, e->blocked)); }
+            HIP_TRY(launch_gemm_nt_res(c.w.y, E, W.W_out, E, c.w.u, (float*)c.w.res, c.w.ssq, rows, D, E, dt, s, e->blocked)); }
             ProfScope ps(e, PCAD_K_RSTD, s);
             HIP_TRY(launch_rstd(c.w.ssq, c.w.rstd, rows, D / 128, D, eps, s));
             return PCAD_OK;
@@ -569,7 +572,7 @@ static int forward_impl(pcad_handle h, const int32_t* ids, int B, int L, const i
             ProfScope ps(e, PCAD_K_HEAD, cs);
             HIP_TRY(launch_final_head(c.w.h, c.w.res, e->normf_w, e->emb, e->emb_f32, e->comp, hout, lout, c.Bc, L, D, eps,
                                       pos, pos_per_seq ? pos_per_seq + c.b0 : nullptr, dt, rdt, cs, walk_len > 0,
-                                      ids + (int64_t)c.b0 * L, e->status));
+                                      ids + (int64_t)c.b0 * L, e->status, c.fold));
         }
         return PCAD_OK;
     };
@@ -736,7 +739,7 @@ int pcad_gemm_nt(const void* A, int64_t lda, const void* W, int64_t ldw, void* C
 
 int pcad_gemm_nt_residual(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, float* res, float* ssq, int64_t M, int N,
                           int K, int dtype, pcad_stream stream) {
-    if (!A || !W || !res || !ssq || (dtype == PCAD_BF16 && !C)) return fail(PCAD_ERR_INVALID, "pcad_gemm_nt_residual: null argument");
+    if (!A || !W || !res || !ssq || !C) return fail(PCAD_ERR_INVALID, "pcad_gemm_nt_residual: null argument");
     if (dtype != PCAD_F32 && dtype != PCAD_BF16) return fail(PCAD_ERR_INVALID, "pcad_gemm_nt_residual: bad dtype");
     if (M < 0 || N <= 0 || K <= 0 || M % 256 || N % 256 || M * (int64_t)N * 4 >= ((int64_t)1 << 32))
         return fail(PCAD_ERR_INVALID, "pcad_gemm_nt_residual: M and N must be multiples of 256 and M * N * 4 < 2^32");
@@ -773,8 +776,10 @@ int pcad_gather_rows(const void* src, void* out, int B, int L, int E, const int3
 int pcad_final_head(const void* h, const void* res, const float* norm_weight, const float* emb_f32, const int32_t* complement,
                     void* hidden_out, float* logits_out, int B, int L, int D, float eps, const int32_t* positions, int P,
                     const int32_t* pos_per_seq, int h_compact, const int32_t* ids, int32_t* status, int dtype, int res_dtype,
-                    pcad_stream stream) {
+                    int res_fragment_layout, pcad_stream stream) {
     if (!h || !res || !norm_weight || !emb_f32 || !complement) return fail(PCAD_ERR_INVALID, "pcad_final_head: null argument");
+    if (res_fragment_layout && (res_dtype != PCAD_F32 || D % 256 || ((int64_t)2 * B * L) % 256))
+        return fail(PCAD_ERR_INVALID, "pcad_final_head: the fragment layout needs an fp32 residual, D %% 256 == 0 and 2 B L %% 256 == 0");
     if ((dtype != PCAD_F32 && dtype != PCAD_BF16) || (res_dtype != PCAD_F32 && res_dtype != PCAD_BF16) || (dtype == PCAD_F32 && res_dtype != PCAD_F32))
         return fail(PCAD_ERR_INVALID, "pcad_final_head: bad dtype / res_dtype");
     if (B < 0 || L <= 0 || D <= 0 || D % 8 || D > 2048) return fail(PCAD_ERR_INVALID, "pcad_final_head: bad B / L / D");
@@ -784,7 +789,7 @@ int pcad_final_head(const void* h, const void* res, const float* norm_weight, co
     if (int rc = positions_arg("pcad_final_head", positions, P, L, &pos)) return rc;
     if (B == 0) return PCAD_OK;
     HIP_TRY(launch_final_head(h, res, norm_weight, nullptr, emb_f32, complement, hidden_out, logits_out, B, L, D, eps, pos, pos_per_seq,
-                              dtype, res_dtype, (hipStream_t)stream, h_compact != 0, ids, status));
+                              dtype, res_dtype, (hipStream_t)stream, h_compact != 0, ids, status, res_fragment_layout != 0));
     return PCAD_OK;
 }
 

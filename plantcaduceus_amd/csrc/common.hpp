@@ -91,6 +91,21 @@ __host__ __device__ __forceinline__ int64_t blocked_off(int64_t r, int64_t cb, i
     return (((r >> 3) * pieces + (cb >> 7)) << 10) + ((r & 7) << 7) + (cb & 127);
 }
 
+// "Fragment" layout of the fp32 residual stream in the norm-folded layer form (api.hip "norm_fold"): the order in which the 4-wave
+// GEMM's lanes hold a 256 x 256 output tile in their accumulators, so that the read-modify-write in out_proj's epilogue is
+// whole 1 KiB runs per instruction (in plain rows a lane's 16 bytes sit in a different row than its neighbour's: 64 separate
+// 16-byte requests per store instruction, which made the epilogue L2-request-bound: +23 us per tile measured).
+//   [tile_m][tile_n][wave = 2 wm + wn][i = 0..7][jg = 0..1][k = 0..3][lane = 16 lg + li][r = 0..3]   (floats)
+//   row = 256 tile_m + 128 wm + 16 i + li,   col = 256 tile_n + 128 wn + 64 jg + 16 lg + 4 k + r
+// float offset of the 4-float quad that holds (row, col), col % 4 == 0, for a [rows, D] tensor (rows % 256 == 0, D % 256 == 0):
+__host__ __device__ __forceinline__ int64_t res_frag_off(int64_t row, int col, int D) {
+    const int64_t tile = (row >> 8) * (D >> 8) + (col >> 8);
+    const int wave = (int)((row >> 7) & 1) * 2 + ((col >> 7) & 1);
+    const int i = (int)(row >> 4) & 7, li = (int)row & 15;
+    const int jg = (col >> 6) & 1, lg = (col >> 4) & 3, k = (col >> 2) & 3;
+    return (((tile * 4 + wave) * 8 + i) * 2 + jg) * 1024 + k * 256 + (lg * 16 + li) * 4;
+}
+
 constexpr float kLog2e = 1.4426950408889634f;
 constexpr float kLn2 = 0.6931471805599453f;
 

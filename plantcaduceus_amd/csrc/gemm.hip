@@ -646,7 +646,8 @@ template <int OFF> __device__ __forceinline__ void gload_v32(float& dst, uint32_
 // prenorm=True, residual_in_fp32=True) between out_proj of one block and in_proj of the next):
 //   EPI_SCALE  C = (A . W^T) * rscale[row]                 in_proj on the UN-normalised residual with W_in . diag(w_norm) folded at
 //              bind time: rscale = rstd of the row.  The 8 factors a lane needs are fetched when the tile starts.
-//   EPI_RES    res += A . W^T (fp32, in place);  C = round(res);  ssq[row][n / 128] = sum of res^2 over the wave's 128 columns.
+//   EPI_RES    res += A . W^T (fp32, in place, fragment layout: common.hpp res_frag_off);  C = round(res) (plain rows);
+//              ssq[row][n / 128] = sum of res^2 over the wave's 128 columns.
 //              The accumulators START as the tile's residual values (loaded straight into the accumulator-file registers when
 //              the tile begins; the first k-step waits row by row), so the read-modify-write of the fp32 stream costs no
 //              register and no separate pass; the per-row partial sums of squares are written without atomics
@@ -654,8 +655,9 @@ template <int OFF> __device__ __forceinline__ void gload_v32(float& dst, uint32_
 enum { EPI_NONE = 0, EPI_SCALE = 1, EPI_RES = 2 };
 struct GemmEpi {
     const float* rscale;    // EPI_SCALE: [M]
-    float* res;             // EPI_RES: [M, N] fp32, row stride N
+    float* res;             // EPI_RES: [M, N] fp32 in the fragment layout (common.hpp res_frag_off)
     float* ssq;             // EPI_RES: [M, N / 128]
+    int stagger;            // EPI_RES: start delay per phase step in shader cycles (0: none), see the kernel
 };
 
 template <typename T, typename OutT, int EPI>
@@ -675,6 +677,19 @@ __global__ __launch_bounds__(GEMMQ_THREADS, 1) void gemm256q_kernel(const T* __r
     if ((int)blockIdx.x >= nblk) return;
     const int my_tiles = (nblk - (int)blockIdx.x + gstride - 1) / gstride;
     const int G = my_tiles * nkt;                                 // K-tiles this block walks
+    if constexpr (EPI == EPI_RES) {
+        // Staggered start.  Every block walks equally long tiles, so left alone all 256 CUs reach their epilogues together and
+        // the residual read-modify-write (512 KiB per tile on top of the 128 KiB result) hits HBM as one synchronised 160 MB
+        // burst per round of tiles while the memory system idles during the mainloops (measured: +23.6 us per 50 us tile, the
+        // time that burst takes at ~5.5 TB/s).  Delaying block b by ((b / 8) % 8) eighths of a tile time keeps an eighth of
+        // every XCD's CUs in their epilogue at any moment instead; the price is the last phase's tail, 7/8 of one tile per launch.
+        const int phase = ((int)blockIdx.x >> 3) & 7;
+        if (epi.stagger > 0 && phase != 0) {
+            const uint64_t t0 = __builtin_amdgcn_s_memtime();
+            const uint64_t want = (uint64_t)phase * (uint64_t)epi.stagger;
+            while (__builtin_amdgcn_s_memtime() - t0 < want) __builtin_amdgcn_s_sleep(32);
+        }
+    }
 
     auto tile_coords = [&](int tile, int64_t& m0, int& n0) {
         const int xcd = tile & 7, idx = tile >> 3;
@@ -846,22 +861,26 @@ __global__ __launch_bounds__(GEMMQ_THREADS, 1) void gemm256q_kernel(const T* __r
             gload_v32<256>(rs[4], vo, sb); gload_v32<320>(rs[5], vo, sb); gload_v32<384>(rs[6], vo, sb); gload_v32<448>(rs[7], vo, sb);
         }
     };
-    // EPI_RES: residual values of tile (m0, n0) -> accumulator group (i, jg): 4 x 16 bytes per lane, straight into the AGPRs
-    const uint32_t res_vo = ((uint32_t)li * (uint32_t)N + (uint32_t)lg * 16u) * 4u;
-    auto res_tile_base = [&](int64_t m0, int n0) -> const float* {
-        return epi.res + ((m0 + wm * 128) * (int64_t)N + n0 + wn * 128);
+    // EPI_RES: residual values of tile (m0, n0) -> accumulator group (i, jg): 4 x 16 bytes per lane, straight into the AGPRs.
+    // The residual tensor is in the fragment layout (common.hpp res_frag_off): the wave's 128 x 128 part of a tile is 64 KiB
+    // contiguous, group (i, jg) quad k = 1 KiB = lane-linear 16-byte pieces, so every access instruction moves whole lines.
+    const uint32_t res_vo = (uint32_t)lane * 16u;
+    auto res_tile_base = [&](int64_t m0, int n0) -> float* {
+        return epi.res + ((((m0 >> 8) * (int64_t)(N >> 8) + (n0 >> 8)) * 4 + wave) << 14);
     };
     auto load_res_group = [&](const float* tb, int i, int jg) {
-        const float* sb = tb + ((int64_t)i * 16 * N + jg * 64);
-        gload_a128<0>(acc[i][jg * 4 + 0], res_vo, sb);  gload_a128<16>(acc[i][jg * 4 + 1], res_vo, sb);
-        gload_a128<32>(acc[i][jg * 4 + 2], res_vo, sb); gload_a128<48>(acc[i][jg * 4 + 3], res_vo, sb);
+        const float* sb = tb + (i * 2 + jg) * 1024;
+        gload_a128<0>(acc[i][jg * 4 + 0], res_vo, sb);    gload_a128<1024>(acc[i][jg * 4 + 1], res_vo, sb);
+        gload_a128<2048>(acc[i][jg * 4 + 2], res_vo, sb); gload_a128<3072>(acc[i][jg * 4 + 3], res_vo, sb);
     };
     auto epilogue = [&](int64_t m0, int n0) {
         const int64_t mrow = m0 + wm * 128 + li;
         float ss[8];
+        float* res_tb = nullptr;
         if constexpr (EPI == EPI_RES) {
 #pragma unroll
             for (int i = 0; i < 8; ++i) ss[i] = 0.f;
+            res_tb = res_tile_base(m0, n0);
         }
 #pragma unroll
         for (int jg = 0; jg < 2; ++jg) {
@@ -890,17 +909,13 @@ __global__ __launch_bounds__(GEMMQ_THREADS, 1) void gemm256q_kernel(const T* __r
                 f32x4 t0 = acc[i][jg * 4 + 0], t1 = acc[i][jg * 4 + 1], t2 = acc[i][jg * 4 + 2], t3 = acc[i][jg * 4 + 3];
                 asm volatile("" : "+v"(t0), "+v"(t1), "+v"(t2), "+v"(t3));
                 if constexpr (EPI == EPI_RES) {
-                    float* rdst = epi.res + (mrow * (int64_t)N + n0 + wn * 128 + lg * 16) + ((int64_t)i * 16 * N + jg * 64);
-                    *reinterpret_cast<f32x4*>(rdst) = t0;       *reinterpret_cast<f32x4*>(rdst + 4) = t1;
-                    *reinterpret_cast<f32x4*>(rdst + 8) = t2;   *reinterpret_cast<f32x4*>(rdst + 12) = t3;
+                    float* rdst = res_tb + (i * 2 + jg) * 1024 + lane * 4;
+                    *reinterpret_cast<f32x4*>(rdst) = t0;       *reinterpret_cast<f32x4*>(rdst + 256) = t1;
+                    *reinterpret_cast<f32x4*>(rdst + 512) = t2; *reinterpret_cast<f32x4*>(rdst + 768) = t3;
 #pragma unroll
                     for (int rr = 0; rr < 4; ++rr)
                         ss[i] = __builtin_fmaf(t0[rr], t0[rr], __builtin_fmaf(t1[rr], t1[rr], __builtin_fmaf(t2[rr], t2[rr], __builtin_fmaf(t3[rr], t3[rr], ss[i]))));
                     asm volatile("" : "+v"(ss[i]));             // computed HERE (otherwise the chain is sunk to the end of the epilogue and every group's values stay live: spills)
-                    if constexpr (sizeof(OutT) == 4) {          // fp32 model: the next in_proj reads the residual stream itself
-                        __builtin_amdgcn_sched_barrier(0);
-                        continue;
-                    }
                 }
                 if constexpr (EPI == EPI_SCALE) { t0 *= rs[i]; t1 *= rs[i]; t2 *= rs[i]; t3 *= rs[i]; }
                 float lo[8], hi[8];
@@ -1068,7 +1083,7 @@ static bool quad_ok(int64_t lda, int64_t ldw, int64_t M, int N, bool two, int ns
 template <typename T>
 static hipError_t launch_gemm256_t(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc, int64_t M,
                                    int N, int K, hipStream_t s, bool a_blocked, void* C2 = nullptr, int nsplit = 0,
-                                   bool out_blocked = false, int epi_kind = EPI_NONE, GemmEpi epi = GemmEpi{nullptr, nullptr, nullptr}) {
+                                   bool out_blocked = false, int epi_kind = EPI_NONE, GemmEpi epi = GemmEpi{nullptr, nullptr, nullptr, 0}) {
     const int tiles_m = (int)((M + BM2 - 1) / BM2), tiles_n = (N + BN2 - 1) / BN2;
     dim3 grid((unsigned)persistent_grid(tiles_m * tiles_n)), block(GEMM_THREADS);
     static const bool quad = dev_env("PCAD_GEMM_NOQUAD") == nullptr;   // PCAD_DEV=1 only: the 8-wave kernel for A/B runs
@@ -1106,7 +1121,7 @@ hipError_t launch_gemm_nt_two(const void* A, int64_t lda, const void* W, int64_t
     if (((uintptr_t)C1) % 16 || ((uintptr_t)C2) % 16) return hipErrorInvalidValue;
     if (out_blocked && ((nsplit * esz) % 128 || ((N - nsplit) * esz) % 128)) return hipErrorInvalidValue;
     const int ek = rscale ? EPI_SCALE : EPI_NONE;
-    const GemmEpi epi{rscale, nullptr, nullptr};
+    const GemmEpi epi{rscale, nullptr, nullptr, 0};
     if (dt == BF16) return launch_gemm256_t<bf16_t>(A, lda, W, ldw, C1, nsplit, M, N, K, s, false, C2, nsplit, out_blocked, ek, epi);
     return launch_gemm256_t<float>(A, lda, W, ldw, C1, nsplit, M, N, K, s, false, C2, nsplit, out_blocked, ek, epi);
 }
@@ -1124,10 +1139,19 @@ hipError_t launch_gemm_nt_res(const void* A, int64_t lda, const void* W, int64_t
                               int N, int K, int dt, hipStream_t s, bool a_blocked) {
     if (M <= 0 || N <= 0) return hipSuccess;
     const int esz = dt == BF16 ? 2 : 4;
-    if (K <= 0 || (K * esz) % ROWB || !res || !ssq || (dt == BF16 && !C)) return hipErrorInvalidValue;
+    if (K <= 0 || (K * esz) % ROWB || !res || !ssq || !C) return hipErrorInvalidValue;
     if ((lda * esz) % 16 || (ldw * esz) % 16 || ((uintptr_t)A) % 16 || ((uintptr_t)W) % 16 || ((uintptr_t)res) % 16) return hipErrorInvalidValue;
     if (a_blocked && (lda * esz) % 128) return hipErrorInvalidValue;
-    const GemmEpi epi{nullptr, res, ssq};
+    // stagger step = an eighth of a tile's duration: a tile is nkt K-tiles of 128 MFMAs x 16 cycles per SIMD at ~0.6 pipe
+    // utilisation ~ 3400 shader cycles per K-tile (out_proj at l32: 32 K-tiles = 50 us at ~2.1 GHz); only when a block has
+    // enough tiles for the 7/8-tile tail to be small.  PCAD_DEV=1 PCAD_GEMM_STAGGER=<cycles per K-tile> overrides (0: off).
+    static const char* sv = dev_env("PCAD_GEMM_STAGGER");
+    const int per_kt = sv ? atoi(sv) : 3400;
+    const int nkt = (K * esz) / ROWB;
+    const int64_t tiles = (M / BM2) * (int64_t)(N / BN2);
+    const int cus = device_cu_count() / 8 * 8;
+    const int stagger = tiles >= (int64_t)8 * cus ? per_kt * nkt / 8 : 0;
+    const GemmEpi epi{nullptr, res, ssq, stagger};
     if (dt == BF16) return launch_gemm256_t<bf16_t>(A, lda, W, ldw, C, N, M, N, K, s, a_blocked, nullptr, 0, false, EPI_RES, epi);
     return launch_gemm256_t<float>(A, lda, W, ldw, C, N, M, N, K, s, a_blocked, nullptr, 0, false, EPI_RES, epi);
 }

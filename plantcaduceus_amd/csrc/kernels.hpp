@@ -31,7 +31,8 @@ struct Positions {            // by-value kernel argument: the positions evaluat
 hipError_t launch_add_rmsnorm(const void* x, const void* res_in, const float* w, void* y, void* res_out,
                               int64_t rows, int D, float eps, int dt, int rdt, hipStream_t s);
 // layer-0 variant: x = Emb[strand token] gathered on the fly (RCPS strands by index arithmetic).
-// rstd_out != nullptr: the norm-folded form - y (may be nullptr) = the un-normalised embedding row, rstd_out[row] = its rstd.
+// rstd_out != nullptr: the norm-folded form - y (may be nullptr) = the un-normalised embedding row, rstd_out[row] = its rstd, and
+// res_out (fp32) is written in the 4-wave GEMM's fragment layout (common.hpp res_frag_off; 2 B L % 256 == 0, D % 256 == 0).
 hipError_t launch_embed_rmsnorm(const int32_t* ids, const void* emb, const int32_t* comp8, const float* w,
                                 void* y, void* res_out, int B, int L, int D, float eps, int dt, int rdt,
                                 hipStream_t s, float* rstd_out = nullptr);
@@ -44,7 +45,8 @@ hipError_t launch_rstd(const float* ssq, float* rstd, int64_t rows, int np, int 
 hipError_t launch_final_head(const void* h, const void* res, const float* w, const void* emb,
                              const float* emb_f32, const int32_t* comp8, void* hidden_out, float* logits_out,
                              int B, int L, int D, float eps, Positions pos, const int32_t* pos_per_seq, int dt, int rdt,
-                             hipStream_t s, bool h_compact = false, const int32_t* ids = nullptr, int32_t* status = nullptr);
+                             hipStream_t s, bool h_compact = false, const int32_t* ids = nullptr, int32_t* status = nullptr,
+                             bool res_frag = false);       // res_frag: fp32 residual in the fragment layout (common.hpp res_frag_off)
 // hidden_states[i] (block input = previous mixer output / embedding) assembled in RCPS layout.
 hipError_t launch_assemble_hidden(const void* h, void* out, int B, int L, int D, int dt, hipStream_t s);
 hipError_t launch_embed_only(const int32_t* ids, const void* emb, const int32_t* comp8, void* h, int B, int L,
@@ -70,7 +72,8 @@ hipError_t launch_gemm_nt_two(const void* A, int64_t lda, const void* W, int64_t
                               bool out_blocked, int64_t M, int N, int K, int dt, hipStream_t s, const float* rscale = nullptr);
 
 // out_proj of the norm-folded layer form, on the 4-wave kernel only (gemm_fold_shapes_ok):
-//   res [M, N] fp32 += A . W^T (in place);  C [M, N] (dtype dt; unused for fp32) = round(res);  ssq [M, N / 128] = per-row partial
+//   res [M, N] fp32 (FRAGMENT layout, common.hpp res_frag_off) += A . W^T (in place);  C [M, N] (plain rows, dtype dt; unused for
+//   fp32: see api.hip) = round(res);  ssq [M, N / 128] = per-row partial
 //   sums of squares of the updated residual, one per 128-column wave tile (deterministic; reduced by launch_rstd).
 hipError_t launch_gemm_nt_res(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, float* res, float* ssq, int64_t M,
                               int N, int K, int dt, hipStream_t s, bool a_blocked);

@@ -52,7 +52,14 @@ __global__ __launch_bounds__(256) void add_rmsnorm_kernel(const T* __restrict__ 
             }
 #pragma unroll
             for (int i = 0; i < 8; ++i) ss += v[j][i] * v[j][i];
-            if (res_out != nullptr) store8<RT>(res_out + row * D + c * 8, v[j]);
+            if constexpr (FOLD) {          // the fp32 residual stream in the 4-wave GEMM's fragment layout: 8 columns = two quads
+                const int64_t o = res_frag_off(row, c * 8, D);
+                float* ro = reinterpret_cast<float*>(res_out);
+                *reinterpret_cast<f32x4*>(ro + o) = f32x4{v[j][0], v[j][1], v[j][2], v[j][3]};
+                *reinterpret_cast<f32x4*>(ro + o + 256) = f32x4{v[j][4], v[j][5], v[j][6], v[j][7]};
+            } else if (res_out != nullptr) {
+                store8<RT>(res_out + row * D + c * 8, v[j]);
+            }
         }
     }
     ss = wave_sum(ss);
@@ -171,7 +178,7 @@ __global__ __launch_bounds__(128) void final_head_kernel(const T* __restrict__ h
                                                          const int32_t* __restrict__ comp8, T* __restrict__ hidden_out,
                                                          float* __restrict__ logits_out, int B, int L, int D, float eps,
                                                          Positions pos, const int32_t* __restrict__ pos_per_seq, int h_compact,
-                                                         const int32_t* __restrict__ ids, int32_t* __restrict__ status) {
+                                                         const int32_t* __restrict__ ids, int32_t* __restrict__ status, int res_frag) {
     __shared__ float part[8];
     const int lane = threadIdx.x & 63;
     const int wv = threadIdx.x >> 6;   // 0: forward strand, 1: rc strand
@@ -209,7 +216,13 @@ __global__ __launch_bounds__(128) void final_head_kernel(const T* __restrict__ h
         if (c < nchunk) {
             float r[8];
             load8<T>(h + hrow * D + c * 8, v[j]);
-            load8<RT>(res + row * D + c * 8, r);
+            if (res_frag) {                  // norm-folded form: fp32 residual in the GEMM's fragment layout (RT == float)
+                const float* rp = reinterpret_cast<const float*>(res) + res_frag_off(row, c * 8, D);
+                const f32x4 a = *reinterpret_cast<const f32x4*>(rp), b = *reinterpret_cast<const f32x4*>(rp + 256);
+                r[0] = a[0]; r[1] = a[1]; r[2] = a[2]; r[3] = a[3]; r[4] = b[0]; r[5] = b[1]; r[6] = b[2]; r[7] = b[3];
+            } else {
+                load8<RT>(res + row * D + c * 8, r);
+            }
 #pragma unroll
             for (int i = 0; i < 8; ++i) { v[j][i] += r[i]; ss += v[j][i] * v[j][i]; }
         }
@@ -273,13 +286,13 @@ template <typename T, typename RT>
 static hipError_t launch_final_t(const void* h, const void* res, const float* w, const float* emb_f32,
                                  const int32_t* comp8, void* hidden_out, float* logits_out, int B, int L, int D,
                                  float eps, Positions pos, const int32_t* pos_per_seq, hipStream_t s, int h_compact,
-                                 const int32_t* ids, int32_t* status) {
+                                 const int32_t* ids, int32_t* status, int res_frag) {
     const int Q = pos_per_seq ? 1 : (pos.n ? pos.n : L);
     dim3 grid((unsigned)(B * Q)), block(128);
     if (B * Q == 0) return hipSuccess;
 #define PCAD_FH(MC)                                                                                          \
     hipLaunchKernelGGL((final_head_kernel<T, RT, MC>), grid, block, 0, s, (const T*)h, (const RT*)res, w, emb_f32, \
-                       comp8, (T*)hidden_out, logits_out, B, L, D, eps, pos, pos_per_seq, h_compact, ids, status)
+                       comp8, (T*)hidden_out, logits_out, B, L, D, eps, pos, pos_per_seq, h_compact, ids, status, res_frag)
     if (D <= 512) PCAD_FH(1);
     else if (D <= 1024) PCAD_FH(2);
     else PCAD_FH(4);
@@ -290,16 +303,18 @@ static hipError_t launch_final_t(const void* h, const void* res, const float* w,
 hipError_t launch_final_head(const void* h, const void* res, const float* w, const void* /*emb*/,
                              const float* emb_f32, const int32_t* comp8, void* hidden_out, float* logits_out, int B,
                              int L, int D, float eps, Positions pos, const int32_t* pos_per_seq, int dt, int rdt,
-                             hipStream_t s, bool h_compact, const int32_t* ids, int32_t* status) {
+                             hipStream_t s, bool h_compact, const int32_t* ids, int32_t* status, bool res_frag) {
     if (D % 8 || D > 2048) return hipErrorInvalidValue;
     if (h_compact && (pos_per_seq || pos.n == 0)) return hipErrorInvalidValue;
+    if (res_frag && (rdt != F32 || D % 256 || ((int64_t)2 * B * L) % 256)) return hipErrorInvalidValue;
     const int hc = h_compact ? 1 : 0;
+    const int rf = res_frag ? 1 : 0;
     if (dt == BF16 && rdt == F32)
-        return launch_final_t<bf16_t, float>(h, res, w, emb_f32, comp8, hidden_out, logits_out, B, L, D, eps, pos, pos_per_seq, s, hc, ids, status);
+        return launch_final_t<bf16_t, float>(h, res, w, emb_f32, comp8, hidden_out, logits_out, B, L, D, eps, pos, pos_per_seq, s, hc, ids, status, rf);
     if (dt == BF16 && rdt == BF16)
-        return launch_final_t<bf16_t, bf16_t>(h, res, w, emb_f32, comp8, hidden_out, logits_out, B, L, D, eps, pos, pos_per_seq, s, hc, ids, status);
+        return launch_final_t<bf16_t, bf16_t>(h, res, w, emb_f32, comp8, hidden_out, logits_out, B, L, D, eps, pos, pos_per_seq, s, hc, ids, status, rf);
     if (dt == F32 && rdt == F32)
-        return launch_final_t<float, float>(h, res, w, emb_f32, comp8, hidden_out, logits_out, B, L, D, eps, pos, pos_per_seq, s, hc, ids, status);
+        return launch_final_t<float, float>(h, res, w, emb_f32, comp8, hidden_out, logits_out, B, L, D, eps, pos, pos_per_seq, s, hc, ids, status, rf);
     return hipErrorInvalidValue;
 }
 

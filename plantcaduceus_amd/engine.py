@@ -77,7 +77,7 @@ SIGNATURES = {
                                    C.c_void_p]),
     "pcad_final_head": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                   C.c_int, C.c_int, C.c_int, C.c_float, C.POINTER(C.c_int32), C.c_int, C.c_void_p, C.c_int,
-                                  C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+                                  C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
 }
 
 _lib = None

@@ -217,25 +217,45 @@ def linear(x, weight, out_dtype: Optional[torch.dtype] = None):
     return out.view(*x.shape[:-1], N)
 
 
+def to_res_fragment(res: torch.Tensor) -> torch.Tensor:
+    """[M, N] (M, N multiples of 256) -> the same values in the 4-wave GEMM's fragment layout (include/pcad.h
+    pcad_gemm_nt_residual), as a flat [M * N] tensor."""
+    M, N = res.shape
+    if M % 256 or N % 256:
+        raise ValueError("the fragment layout needs M % 256 == 0 and N % 256 == 0")
+    #          tm        wm i  li   tn        wn jg lg k  r
+    v = res.reshape(M // 256, 2, 8, 16, N // 256, 2, 2, 4, 4, 4)
+    #  -> [tm, tn, wm, wn, i, jg, k, lg, li, r]
+    return v.permute(0, 4, 1, 5, 2, 6, 8, 7, 3, 9).contiguous().view(-1)
+
+
+def from_res_fragment(frag: torch.Tensor, M: int, N: int) -> torch.Tensor:
+    v = frag.view(M // 256, N // 256, 2, 2, 8, 2, 4, 4, 16, 4)
+    #  [tm, tn, wm, wn, i, jg, k, lg, li, r] -> [tm, wm, i, li, tn, wn, jg, lg, k, r]
+    return v.permute(0, 2, 4, 8, 1, 3, 5, 7, 6, 9).contiguous().view(M, N)
+
+
 def linear_residual(x, weight, residual):
-    """The "norm_fold" out_proj as an operator (include/pcad.h pcad_gemm_nt_residual): residual (fp32 [M, N], updated IN PLACE)
-    += x [M, K] @ weight [N, K]^T; returns (round(residual) in x.dtype [M, N] (None for fp32), ssq [M, N/128] per-row partial
-    sums of squares of the updated residual)."""
+    """The "norm_fold" out_proj as an operator (include/pcad.h pcad_gemm_nt_residual): residual fp32 [M, N] + x [M, K] @ weight
+    [N, K]^T.  Returns (new residual fp32 [M, N], round(new residual) in x.dtype [M, N], ssq [M, N/128] per-row partial sums of
+    squares).  The kernel updates the residual in place in its fragment layout; the conversions are done here (test plumbing)."""
     _require_gpu(x, "x")
     lib = load_library()
     M, K = x.shape
     N = weight.shape[0]
-    if residual.dtype != torch.float32 or not residual.is_contiguous() or tuple(residual.shape) != (M, N):
-        raise ValueError("residual must be a contiguous fp32 [M, N] tensor")
+    if M % 256 or N % 256:
+        raise RuntimeError("pcad_gemm_nt_residual: M and N must be multiples of 256")
+    if residual.dtype != torch.float32 or tuple(residual.shape) != (M, N):
+        raise ValueError("residual must be an fp32 [M, N] tensor")
     xf = x.contiguous()
     wf = weight.to(x.dtype).contiguous()
-    out = torch.empty((M, N), dtype=x.dtype, device=x.device) if x.dtype != torch.float32 else None
+    frag = to_res_fragment(residual)
+    out = torch.empty((M, N), dtype=x.dtype, device=x.device)
     ssq = torch.empty((M, N // 128), dtype=torch.float32, device=x.device)
     with torch.cuda.device(x.device):
-        _check(lib.pcad_gemm_nt_residual(xf.data_ptr(), K, wf.data_ptr(), K, out.data_ptr() if out is not None else None,
-                                         residual.data_ptr(), ssq.data_ptr(), M, N, K, _dt(xf), _stream_ptr()),
-               "pcad_gemm_nt_residual")
-    return out, ssq
+        _check(lib.pcad_gemm_nt_residual(xf.data_ptr(), K, wf.data_ptr(), K, out.data_ptr(), frag.data_ptr(), ssq.data_ptr(),
+                                         M, N, K, _dt(xf), _stream_ptr()), "pcad_gemm_nt_residual")
+    return from_res_fragment(frag, M, N), out, ssq
 
 
 def gather_rows(src, B: int, L: int, positions):
@@ -254,7 +274,8 @@ def gather_rows(src, B: int, L: int, positions):
 
 
 def final_head(h, res, norm_weight, emb, complement, B: int, L: int, eps: float, positions=None, pos_per_seq=None,
-               h_compact: bool = False, want_hidden: bool = True, want_logits: bool = True, ids=None, status=None):
+               h_compact: bool = False, want_hidden: bool = True, want_logits: bool = True, ids=None, status=None,
+               res_fragment: bool = False):
     """norm_f + RC re-assembly + tied RCPS LM head at the requested positions (include/pcad.h pcad_final_head).
     h [2B*L, D] (or the gathered rows when h_compact), res [2B*L, D] (fp32 or h.dtype), emb [V, D] (rounded to h.dtype here, as the
     tied lm_head weight is).  -> (hidden [B, Q, 2D] | None, logits fp32 [B, Q, V] | None)."""
@@ -278,5 +299,5 @@ def final_head(h, res, norm_weight, emb, complement, B: int, L: int, eps: float,
                                    hid.data_ptr() if hid is not None else None, lg.data_ptr() if lg is not None else None,
                                    B, L, D, float(eps), arr, P, pps.data_ptr() if pps is not None else None, int(bool(h_compact)),
                                    ids.data_ptr() if ids is not None else None, status.data_ptr() if status is not None else None,
-                                   _dt(hf), _DT[rf.dtype], _stream_ptr()), "pcad_final_head")
+                                   _dt(hf), _DT[rf.dtype], int(bool(res_fragment)), _stream_ptr()), "pcad_final_head")
     return hid, lg

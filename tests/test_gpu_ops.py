@@ -237,20 +237,15 @@ def test_linear_residual(ops, M, N, K, dtype):
     w = (torch.randn(N, K, generator=g) / K ** 0.5).to(dtype)
     res = torch.randn(M, N, generator=g) * 3
     ref = res.double() + x.double() @ w.double().t()
-    r_dev = res.to(DEV).clone()
-    out, ssq = ops.linear_residual(x.to(DEV), w.to(DEV), r_dev)
+    r_dev, out, ssq = ops.linear_residual(x.to(DEV), w.to(DEV), res.to(DEV))
     tol = 5e-6 if dtype == torch.float32 else 1e-5          # fp32: exact products, only the accumulation order differs (K up to 2048, |res| ~ 3 sigma 9); bf16 products are exact in fp32
     assert relerr(r_dev, ref) < tol
-    if dtype == torch.bfloat16:
-        assert torch.equal(out.cpu(), r_dev.cpu().bfloat16())            # C is the updated residual rounded once
-    else:
-        assert out is None
+    assert torch.equal(out.cpu(), r_dev.cpu().to(dtype))                 # C is the updated residual rounded once
     want = (r_dev.double().cpu() ** 2).view(M, N // 128, 128).sum(-1)
     assert ssq.shape == (M, N // 128) and relerr(ssq, want) < 1e-5
     # deterministic: a second run on the same inputs gives the same bits
-    r2 = res.to(DEV).clone()
-    out2, ssq2 = ops.linear_residual(x.to(DEV), w.to(DEV), r2)
-    assert torch.equal(r2, r_dev) and torch.equal(ssq2, ssq)
+    r2, out2, ssq2 = ops.linear_residual(x.to(DEV), w.to(DEV), res.to(DEV))
+    assert torch.equal(r2, r_dev) and torch.equal(ssq2, ssq) and torch.equal(out2, out)
 
 
 def test_linear_residual_rejects_partial_tiles(ops):
@@ -290,7 +285,7 @@ def _final_head_ref(h, res, w, emb, comp, B, L, eps, rows_p, dtype):
 
 
 @pytest.mark.parametrize("dtype,rdtype", [(torch.float32, torch.float32), (torch.bfloat16, torch.float32), (torch.bfloat16, torch.bfloat16)])
-@pytest.mark.parametrize("B,L,D", [(3, 24, 64), (2, 50, 384), (2, 16, 1024), (1, 9, 2048)])
+@pytest.mark.parametrize("B,L,D", [(3, 24, 64), (2, 50, 384), (2, 16, 1024), (1, 9, 2048), (2, 64, 512)])
 def test_final_head(ops, dtype, rdtype, B, L, D):
     g = torch.Generator().manual_seed(B + L + D)
     h = torch.randn(2 * B * L, D, generator=g).to(dtype)
@@ -313,6 +308,12 @@ def test_final_head(ops, dtype, rdtype, B, L, D):
     hid_c, lg_c = ops.final_head(hc, res.to(DEV), w.to(DEV), emb.to(DEV), comp, B, L, 1e-5, positions=pos, h_compact=True)
     hid_f, lg_f = ops.final_head(h.to(DEV), res.to(DEV), w.to(DEV), emb.to(DEV), comp, B, L, 1e-5, positions=pos)
     assert torch.equal(hid_c, hid_f) and torch.equal(lg_c, lg_f)
+    # the fp32 residual in the folded GEMM's fragment layout (norm_fold): same bits as from plain rows
+    if rdtype == torch.float32 and D % 256 == 0 and (2 * B * L) % 256 == 0:
+        frag = ops.to_res_fragment(res.to(DEV))
+        assert torch.equal(ops.from_res_fragment(frag, 2 * B * L, D), res.to(DEV))
+        hid_g, lg_g = ops.final_head(h.to(DEV), frag, w.to(DEV), emb.to(DEV), comp, B, L, 1e-5, positions=pos, res_fragment=True)
+        assert torch.equal(hid_g, hid_f) and torch.equal(lg_g, lg_f)
 
 
 def test_final_head_clamps_and_flags_bad_positions(ops):

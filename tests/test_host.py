@@ -224,3 +224,23 @@ def test_effective_batch_keeps_an_explicit_batch_size():
     assert a.batchSize == 128 and a.batchExplicit is False
     b = zero_shot.parse_args(["-input-table", "x.tsv", "-batchSize", "7"])
     assert b.batchSize == 7 and b.batchExplicit is True
+
+
+def test_residual_fragment_layout_formula():
+    """include/pcad.h documents the fragment layout of pcad_gemm_nt_residual's residual operand as a closed formula
+    (csrc/common.hpp res_frag_off); ops.to_res_fragment / from_res_fragment (torch permutes) must implement exactly that."""
+    from plantcaduceus_amd import ops
+    M, N = 768, 512
+    res = torch.arange(M * N, dtype=torch.float32).view(M, N)
+    frag = ops.to_res_fragment(res)
+    assert torch.equal(ops.from_res_fragment(frag, M, N), res)
+
+    def off(row, col):
+        tile = (row // 256) * (N // 256) + col // 256
+        wave = 2 * ((row // 128) % 2) + (col // 128) % 2
+        i, li = (row // 16) % 8, row % 16
+        jg, lg, k, r = (col // 64) % 2, (col // 16) % 4, (col // 4) % 4, col % 4
+        return ((((tile * 4 + wave) * 8 + i) * 2 + jg) * 4 + k) * 256 + (16 * lg + li) * 4 + r
+    rng = np.random.default_rng(0)
+    for row, col in zip(rng.integers(0, M, 500), rng.integers(0, N, 500)):
+        assert frag[off(int(row), int(col))] == res[row, col]
