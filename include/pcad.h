@@ -94,14 +94,15 @@ void   pcad_destroy(pcad_handle h);
  *   "gate_each"   1: SiLU(z) applied to each direction's scan output, each rounded, then summed — the reference's order
  *                 (two selective_scan_fn calls);  0 (default): applied once to the sum of both directions (same value in
  *                 exact arithmetic, one rounding fewer, faster).
- *   "norm_fold"   1: the fused add + RMSNorm launch between two blocks is folded into the GEMMs around it: out_proj's epilogue
+ *   "norm_fold"   1 (default): the fused add + RMSNorm launch between two blocks is folded into the GEMMs around it: out_proj's epilogue
  *                 adds its fp32 result to the fp32 residual stream in place and writes the rounded sum plus per-row partial sums of
  *                 squares (deterministic, no atomics); in_proj runs on that un-normalised operand with W_in . diag(w_norm) (folded
  *                 when the weights are bound) and multiplies by the row's rstd before it rounds.  Same value in exact arithmetic
  *                 as rms_norm_fn(prenorm=True, residual_in_fp32=True); rounding points move (the mixer output is not rounded
  *                 before it is added; in_proj's operand is round(res) instead of round(res * rstd * w)).  Used for chunks whose
  *                 GEMMs are whole 256 x 256 tiles (d_model % 256 == 0, token-rows % 256 == 0) with an fp32 residual stream,
- *                 never by pcad_forward_all_hidden;  0 (default): the reference's operation order.
+ *                 never by pcad_forward_all_hidden (+4.5 % end to end, same-box A/B, profiles/r04_ab_runs.txt);
+ *                 0: the reference's operation order (one add + RMSNorm launch per block).
  *   "scan_segments"  1 (default): for long sequences with few strands (PlantCAD2's 8 192-bp windows in small batches: at most 768 scan waves in a
  *                 launch and L >= 2 048) the scan of every strand is cut into up to 8 segments that run as separate workgroups
  *                 (zero-state pass, carry, real pass: ~1.8x the arithmetic for up to 8x the parallelism; results equal up to fp32

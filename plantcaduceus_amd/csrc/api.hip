@@ -72,7 +72,7 @@ struct pcad_engine {
     bool blocked;   // xc and y in the blocked layout (common.hpp::blocked_off); PCAD_PLAIN_LAYOUT=1 turns it off (A/B knob)
     bool segments = true;  // pcad_set_option("scan_segments", 0): never cut the scan of long strands into segments
     bool shortcut = true;  // pcad_set_option("last_layer_shortcut", 0): run the last layer in full even when only a few positions are evaluated
-    bool norm_fold = false; // pcad_set_option("norm_fold", 1): the add+RMSNorm pass folded into out_proj's epilogue / in_proj (forward_impl)
+    bool norm_fold = true;  // pcad_set_option("norm_fold", 0): the reference's add + RMSNorm launch instead of the fold into out_proj's epilogue / in_proj (forward_impl)
     bool poison = false;   // pcad_set_option("poison_workspace", 1): debug — fill the workspace with 0xFF (NaN patterns) before every forward
     bool bound = false;
     int32_t* status = nullptr;   // caller-owned device word for asynchronous input-validation flags (pcad_set_status_buffer)
@@ -442,7 +442,7 @@ static int forward_impl(pcad_handle h, const int32_t* ids, int B, int L, const i
     // value no kernel of THIS forward produced turns the outputs into NaN instead of silently reusing the previous call's data
     if (e->poison) HIP_TRY(hipMemsetAsync(workspace, 0xFF, need, cs));
 
-    // Norm-folded layer form (pcad_set_option("norm_fold", 1)).  The reference's block is
+    // Norm-folded layer form (default; pcad_set_option("norm_fold", 0) restores the reference's order).  The reference's block is
     //     res = h + res (fp32);  u = round(res * rstd(res) * w_norm);  xz = round(u . W_in^T);  ...;  h = round(y . W_out^T)
     // (rms_norm_fn(..., prenorm=True, residual_in_fp32=True)).  Folded: out_proj's epilogue does
     // res += y . W_out^T in fp32 (the accumulators start as the residual values), writes round(res) and per-row partial sums of

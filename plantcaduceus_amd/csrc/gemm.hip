@@ -657,7 +657,6 @@ struct GemmEpi {
     const float* rscale;    // EPI_SCALE: [M]
     float* res;             // EPI_RES: [M, N] fp32 in the fragment layout (common.hpp res_frag_off)
     float* ssq;             // EPI_RES: [M, N / 128]
-    int stagger;            // EPI_RES: start delay per phase step in shader cycles (0: none), see the kernel
 };
 
 template <typename T, typename OutT, int EPI>
@@ -677,19 +676,6 @@ __global__ __launch_bounds__(GEMMQ_THREADS, 1) void gemm256q_kernel(const T* __r
     if ((int)blockIdx.x >= nblk) return;
     const int my_tiles = (nblk - (int)blockIdx.x + gstride - 1) / gstride;
     const int G = my_tiles * nkt;                                 // K-tiles this block walks
-    if constexpr (EPI == EPI_RES) {
-        // Staggered start.  Every block walks equally long tiles, so left alone all 256 CUs reach their epilogues together and
-        // the residual read-modify-write (512 KiB per tile on top of the 128 KiB result) hits HBM as one synchronised 160 MB
-        // burst per round of tiles while the memory system idles during the mainloops (measured: +23.6 us per 50 us tile, the
-        // time that burst takes at ~5.5 TB/s).  Delaying block b by ((b / 8) % 8) eighths of a tile time keeps an eighth of
-        // every XCD's CUs in their epilogue at any moment instead; the price is the last phase's tail, 7/8 of one tile per launch.
-        const int phase = ((int)blockIdx.x >> 3) & 7;
-        if (epi.stagger > 0 && phase != 0) {
-            const uint64_t t0 = __builtin_amdgcn_s_memtime();
-            const uint64_t want = (uint64_t)phase * (uint64_t)epi.stagger;
-            while (__builtin_amdgcn_s_memtime() - t0 < want) __builtin_amdgcn_s_sleep(32);
-        }
-    }
 
     auto tile_coords = [&](int tile, int64_t& m0, int& n0) {
         const int xcd = tile & 7, idx = tile >> 3;
@@ -1083,7 +1069,7 @@ static bool quad_ok(int64_t lda, int64_t ldw, int64_t M, int N, bool two, int ns
 template <typename T>
 static hipError_t launch_gemm256_t(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc, int64_t M,
                                    int N, int K, hipStream_t s, bool a_blocked, void* C2 = nullptr, int nsplit = 0,
-                                   bool out_blocked = false, int epi_kind = EPI_NONE, GemmEpi epi = GemmEpi{nullptr, nullptr, nullptr, 0}) {
+                                   bool out_blocked = false, int epi_kind = EPI_NONE, GemmEpi epi = GemmEpi{nullptr, nullptr, nullptr}) {
     const int tiles_m = (int)((M + BM2 - 1) / BM2), tiles_n = (N + BN2 - 1) / BN2;
     dim3 grid((unsigned)persistent_grid(tiles_m * tiles_n)), block(GEMM_THREADS);
     static const bool quad = dev_env("PCAD_GEMM_NOQUAD") == nullptr;   // PCAD_DEV=1 only: the 8-wave kernel for A/B runs
@@ -1121,7 +1107,7 @@ hipError_t launch_gemm_nt_two(const void* A, int64_t lda, const void* W, int64_t
     if (((uintptr_t)C1) % 16 || ((uintptr_t)C2) % 16) return hipErrorInvalidValue;
     if (out_blocked && ((nsplit * esz) % 128 || ((N - nsplit) * esz) % 128)) return hipErrorInvalidValue;
     const int ek = rscale ? EPI_SCALE : EPI_NONE;
-    const GemmEpi epi{rscale, nullptr, nullptr, 0};
+    const GemmEpi epi{rscale, nullptr, nullptr};
     if (dt == BF16) return launch_gemm256_t<bf16_t>(A, lda, W, ldw, C1, nsplit, M, N, K, s, false, C2, nsplit, out_blocked, ek, epi);
     return launch_gemm256_t<float>(A, lda, W, ldw, C1, nsplit, M, N, K, s, false, C2, nsplit, out_blocked, ek, epi);
 }
@@ -1142,16 +1128,11 @@ hipError_t launch_gemm_nt_res(const void* A, int64_t lda, const void* W, int64_t
     if (K <= 0 || (K * esz) % ROWB || !res || !ssq || !C) return hipErrorInvalidValue;
     if ((lda * esz) % 16 || (ldw * esz) % 16 || ((uintptr_t)A) % 16 || ((uintptr_t)W) % 16 || ((uintptr_t)res) % 16) return hipErrorInvalidValue;
     if (a_blocked && (lda * esz) % 128) return hipErrorInvalidValue;
-    // stagger step = an eighth of a tile's duration: a tile is nkt K-tiles of 128 MFMAs x 16 cycles per SIMD at ~0.6 pipe
-    // utilisation ~ 3400 shader cycles per K-tile (out_proj at l32: 32 K-tiles = 50 us at ~2.1 GHz); only when a block has
-    // enough tiles for the 7/8-tile tail to be small.  PCAD_DEV=1 PCAD_GEMM_STAGGER=<cycles per K-tile> overrides (0: off).
-    static const char* sv = dev_env("PCAD_GEMM_STAGGER");
-    const int per_kt = sv ? atoi(sv) : 3400;
-    const int nkt = (K * esz) / ROWB;
-    const int64_t tiles = (M / BM2) * (int64_t)(N / BN2);
-    const int cus = device_cu_count() / 8 * 8;
-    const int stagger = tiles >= (int64_t)8 * cus ? per_kt * nkt / 8 : 0;
-    const GemmEpi epi{nullptr, res, ssq, stagger};
+    // (Tried and removed, profiles/r04_ab_runs.txt r04d / r04e / r04g: delaying block b by ((b / 8) % 8) eighths of a tile so that an
+    // eighth of the CUs is in its epilogue at a time - no effect with the fragment layout, 2.096 vs 2.097 ms.  Ablations: residual
+    // loads from cache 1.94 ms, no write-back 1.90, neither 1.71 = the plain out_proj; i.e. the 4.3 GB of extra traffic costs
+    // 0.37 ms, about half of its HBM time, the rest is hidden behind the mainloops.)
+    const GemmEpi epi{nullptr, res, ssq};
     if (dt == BF16) return launch_gemm256_t<bf16_t>(A, lda, W, ldw, C, N, M, N, K, s, a_blocked, nullptr, 0, false, EPI_RES, epi);
     return launch_gemm256_t<float>(A, lda, W, ldw, C, N, M, N, K, s, a_blocked, nullptr, 0, false, EPI_RES, epi);
 }

@@ -1,4 +1,4 @@
-"""-m gpu: the "norm_fold" layer form (include/pcad.h pcad_set_option): the add + RMSNorm launch between two blocks folded into
+"""-m gpu: the "norm_fold" layer form (include/pcad.h pcad_set_option; the engine's default): the add + RMSNorm launch between two blocks folded into
 out_proj's epilogue (fp32 residual read-modify-write + rounded copy + per-row partial sums of squares) and in_proj (norm weight
 folded into W_in at bind time, rstd applied before rounding).  Same value in exact arithmetic as the reference's
 rms_norm_fn(..., prenorm=True, residual_in_fp32=True) between out_proj and in_proj, so: the fp32
@@ -68,7 +68,7 @@ def test_norm_fold_fp32_matches_oracle(D, nl, B, L):
     assert torch.equal(out_p.logits.cpu(), lg[:, [p, 0, L - 1]])
     assert torch.equal(out_p.hidden_states[-1].cpu(), hid[:, [p, 0, L - 1]])
     # and it is as close to the oracle as the reference-order path is (same order of magnitude)
-    m0 = build(cfg, sd, torch.float32)
+    m0 = build(cfg, sd, torch.float32, norm_fold=0)
     lg0 = m0(input_ids=ids.to(DEV)).logits.cpu()
     e0 = ((lg0 - ref["logits"]).abs().max() / scale).item()
     assert e_l < 10 * e0 + 1e-6
@@ -83,13 +83,17 @@ def test_norm_fold_falls_back_on_partial_tiles_and_all_hidden():
         ids = rand_ids(B, L, 1).to(DEV)
         out, n = folded_launches(build(cfg, sd, torch.bfloat16, norm_fold=1), ids)
         assert n["gemm_out_proj_res"] == 0 and n["add_rmsnorm"] == 2
-        assert torch.equal(out.logits, build(cfg, sd, torch.bfloat16)(input_ids=ids).logits)
+        assert torch.equal(out.logits, build(cfg, sd, torch.bfloat16, norm_fold=0)(input_ids=ids).logits)
     cfg = make_config("x", d_model=256, n_layer=3)
     sd = synthetic_state_dict(cfg, seed=4, stress=True)
     ids = rand_ids(2, 64, 2).to(DEV)
+    # the option is the engine's default; norm_fold=0 runs the reference's add + RMSNorm launch per block
+    _, n_def = folded_launches(build(cfg, sd, torch.bfloat16), ids)
+    _, n_off = folded_launches(build(cfg, sd, torch.bfloat16, norm_fold=0), ids)
+    assert n_def["gemm_out_proj_res"] == 2 and n_def["add_rmsnorm"] == 0 and n_off["gemm_out_proj_res"] == 0 and n_off["add_rmsnorm"] == 3
     cfg.materialize_all_hidden_states = True
     a = build(cfg, sd, torch.float32, norm_fold=1)(input_ids=ids, output_hidden_states=True).hidden_states
-    b = build(cfg, sd, torch.float32)(input_ids=ids, output_hidden_states=True).hidden_states
+    b = build(cfg, sd, torch.float32, norm_fold=0)(input_ids=ids, output_hidden_states=True).hidden_states
     assert len(a) == len(b) == 4 and all(torch.equal(x, y) for x, y in zip(a, b))
 
 
@@ -106,7 +110,7 @@ def test_norm_fold_bf16_inside_rounding_noise(L):
     out, n = folded_launches(build(cfg, sd, torch.bfloat16, norm_fold=1), ids.to(DEV), output_hidden_states=True)
     assert n["gemm_out_proj_res"] == 3
     lg = out.logits.cpu()
-    lg0 = build(cfg, sd, torch.bfloat16)(input_ids=ids.to(DEV)).logits.cpu()
+    lg0 = build(cfg, sd, torch.bfloat16, norm_fold=0)(input_ids=ids.to(DEV)).logits.cpu()
     scale = ref["logits"].abs().max()
     e_fold, e_plain = ((lg - ref["logits"]).abs().max() / scale).item(), ((lg0 - ref["logits"]).abs().max() / scale).item()
     e_f32 = ((lg - ref32["logits"]).abs().max() / scale).item()
