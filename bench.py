@@ -54,7 +54,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="zeroshot", choices=["zeroshot", "embed", "ism"])
-    ap.add_argument("--model", default="l32", help="l20|l24|l28|l32 (BASELINE.json metric: l32)")
+    ap.add_argument("--model", default="l32", help="l20|l24|l28|l32 (BASELINE.json metric: l32) | pc2-small|pc2-medium|pc2-large (PlantCAD2 geometries)")
     ap.add_argument("--batch", type=int, default=1024, help="512-bp windows (ism: masked forwards) per GPU per step")
     ap.add_argument("--seqlen", type=int, default=512)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
@@ -88,7 +88,7 @@ def algorithmic_work(cfg, rows, esz):
     bytes     the bytes this build's kernel moves by construction (as executed) — reported as executed_bytes."""
     D, E, N, R = cfg.d_model, cfg.d_inner, cfg.d_state, cfg.dt_rank
     X = R + 2 * N
-    Rp = (R + 63) // 64 * 64
+    Rp = 64 if R <= 64 else (R + 31) // 32 * 32      # kernels.hpp padded_dt_rank
     w = {}
     w["gemm_in_proj"] = dict(flops=2.0 * rows * D * 2 * E, bytes=esz * (rows * D + rows * 2 * E + 2 * E * D),
                              bytes_8d=esz * rows * (D + 2 * E))

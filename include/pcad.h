@@ -94,7 +94,8 @@ void   pcad_destroy(pcad_handle h);
  *   "gate_each"   1: SiLU(z) applied to each direction's scan output, each rounded, then summed — the reference's order
  *                 (two selective_scan_fn calls);  0 (default): applied once to the sum of both directions (same value in
  *                 exact arithmetic, one rounding fewer, faster).
- *   "norm_fold"   1 (default): the fused add + RMSNorm launch between two blocks is folded into the GEMMs around it: out_proj's epilogue
+ *   "norm_fold"   1 (default for the bf16 model; -1 restores "default"): the fused add + RMSNorm launch between two blocks is folded
+ *                 into the GEMMs around it: out_proj's epilogue
  *                 adds its fp32 result to the fp32 residual stream in place and writes the rounded sum plus per-row partial sums of
  *                 squares (deterministic, no atomics); in_proj runs on that un-normalised operand with W_in . diag(w_norm) (folded
  *                 when the weights are bound) and multiplies by the row's rstd before it rounds.  Same value in exact arithmetic
@@ -102,11 +103,17 @@ void   pcad_destroy(pcad_handle h);
  *                 before it is added; in_proj's operand is round(res) instead of round(res * rstd * w)).  Used for chunks whose
  *                 GEMMs are whole 256 x 256 tiles (d_model % 256 == 0, token-rows % 256 == 0) with an fp32 residual stream,
  *                 never by pcad_forward_all_hidden (+4.5 % end to end, same-box A/B, profiles/r04_ab_runs.txt);
- *                 0: the reference's operation order (one add + RMSNorm launch per block).
- *   "scan_segments"  1 (default): for long sequences with few strands (PlantCAD2's 8 192-bp windows in small batches: at most 768 scan waves in a
- *                 launch and L >= 2 048) the scan of every strand is cut into up to 8 segments that run as separate workgroups
- *                 (zero-state pass, carry, real pass: ~1.8x the arithmetic for up to 8x the parallelism; results equal up to fp32
- *                 rounding of the carried decay product);  0: one workgroup walks the whole strand.  Never used at 512 bp.
+ *                 0 (default for the fp32 model, whose 1e-4 parity budget would pay for accumulating onto the residual: 2.2e-5 of
+ *                 max after 32 layers instead of 1.3e-6): the reference's operation order (one add + RMSNorm launch per block).
+ *   "scan_segments"  1 (default): when a launch has at most 768 scan waves (PlantCAD2's 8 192-bp windows in small batches, or
+ *                 fewer than ~12 windows of 512 bp at l32) the scan of every strand is cut into up to 8 segments that run as
+ *                 separate workgroups (zero-state pass, carry, real pass: ~1.8x the arithmetic for up to 8x the parallelism;
+ *                 results equal up to fp32 rounding of the carried decay product);  0: one workgroup walks the whole strand.
+ *                 Never used by the benchmark batch (1 024 windows: 65 536 waves).
+ *   "debug_repeat_class" / "debug_repeat"  measurement aid (tools/power_probe.py): every idempotent launch of ONE pcad_kernel_class
+ *                 (in_proj, conv + x_proj, the forward-direction scan, the reference-order out_proj) is issued `debug_repeat` times
+ *                 back to back, so that a forward is seconds of that kernel at the engine's own launch sizes while board power is
+ *                 sampled; outputs are unchanged.  Default: class -1 (none), repeat 1.
  *   "poison_workspace"  1: debug aid — the workspace is filled with 0xFF bytes (NaN in every dtype) before each forward, so a
  *                 read of anything this forward did not write shows up as NaN outputs (tests/test_gpu_model.py).
  * The library reads NO environment variables unless PCAD_DEV=1 is set (developer A/B switches, see csrc/kernels.hpp). */
@@ -204,16 +211,18 @@ int pcad_causal_conv1d_silu(const void* x, int64_t ldx, const float* w_fwd, cons
  *            (((r >> 3) * (E*esz/128) + (cb >> 7)) << 10) + ((r & 7) << 7) + (cb & 127); rows8 = S*L rounded up to 8;
  *            E*esz a multiple of 128 bytes; (S*L + 16) * E * esz < 2^32
  *   w_*, b_* fp32 [E, 4] / [E] conv taps and bias per direction (fwd: causal, rev: anti-causal on the same rows)
- *   Wx_*     [96, E] dtype: x_proj.weight packed as rows [0, R) = dt rows, zero rows [R, 64), rows [64, 80) = B, [80, 96) = C
- *            (dt_rank R <= 64)
+ *   Rp       dt_rank padded: 64 (dt_rank R <= 64: every PlantCaduceus size, PlantCAD2 Small / Medium) or 96 (R in 65..96:
+ *            PlantCAD2 Large)
+ *   Wx_*     [Rp + 32, E] dtype: x_proj.weight packed as rows [0, R) = dt rows, zero rows [R, Rp), rows [Rp, Rp + 16) = B,
+ *            [Rp + 16, Rp + 32) = C
  *   scratch  device buffer of pcad_conv_xproj_scratch_bytes(E, dtype) bytes (packed taps; written by this call)
  *   xc_*     [rows8, E] dtype, blocked: silu(conv) per direction
- *   dtl_*    [S*L, 64] dtype: x_dbl[:, :R] zero-padded to 64;   bc_* fp32 [S*L, 32] = B_t | C_t rounded to dtype */
+ *   dtl_*    [S*L, Rp] dtype: x_dbl[:, :R] zero-padded to Rp;   bc_* fp32 [S*L, 32] = B_t | C_t rounded to dtype */
 size_t pcad_conv_xproj_scratch_bytes(int E, int dtype);
 int pcad_conv_xproj_bidir(const void* x, const float* w_fwd, const float* b_fwd, const float* w_rev, const float* b_rev,
                           const void* Wx_fwd, const void* Wx_rev, void* scratch,
                           void* xc_fwd, void* dtl_fwd, float* bc_fwd, void* xc_rev, void* dtl_rev, float* bc_rev,
-                          int S, int L, int E, int dtype, pcad_stream stream);
+                          int S, int L, int E, int Rp, int dtype, pcad_stream stream);
 
 /* selective_scan_fn(u, delta, A, B, C, D, z, delta_bias, delta_softplus=True), token-major:
  *   u, delta [S, L, E] dtype; z [S, L, ldz>=E] dtype or NULL; bc fp32 [S*L, 32] = B_t (16) | C_t (16) per token;

@@ -130,4 +130,8 @@ PLANTCADUCEUS_SIZES = {
     "l24": dict(d_model=512, n_layer=24),
     "l28": dict(d_model=768, n_layer=28),
     "l32": dict(d_model=1024, n_layer=32),
+    # PlantCAD2 (reference docs/PlantCAD2-overview.md:19-21; 8 192-bp context, same block): dt_rank = ceil(d_model / 16) = 48 / 64 / 96
+    "pc2-small": dict(d_model=768, n_layer=24),
+    "pc2-medium": dict(d_model=1024, n_layer=48),
+    "pc2-large": dict(d_model=1536, n_layer=48),
 }

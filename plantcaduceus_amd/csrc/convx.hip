@@ -35,14 +35,25 @@ constexpr int CX_ROWB = 128;                 // bytes of K per K-tile row
 constexpr int CX_RAW_BYTES = CX_RAW * CX_ROWB;           // 17408
 constexpr int CX_NRAW = 2;                   // raw ring depth
 constexpr int CX_TILE_BYTES = CX_ROWS * CX_ROWB;         // 16384: cf, cr
-constexpr int CX_WROWS = 96;
-constexpr int CX_W_BYTES = CX_WROWS * CX_ROWB;           // 12288 per direction
 constexpr int CX_CW_BYTES = 3072;            // conv taps of one K-tile: [dir][5][KC] fp32, padded
 constexpr int CX_OFF_C = CX_NRAW * CX_RAW_BYTES;         // conv outputs: [2 stages][cf, cr]
-constexpr int CX_OFF_W = CX_OFF_C + 2 * 2 * CX_TILE_BYTES;   // [2 stages][2 dirs]
-constexpr int CX_OFF_CW = CX_OFF_W + 2 * 2 * CX_W_BYTES; // [2 stages]
-constexpr int CX_LDS = CX_OFF_CW + 2 * CX_CW_BYTES;      // 155648
+constexpr int CX_OFF_W = CX_OFF_C + 2 * 2 * CX_TILE_BYTES;   // Wx slabs: [W stages][2 dirs]
 constexpr int CX_THREADS = 512;
+// NJ = x_proj output columns / 16 = (Rp + 32) / 16: 6 (dt_rank <= 64, every PlantCaduceus size and PlantCAD2 Small / Medium) or
+// 8 (dt_rank 65..96: PlantCAD2 Large, d_model 1536).  The Wx slab of one direction and K-tile is 16 NJ rows of 128 bytes.
+// NJ == 6: two W stages (Wx(it) lands while the MFMAs of K-tile it-1 read the other stage), 152 KiB of LDS.
+// NJ == 8: two such stages would need 168 KiB, so there is ONE: the MFMAs of K-tile it-1 run first in iteration it, a second
+//          barrier marks the end of every wave's fragment reads, and only then is Wx(it) fetched into the same slab (it has the
+//          conv pass of the iteration to land).  136 KiB.
+template <int NJ> struct CxGeom {
+    static constexpr int WROWS = 16 * NJ;
+    static constexpr int W_BYTES = WROWS * CX_ROWB;                       // per direction
+    static constexpr int WSTAGES = NJ <= 6 ? 2 : 1;
+    static constexpr int OFF_CW = CX_OFF_W + WSTAGES * 2 * W_BYTES;       // taps: [2 stages]
+    static constexpr int LDS = OFF_CW + 2 * CX_CW_BYTES;                  // NJ 6: 155648, NJ 8: 139264
+    static constexpr int WPW = (2 * WROWS / 8) / 8;                       // Wx row groups (of 8 rows) staged per wave: 3 / 4
+};
+static_assert(CxGeom<6>::LDS <= 160 * 1024 && CxGeom<8>::LDS <= 160 * 1024, "LDS budget");
 
 __device__ __forceinline__ int cx_key(int r) { return (r >> 1) & 7; }
 
@@ -108,9 +119,9 @@ template <> struct Chunk<float> {
 };
 
 struct ConvxDir {
-    const void* Wx;      // [96, E] model dtype (rows [R, 64) zero)
+    const void* Wx;      // [Rp + 32, E] model dtype (rows [R, Rp) zero)
     void* xc;            // [rows8, E] blocked
-    void* dtl;           // [rows, 64]
+    void* dtl;           // [rows, Rp]
     float* bc;           // [rows, 32]
 };
 
@@ -118,10 +129,13 @@ struct ConvxDir {
 // ZFILL (L % 8 == 0: a strand is a contiguous byte range of the blocked tensor): the raw tile is fetched through a
 // descriptor that covers exactly the strand, so the halo rows outside [0, L) are out of range and arrive as zeros (a
 // negative strand-relative offset wraps to a huge unsigned one) - the conv pass then needs no per-element masking.
-template <typename T, bool ZFILL>
+template <typename T, bool ZFILL, int NJ = 6>
 __global__ __launch_bounds__(CX_THREADS, 2) void convx_kernel(const T* __restrict__ x, const float* __restrict__ convw,
                                                               ConvxDir d0, ConvxDir d1, int S, int L, int E) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    using G = CxGeom<NJ>;
+    constexpr int CX_W_BYTES = G::W_BYTES, CX_OFF_CW = G::OFF_CW;
+    constexpr bool W1 = G::WSTAGES == 1;                    // single Wx slab, second barrier per K-tile (see CxGeom)
     constexpr int CPC = Chunk<T>::CPC;
     constexpr int KC = CX_ROWB / (int)sizeof(T);            // channels per K-tile: 64 (bf16) / 32 (fp32)
     constexpr int CW_PIECES = (2 * 5 * KC * 4 + 1023) / 1024;
@@ -158,13 +172,14 @@ __global__ __launch_bounds__(CX_THREADS, 2) void convx_kernel(const T* __restric
         }
         raw_dst[i] = grp * 8 * CX_ROWB;
     }
-    // Wx slabs: per direction 96 rows = 12 groups of 8; 24 groups over 8 waves = 3 each
-    uint32_t w_src[3];
-    int w_dst[3], w_dir[3];
+    // Wx slabs: per direction 16 NJ rows = 2 NJ groups of 8; 4 NJ groups over 8 waves = NJ / 2 each (3 or 4)
+    constexpr int WPW = G::WPW;
+    uint32_t w_src[WPW];
+    int w_dst[WPW], w_dir[WPW];
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        const int grp = wave * 3 + i;                              // 0..23
-        const int dir = grp / 12, g = grp - dir * 12;
+    for (int i = 0; i < WPW; ++i) {
+        const int grp = wave * WPW + i;                            // 0 .. 4 NJ - 1
+        const int dir = grp / (2 * NJ), g = grp - dir * (2 * NJ);
         const int r = g * 8 + (lane >> 3);
         w_dir[i] = dir;
         w_src[i] = (uint32_t)((int64_t)r * E * (int64_t)sizeof(T) + (((lane & 7) ^ cx_key(r)) << 4));
@@ -179,9 +194,9 @@ __global__ __launch_bounds__(CX_THREADS, 2) void convx_kernel(const T* __restric
         for (int i = 0; i < 3; ++i) cx_blds16(raw_base, raw_src[i], (uint32_t)kt * 1024u, base + raw_dst[i], raw_records);
     };
     auto stage_w = [&](int kt, int par) __attribute__((always_inline)) {
-        char* wb = smem + CX_OFF_W + par * 2 * CX_W_BYTES;
+        char* wb = smem + CX_OFF_W + (W1 ? 0 : par) * 2 * CX_W_BYTES;
 #pragma unroll
-        for (int i = 0; i < 3; ++i) cx_blds16(w_dir[i] ? d1.Wx : d0.Wx, w_src[i], (uint32_t)kt * (uint32_t)CX_ROWB, wb + w_dst[i]);
+        for (int i = 0; i < WPW; ++i) cx_blds16(w_dir[i] ? d1.Wx : d0.Wx, w_src[i], (uint32_t)kt * (uint32_t)CX_ROWB, wb + w_dst[i]);
     };
     auto stage_taps = [&](int kt, int par) __attribute__((always_inline)) {
         cx_blds16(convw, cw_src, (uint32_t)kt * (uint32_t)CX_CW_BYTES, smem + CX_OFF_CW + par * CX_CW_BYTES + cw_dst);
@@ -201,11 +216,11 @@ __global__ __launch_bounds__(CX_THREADS, 2) void convx_kernel(const T* __restric
     int frag_lo[2];
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) frag_lo[kk] = li * CX_ROWB + (((kk * 4 + lg) ^ cx_key(li)) << 4);
-    f32x4 acc[2][6];
+    f32x4 acc[2][NJ];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 6; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     // xc store mapping: wave w copies rows 16w .. 16w+15 of cf and of cr (8 rows x 128 B per instruction)
     T* xcf = (T*)d0.xc;
     T* xcr = (T*)d1.xc;
@@ -217,16 +232,16 @@ __global__ __launch_bounds__(CX_THREADS, 2) void convx_kernel(const T* __restric
     // taps(it+1), raw(it+1), each into the slot whose last reader finished in iteration it-1.
     auto mfma_half = [&](int mpar, int kk) __attribute__((always_inline)) {          // mpar: parity of the K-tile being multiplied
         const char* at = smem + CX_OFF_C + mpar * 2 * CX_TILE_BYTES + cdir * CX_TILE_BYTES;
-        const char* wb = smem + CX_OFF_W + mpar * 2 * CX_W_BYTES + cdir * CX_W_BYTES;
-        u32x4 af[2], wfr[6];
+        const char* wb = smem + CX_OFF_W + (W1 ? 0 : mpar) * 2 * CX_W_BYTES + cdir * CX_W_BYTES;
+        u32x4 af[2], wfr[NJ];
 #pragma unroll
         for (int i = 0; i < 2; ++i) af[i] = *reinterpret_cast<const u32x4*>(at + (mq * 32 + i * 16) * CX_ROWB + frag_lo[kk]);
 #pragma unroll
-        for (int j = 0; j < 6; ++j) wfr[j] = *reinterpret_cast<const u32x4*>(wb + j * 16 * CX_ROWB + frag_lo[kk]);
+        for (int j = 0; j < NJ; ++j) wfr[j] = *reinterpret_cast<const u32x4*>(wb + j * 16 * CX_ROWB + frag_lo[kk]);
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int j = 0; j < 6; ++j) acc[i][j] = CxMma<T>::run(wfr[j], af[i], acc[i][j]);
+            for (int j = 0; j < NJ; ++j) acc[i][j] = CxMma<T>::run(wfr[j], af[i], acc[i][j]);
     };
     // xc copy-out: lane offset of row r0 = 16 * wave + lane / 8 (the i = 1 row is 8 rows = one 1 KiB row-block further)
     const int cr0 = wave * 16 + (lane >> 3);
@@ -267,7 +282,7 @@ __global__ __launch_bounds__(CX_THREADS, 2) void convx_kernel(const T* __restric
 #ifdef PCAD_CX_B64
         constexpr bool B128 = false;
 #else
-        constexpr bool B128 = ZFILL;
+        constexpr bool B128 = ZFILL && NJ <= 6;           // NJ 8: 16 more accumulator registers - the packed window no longer fits
 #endif
         u32x4 rwin[7];
         if constexpr (B128) {
@@ -340,6 +355,22 @@ __global__ __launch_bounds__(CX_THREADS, 2) void convx_kernel(const T* __restric
         else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+        if constexpr (W1) {
+            // single Wx slab: taps / raw tile of K-tile it+1 first, then ALL MFMAs of K-tile it-1 (they read Wx(it-1)), a second
+            // barrier (every wave's fragment reads are complete), and only then the fetch of Wx(it) into the same slab
+            if (it + 1 < nkt) { stage_taps(it + 1, 1 - P); stage_raw(it + 1, 1 - P); }
+            if (it > 0) { mfma_half(1 - P, 0); mfma_half(1 - P, 1); }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (it < nkt) {
+                stage_w(it, P);
+                if (cdir) conv_pass(it, P, std::true_type{}, false);
+                else conv_pass(it, P, std::false_type{}, false);
+            }
+            if (it > 0) copy_out(it - 1, 1 - P);
+            return;
+        }
         if (it < nkt) stage_w(it, P);
         if (it + 1 < nkt) { stage_taps(it + 1, 1 - P); stage_raw(it + 1, 1 - P); }
         if (it < nkt) {
@@ -363,10 +394,10 @@ __global__ __launch_bounds__(CX_THREADS, 2) void convx_kernel(const T* __restric
         const int t = t0 + mq * 32 + i * 16 + li;
         if (t >= L) continue;
         const int64_t row = row0 + t;
-        T* dl = (T*)dd.dtl + row * 64;
+        T* dl = (T*)dd.dtl + row * (16 * (NJ - 2));
         float* bcr = dd.bc + row * 32;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < NJ - 2; ++j) {
             if constexpr (sizeof(T) == 2) {
                 u32x2 v = {pack_bf16x2(acc[i][j][0], acc[i][j][1]), pack_bf16x2(acc[i][j][2], acc[i][j][3])};
                 *reinterpret_cast<u32x2*>(dl + j * 16 + lg * 4) = v;
@@ -375,10 +406,10 @@ __global__ __launch_bounds__(CX_THREADS, 2) void convx_kernel(const T* __restric
             }
         }
 #pragma unroll
-        for (int j = 4; j < 6; ++j) {
+        for (int j = NJ - 2; j < NJ; ++j) {
             f32x4 v = {Elem<T>::round(acc[i][j][0]), Elem<T>::round(acc[i][j][1]), Elem<T>::round(acc[i][j][2]),
                        Elem<T>::round(acc[i][j][3])};
-            *reinterpret_cast<f32x4*>(bcr + (j - 4) * 16 + lg * 4) = v;
+            *reinterpret_cast<f32x4*>(bcr + (j - (NJ - 2)) * 16 + lg * 4) = v;
         }
     }
 }
@@ -416,22 +447,27 @@ hipError_t launch_pack_convw(const float* wf, const float* bf, const float* wr, 
 }
 
 hipError_t launch_convx(const void* x, const float* convw, const void* Wx0, void* xc0, void* dtl0, float* bc0,
-                        const void* Wx1, void* xc1, void* dtl1, float* bc1, int S, int L, int E, int dt, hipStream_t s) {
+                        const void* Wx1, void* xc1, void* dtl1, float* bc1, int S, int L, int E, int dt, hipStream_t s, int Rp) {
     if (S <= 0 || L <= 0) return hipSuccess;
     const int esz = dt == BF16 ? 2 : 4;
-    if ((E * esz) % CX_ROWB) return hipErrorInvalidValue;
+    if ((E * esz) % CX_ROWB || (Rp != 64 && Rp != 96)) return hipErrorInvalidValue;
     if (((int64_t)S * L + 16) * E * esz >= ((int64_t)1 << 32)) return hipErrorInvalidValue;    // unsigned 32-bit in-tensor offsets
     ConvxDir d0{Wx0, xc0, dtl0, bc0}, d1{Wx1, xc1, dtl1, bc1};
     const int tiles = S * ((L + CX_ROWS - 1) / CX_ROWS);
     const bool zfill = L % 8 == 0;
-#define PCAD_CONVX(T, Z)                                                                                              \
+#define PCAD_CONVX(T, Z, NJ_)                                                                                         \
     do {                                                                                                                \
-        auto k = convx_kernel<T, Z>;                                                                                    \
-        if (hipError_t ae = ensure_dynamic_lds((const void*)k, CX_LDS)) return ae;                                      \
-        hipLaunchKernelGGL(k, dim3((unsigned)tiles), dim3(CX_THREADS), CX_LDS, s, (const T*)x, convw, d0, d1, S, L, E);  \
+        auto k = convx_kernel<T, Z, NJ_>;                                                                               \
+        if (hipError_t ae = ensure_dynamic_lds((const void*)k, CxGeom<NJ_>::LDS)) return ae;                            \
+        hipLaunchKernelGGL(k, dim3((unsigned)tiles), dim3(CX_THREADS), CxGeom<NJ_>::LDS, s, (const T*)x, convw, d0, d1, S, L, E); \
     } while (0)
-    if (dt == BF16) { if (zfill) PCAD_CONVX(bf16_t, true); else PCAD_CONVX(bf16_t, false); }
-    else { if (zfill) PCAD_CONVX(float, true); else PCAD_CONVX(float, false); }
+#define PCAD_CONVX_NJ(NJ_)                                                                                            \
+    do {                                                                                                                \
+        if (dt == BF16) { if (zfill) PCAD_CONVX(bf16_t, true, NJ_); else PCAD_CONVX(bf16_t, false, NJ_); }              \
+        else { if (zfill) PCAD_CONVX(float, true, NJ_); else PCAD_CONVX(float, false, NJ_); }                           \
+    } while (0)
+    if (Rp == 64) PCAD_CONVX_NJ(6); else PCAD_CONVX_NJ(8);
+#undef PCAD_CONVX_NJ
 #undef PCAD_CONVX
     return hipGetLastError();
 }

@@ -88,17 +88,20 @@ hipError_t launch_conv_bidir(const void* x, int64_t ldx, const float* wf, const 
                              hipStream_t s, bool in_blocked = false);
 
 // convx.hip -------------------------------------------------------------------------------------
-// Fused conv1d+SiLU (both directions) + x_proj (both directions), Rp == 64: x [S*L, E] blocked -> xc0 / xc1 [S*L, E]
-// blocked, dtl_d [S*L, 64] (dtype dt), bc_d [S*L, 32] fp32.  convw: taps packed by launch_pack_convw.
+// Fused conv1d+SiLU (both directions) + x_proj (both directions), Rp == 64 or 96: x [S*L, E] blocked -> xc0 / xc1 [S*L, E]
+// blocked, dtl_d [S*L, Rp] (dtype dt), bc_d [S*L, 32] fp32; Wx_d [Rp + 32, E].  convw: taps packed by launch_pack_convw.
 size_t convx_packed_bytes(int E, int dt);
 hipError_t launch_pack_convw(const float* wf, const float* bf, const float* wr, const float* br, float* out, int E, int dt,
                              hipStream_t s);
 hipError_t launch_convx(const void* x, const float* convw, const void* Wx0, void* xc0, void* dtl0, float* bc0,
-                        const void* Wx1, void* xc1, void* dtl1, float* bc1, int S, int L, int E, int dt, hipStream_t s);
+                        const void* Wx1, void* xc1, void* dtl1, float* bc1, int S, int L, int E, int dt, hipStream_t s, int Rp = 64);
+// dt_rank padded to the K granule of the fused kernels: 64 up to dt_rank 64 (every PlantCaduceus size), else the next multiple of 32
+// (PlantCAD2 Large: dt_rank 96 -> 96)
+inline int padded_dt_rank(int R) { return R <= 64 ? 64 : (R + 31) / 32 * 32; }
 
 // scan.hip --------------------------------------------------------------------------------------
 // Selective scan of one direction.  delta == nullptr: fused dt_proj (delta tile = dt_low[rows, Rp] . Wdt[E, Rp]^T on
-// MFMA inside the kernel, Rp % 64 == 0, zero-padded K);  delta != nullptr: delta [rows, E] read from memory.
+// MFMA inside the kernel, Rp % 32 == 0, zero-padded K);  delta != nullptr: delta [rows, E] read from memory.
 // bc: fp32 [rows, 32] = B_t | C_t.  The recurrence uses A2 * a_scale as the base-2 decay rate: pass
 // (A * log2(e), 1) or (A, log2(e)).
 // uy_blocked: u and y are in the blocked layout (whole-tensor row index s*L + t, buffers padded to 8 rows).
@@ -114,16 +117,19 @@ hipError_t launch_scan(const void* u, const void* z, int64_t ldz, const void* de
 
 // Segments per strand for the scan of S strands of L steps over E channels.  Pass A + pass B cost ~1.8x the arithmetic of one
 // walk, and a single wave per SIMD already keeps the VALU ~65 % busy, so cutting only pays when most SIMDs would otherwise idle
-// (measured: 1 536 waves at L = 8 192 are 15 % FASTER uncut).  Cut when the launch has at most 768 waves (0.75 per SIMD) and the
-// strands are long (L >= 2 048): into enough segments for ~2 300 waves, at most 8, each at least 512 steps (16 blocks of 32).
+// (measured: 1 536 waves at L = 8 192 are 15 % FASTER uncut).  Cut when the launch has at most 768 waves (0.75 per SIMD): into
+// enough segments for ~2 300 waves, at most 8; long strands (L >= 2 048) into segments of at least 512 steps (16 blocks of 32),
+// short ones (the reference's 512-bp windows in batches below ~12: notebooks/examples.ipynb:141-170 runs B = 1) into segments of
+// at least 64 steps, where the chip is so empty that two 64-step passes beat one 512-step walk (round 4: bench --batch 1 / 8).
 inline int scan_segments(int S, int L, int E, int* seg_blocks) {
     const int64_t waves = (int64_t)S * (E / 64);
     const int nblk = (L + 31) / 32;
+    const int min_blocks = L >= 2048 ? 16 : 2;
     int G = 1;
-    if (L >= 2048 && waves > 0 && waves <= 768) {
+    if (L >= 256 && waves > 0 && waves <= 768) {
         G = (int)((2304 + waves - 1) / waves);
         if (G > 8) G = 8;
-        if (G > nblk / 16) G = nblk / 16;
+        if (G > nblk / min_blocks) G = nblk / min_blocks;
         if (G < 3) G = 1;                              // below ~3x the waves the second pass is not paid for
     }
     const int sb = (nblk + G - 1) / G;

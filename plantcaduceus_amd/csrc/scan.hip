@@ -96,24 +96,26 @@ template <> struct DeltaTile<bf16_t> {
     }
 };
 
-// Rp == 64 (every PlantCaduceus size: dt_rank <= 64): the dt_low operand of the NEXT block (4 x 16 bytes per lane) is
-// loaded one block ahead and held in registers through the walk, so its HBM/L2 latency is never exposed.
-struct DeltaPre { u32x4 a[4]; };
-__device__ __forceinline__ DeltaPre delta_prefetch(const bf16_t* __restrict__ dtl, int64_t lddt, int64_t row_base,
-                                                   int t0, int L, int lane) {
+// Rp == 64 (every PlantCaduceus size: dt_rank <= 64) or 96 (PlantCAD2 Large): the dt_low operand of the NEXT block (Rp / 16 x 16
+// bytes per lane) is loaded one block ahead and held in registers through the walk, so its HBM/L2 latency is never exposed.
+template <int RP> struct DeltaPre { u32x4 a[RP / 16]; };
+template <int RP>
+__device__ __forceinline__ DeltaPre<RP> delta_prefetch(const bf16_t* __restrict__ dtl, int64_t lddt, int64_t row_base,
+                                                       int t0, int L, int lane) {
     const int tr = max(0, min(t0 + (lane & 31), L - 1));
     const bf16_t* arow = dtl + (row_base + tr) * lddt + (lane >> 5) * 8;
-    DeltaPre p;
+    DeltaPre<RP> p;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) p.a[k] = *reinterpret_cast<const u32x4*>(arow + k * 16);
+    for (int k = 0; k < RP / 16; ++k) p.a[k] = *reinterpret_cast<const u32x4*>(arow + k * 16);
     return p;
 }
-__device__ __forceinline__ void delta_run_pre(const DeltaPre& p, const bf16_t* __restrict__ Wdt, int c0, int lane,
+template <int RP>
+__device__ __forceinline__ void delta_run_pre(const DeltaPre<RP>& p, const bf16_t* __restrict__ Wdt, int c0, int lane,
                                               f32x16& acc0, f32x16& acc1) {
-    const bf16_t* b0 = Wdt + (int64_t)(c0 + (lane & 31)) * 64 + (lane >> 5) * 8;
-    const bf16_t* b1 = b0 + (int64_t)32 * 64;
+    const bf16_t* b0 = Wdt + (int64_t)(c0 + (lane & 31)) * RP + (lane >> 5) * 8;
+    const bf16_t* b1 = b0 + (int64_t)32 * RP;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < RP / 16; ++k) {
         const u32x4 w0 = *reinterpret_cast<const u32x4*>(b0 + k * 16);
         const u32x4 w1 = *reinterpret_cast<const u32x4*>(b1 + k * 16);
         acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, p.a[k]),
@@ -148,14 +150,14 @@ template <> struct DeltaTile<float> {
 };
 
 // FUSED: delta comes from dt_low . Wdt^T (above);  !FUSED: delta is read from memory like u (operator entry).
-// PRE (bf16, FUSED, Rp == 64): dt_low operand prefetched one block ahead.
+// PRE (bf16, FUSED; 0: off, else = Rp, 64 or 96): dt_low operand prefetched one block ahead.
 // BLK8: u / y in the blocked layout AND L % 8 == 0 (the engine's case): one scalar block offset per 4-step chunk, the
 // per-step +-128 bytes ride in the buffer instruction's immediate offset.
 // SEG (long sequences with few strands, launch_scan below): the walk of a strand is cut into G segments of `seg_blocks` blocks that
 // run as separate workgroups.  SEG = 1, pass A: from a ZERO state, no output - stores the segment's end state and its sum of delta
 // (the product of its decays is exp2(A2 * sum delta));  SEG = 2, pass B: the normal walk of the segment from the true initial state
 // that scan_carry_kernel derived from pass A.  SEG = 0: the whole strand in one workgroup (G = 1).
-template <typename T, bool REV, int ACC, bool HASZ, bool FUSED, bool PRE, bool BLK8, int SEG = 0, bool ZB = false>
+template <typename T, bool REV, int ACC, bool HASZ, bool FUSED, int PRE, bool BLK8, int SEG = 0, bool ZB = false>
 __global__ __launch_bounds__(64, 4) void scan_kernel(const T* __restrict__ u, const T* __restrict__ z, int64_t ldz,
                                                   const T* __restrict__ dsrc, int64_t ldd,
                                                   const T* __restrict__ Wdt, int Rp,
@@ -318,8 +320,8 @@ __global__ __launch_bounds__(64, 4) void scan_kernel(const T* __restrict__ u, co
         return yv;
     };
 
-    DeltaPre pre;
-    if constexpr (PRE) pre = delta_prefetch((const bf16_t*)dsrc, ldd, row0, REV ? (L - (b_begin + 1) * TB) : b_begin * TB, L, lane);
+    DeltaPre<PRE ? PRE : 16> pre;
+    if constexpr (PRE != 0) pre = delta_prefetch<PRE>((const bf16_t*)dsrc, ldd, row0, REV ? (L - (b_begin + 1) * TB) : b_begin * TB, L, lane);
 
     const int b_end = SEG ? min(nblk, b_begin + seg_blocks) : nblk;
     for (int b = b_begin; b < b_end; ++b) {
@@ -328,10 +330,10 @@ __global__ __launch_bounds__(64, 4) void scan_kernel(const T* __restrict__ u, co
             f32x16 acc0, acc1;
 #pragma unroll
             for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
-            if constexpr (PRE) {
-                delta_run_pre(pre, (const bf16_t*)Wdt, c0, lane, acc0, acc1);
+            if constexpr (PRE != 0) {
+                delta_run_pre<PRE>(pre, (const bf16_t*)Wdt, c0, lane, acc0, acc1);
                 // next block's operand: in flight during this block's 32-step walk (rows clamp at the sequence ends)
-                pre = delta_prefetch((const bf16_t*)dsrc, ldd, row0, REV ? (L - (b + 2) * TB) : (b + 1) * TB, L, lane);
+                pre = delta_prefetch<PRE>((const bf16_t*)dsrc, ldd, row0, REV ? (L - (b + 2) * TB) : (b + 1) * TB, L, lane);
             } else {
                 DeltaTile<T>::run(dsrc, ldd, row0, tb0, L, Wdt, c0, Rp, lane, acc0, acc1);
             }
@@ -417,7 +419,7 @@ __global__ __launch_bounds__(256) void scan_carry_kernel(float* __restrict__ seg
     }
 }
 
-template <typename T, bool FUSED, bool PRE = false, bool BLK8 = false, bool ZB = false>
+template <typename T, bool FUSED, int PRE = 0, bool BLK8 = false, bool ZB = false>
 static hipError_t launch_scan_t(const void* u, const void* z, int64_t ldz, const void* dsrc, int64_t ldd,
                                 const void* Wdt, int Rp, const float* bc, const float* A2, float a_scale,
                                 const float* Dskip, const float* dbias, void* y, int S, int L, int E, bool reverse,
@@ -472,14 +474,16 @@ hipError_t launch_scan(const void* u, const void* z, int64_t ldz, const void* de
     if (uyb && (((int64_t)S * L + 7) / 8 * 8 * E * (dt == BF16 ? 2 : 4) >= ((int64_t)1 << 32) || (E * (dt == BF16 ? 2 : 4)) % 128))
         return hipErrorInvalidValue;     // blocked layout: 32-bit whole-tensor offsets
     const bool fused = delta == nullptr;
-    if (fused && (!dt_low || !Wdt || Rp <= 0 || Rp % 64)) return hipErrorInvalidValue;
+    if (fused && (!dt_low || !Wdt || Rp <= 0 || Rp % 32)) return hipErrorInvalidValue;
     if (dt == BF16) {
         if (fused && Rp == 64 && lddt % 8 == 0 && uyb && L % 8 == 0 && zblk)      // the engine's case: every layout known at compile time
-            return launch_scan_t<bf16_t, true, true, true, true>(u, z, ldz, dt_low, lddt, Wdt, Rp, bc, A2, a_scale, Dskip, dbias, y, S, L, E, reverse, accumulate, s, uyb, zblk, seg_ws, walk_len);
+            return launch_scan_t<bf16_t, true, 64, true, true>(u, z, ldz, dt_low, lddt, Wdt, Rp, bc, A2, a_scale, Dskip, dbias, y, S, L, E, reverse, accumulate, s, uyb, zblk, seg_ws, walk_len);
+        if (fused && Rp == 96 && lddt % 8 == 0 && uyb && L % 8 == 0 && zblk)      // the engine's case at dt_rank 65..96 (PlantCAD2 Large)
+            return launch_scan_t<bf16_t, true, 96, true, true>(u, z, ldz, dt_low, lddt, Wdt, Rp, bc, A2, a_scale, Dskip, dbias, y, S, L, E, reverse, accumulate, s, uyb, zblk, seg_ws, walk_len);
         if (fused && Rp == 64 && lddt % 8 == 0 && uyb && L % 8 == 0)
-            return launch_scan_t<bf16_t, true, true, true>(u, z, ldz, dt_low, lddt, Wdt, Rp, bc, A2, a_scale, Dskip, dbias, y, S, L, E, reverse, accumulate, s, uyb, zblk, seg_ws, walk_len);
+            return launch_scan_t<bf16_t, true, 64, true>(u, z, ldz, dt_low, lddt, Wdt, Rp, bc, A2, a_scale, Dskip, dbias, y, S, L, E, reverse, accumulate, s, uyb, zblk, seg_ws, walk_len);
         if (fused && Rp == 64 && lddt % 8 == 0)
-            return launch_scan_t<bf16_t, true, true>(u, z, ldz, dt_low, lddt, Wdt, Rp, bc, A2, a_scale, Dskip, dbias, y, S, L, E, reverse, accumulate, s, uyb, zblk, seg_ws, walk_len);
+            return launch_scan_t<bf16_t, true, 64>(u, z, ldz, dt_low, lddt, Wdt, Rp, bc, A2, a_scale, Dskip, dbias, y, S, L, E, reverse, accumulate, s, uyb, zblk, seg_ws, walk_len);
         if (fused) return launch_scan_t<bf16_t, true>(u, z, ldz, dt_low, lddt, Wdt, Rp, bc, A2, a_scale, Dskip, dbias, y, S, L, E, reverse, accumulate, s, uyb, zblk, seg_ws, walk_len);
         return launch_scan_t<bf16_t, false>(u, z, ldz, delta, E, nullptr, 0, bc, A2, a_scale, Dskip, dbias, y, S, L, E, reverse, accumulate, s, uyb, zblk, seg_ws, walk_len);
     }

@@ -62,7 +62,7 @@ SIGNATURES = {
     "pcad_causal_conv1d_silu": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                           C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "pcad_conv_xproj_scratch_bytes": (C.c_size_t, [C.c_int, C.c_int]),
-    "pcad_conv_xproj_bidir": (C.c_int, [C.c_void_p] * 14 + [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "pcad_conv_xproj_bidir": (C.c_int, [C.c_void_p] * 14 + [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "pcad_selective_scan": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                       C.c_int, C.c_int, C.c_void_p]),

@@ -86,28 +86,29 @@ def conv_xproj_bidir(x_tm, w_fwd, b_fwd, w_rev, b_rev, x_proj_fwd, x_proj_rev):
     """The engine's fused head of mamba_inner_fn, both directions from one read of x:
         xc_d    = causal_conv1d_fn(x, w_d, b_d, "silu")        (d = rev: anti-causal on the same rows)
         x_dbl_d = F.linear(xc_d, x_proj_d)                     (stored in the model dtype)
-    x_tm [S, L, E]; w_* [E, 4]; b_* [E]; x_proj_* [R + 32, E] with R <= 64.
+    x_tm [S, L, E]; w_* [E, 4]; b_* [E]; x_proj_* [R + 32, E] with R <= 96.
     Returns (xc_fwd, xc_rev [S, L, E], x_dbl_fwd, x_dbl_rev [S, L, R + 32]) in x's dtype."""
     _require_gpu(x_tm, "x")
     lib = load_library()
     S, L, E = x_tm.shape
     dt, dev = x_tm.dtype, x_tm.device
     R = x_proj_fwd.shape[0] - 32
-    if not 0 < R <= 64:
-        raise ValueError("dt_rank must be in [1, 64] for the fused kernel")
+    if not 0 < R <= 96:
+        raise ValueError("dt_rank must be in [1, 96] for the fused kernel")
+    Rp = 64 if R <= 64 else 96
     rows = S * L
     xb = to_blocked(x_tm.reshape(rows, E))
 
     def pack_wx(w):
-        p = torch.zeros((96, E), dtype=dt, device=dev)
+        p = torch.zeros((Rp + 32, E), dtype=dt, device=dev)
         p[:R] = w[:R].to(dt)
-        p[64:] = w[R:].to(dt)
+        p[Rp:] = w[R:].to(dt)
         return p
     wx = [pack_wx(x_proj_fwd), pack_wx(x_proj_rev)]
     taps = [t.float().contiguous() for t in (w_fwd.reshape(E, -1), b_fwd, w_rev.reshape(E, -1), b_rev)]
     scratch = torch.empty(lib.pcad_conv_xproj_scratch_bytes(E, _DT[dt]) + 256, dtype=torch.uint8, device=dev)
     xc = [torch.zeros_like(xb) for _ in range(2)]
-    dtl = [torch.empty((rows, 64), dtype=dt, device=dev) for _ in range(2)]
+    dtl = [torch.empty((rows, Rp), dtype=dt, device=dev) for _ in range(2)]
     bc = [torch.empty((rows, 32), dtype=torch.float32, device=dev) for _ in range(2)]
     with torch.cuda.device(dev):
         _check(lib.pcad_conv_xproj_bidir(xb.data_ptr(), taps[0].data_ptr(), taps[1].data_ptr(), taps[2].data_ptr(),
@@ -115,7 +116,7 @@ def conv_xproj_bidir(x_tm, w_fwd, b_fwd, w_rev, b_rev, x_proj_fwd, x_proj_rev):
                                          (scratch.data_ptr() + 255) // 256 * 256,
                                          xc[0].data_ptr(), dtl[0].data_ptr(), bc[0].data_ptr(),
                                          xc[1].data_ptr(), dtl[1].data_ptr(), bc[1].data_ptr(),
-                                         S, L, E, _DT[dt], _stream_ptr()), "pcad_conv_xproj_bidir")
+                                         S, L, E, Rp, _DT[dt], _stream_ptr()), "pcad_conv_xproj_bidir")
     outs = [from_blocked(c, rows).view(S, L, E) for c in xc]
     dbl = [torch.cat([dtl[d][:, :R], bc[d].to(dt)], dim=1).view(S, L, R + 32) for d in range(2)]
     return outs[0], outs[1], dbl[0], dbl[1]
@@ -185,7 +186,7 @@ def selective_scan_dtproj_fn(u, dt_low, dt_proj_weight, A, B, C, D=None, z=None,
     lib = load_library()
     Bsz, E, L = u.shape
     R = dt_low.shape[-1]
-    Rp = (R + 63) // 64 * 64
+    Rp = 64 if R <= 64 else (R + 31) // 32 * 32          # kernels.hpp padded_dt_rank
     u_tm, z_tm, bc, A32, Dv, db = _scan_common(u, B, C, A, D, z, delta_bias)
     dl = torch.zeros((Bsz, L, Rp), dtype=u.dtype, device=u.device)
     dl[..., :R] = dt_low.to(u.dtype)

@@ -62,11 +62,17 @@ def main():
             res[k]["valu_busy_frac"] = round(row["SQ_ACTIVE_INST_VALU"] * 4 / 1024 / gui, 3)   # quad-cycles
             res[k]["mfma_busy_frac"] = round(row["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024 / gui, 3)
     cls = {"selective_scan": [k for k in res if "scan_kernel" in k],
-           "gemm_in_out_proj": [k for k in res if "gemm256" in k] or [k for k in res if "gemm_nt_kernel" in k and k.endswith("false>")],
+           # 4-wave GEMM by fused epilogue (gemm.hip EPI_*): <T, T, 1> = in_proj with the row scale, <T, T, 2> = out_proj + residual
+           # (norm_fold); <T, T, 0> / round-3 names without the parameter = both projections of the reference-order path
+           "gemm_in_proj": [k for k in res if "gemm256q" in k and k.endswith(", 1>")],
+           "gemm_out_proj_res": [k for k in res if "gemm256q" in k and k.endswith(", 2>")],
+           "gemm_in_out_proj": [k for k in res if "gemm256" in k and not k.endswith(", 1>") and not k.endswith(", 2>")]
+                               or [k for k in res if "gemm_nt_kernel" in k and k.endswith("false>")],
+           "rstd_reduce": [k for k in res if "rstd_kernel" in k],
            "gemm_x_proj": [k for k in res if "gemm_nt_kernel" in k and k.endswith("true>")],
            "conv1d_bidir": [k for k in res if "conv_bidir" in k],
            "conv_xproj_fused": [k for k in res if "convx" in k],
-           "add_rmsnorm": [k for k in res if "add_rmsnorm" in k and k.endswith("false>")]}
+           "add_rmsnorm": [k for k in res if "add_rmsnorm" in k and (k.endswith("false>") or k.endswith("false, false>"))]}
     o = {"source": NOTE_SRC.format(batch=rows // 512, rows=rows), "correction": NOTE_CORR, "rows_per_launch": rows, "kernels": res, "classes": {}}
     try:
         o["src_hash"] = open(base + "src_hash.txt").read().strip()     # bench.source_hash() of the profiled build

@@ -133,18 +133,19 @@ def test_full_depth_bf16_engine_options_against_reference_order():
     assert d["norm_fold"] <= 2 * max(d["default"], floor) + 1e-3
 
 
-def test_full_depth_fp32_reference_order_norm():
-    """north_star's 1e-4 on the fp32 model, all 32 layers, with the reference's add + RMSNorm launch per block (norm_fold=0; the
-    default, folded form is what test_full_depth_fp32 runs)."""
+def test_full_depth_fp32_norm_fold():
+    """north_star's 1e-4 on the fp32 model, all 32 layers, with the folded add + norm forced on (norm_fold=1; the fp32 model's
+    default is the reference-order launch, which test_full_depth_fp32 runs: accumulating the GEMM onto the residual value costs
+    fp32 precision - measured 2.2e-5 of max on the hidden states against 1.3e-6 - and only the bf16 model folds by default)."""
     cfg = make_config("l32")
     sd = synthetic_state_dict(cfg, seed=21, stress=True)
     ids = windows(8, 5)
     lg_ref, hid_ref = COracle(sd, cfg, blas=True).forward(ids, want_hidden=True)
-    out = hip_model(cfg, sd, torch.float32, norm_fold=0)(input_ids=torch.from_numpy(ids).to(DEV), output_hidden_states=True)
+    out = hip_model(cfg, sd, torch.float32, norm_fold=1)(input_ids=torch.from_numpy(ids).to(DEV), output_hidden_states=True)
     lg, hid = out.logits.cpu().numpy(), out.hidden_states[-1].cpu().numpy()
     e_l = np.abs(lg - lg_ref).max() / np.abs(lg_ref).max()
     e_h = np.abs(hid - hid_ref).max() / np.abs(hid_ref).max()
-    print(f"l32 fp32 full depth, norm_fold=0: logits rel err {e_l:.2e}, hidden rel err {e_h:.2e}")
+    print(f"l32 fp32 full depth, norm_fold=1: logits rel err {e_l:.2e}, hidden rel err {e_h:.2e}")
     assert e_l < 1e-4 and e_h < 1e-4
     assert (lg[:, P, 3:7].argmax(-1) == lg_ref[:, P, 3:7].argmax(-1)).all()
 

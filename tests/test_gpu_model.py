@@ -206,8 +206,47 @@ def test_long_window_8192():
     assert (lg[:, 0, 3:7].argmax(-1) == lg_ref[:, 4095, 3:7].argmax(-1)).all()
 
 
+@pytest.mark.parametrize("dtype,L,B,nl", [(torch.float32, 8192, 1, 1), (torch.bfloat16, 8192, 2, 2), (torch.bfloat16, 512, 6, 2)])
+def test_plantcad2_large_geometry(dtype, L, B, nl):
+    """PlantCAD2-Large's block (reference docs/PlantCAD2-overview.md:21: d_model 1536 => d_inner 3072, dt_rank 96) at full width
+    on the fused path: conv + x_proj with 8 output fragments and one Wx slab (convx.hip NJ = 8), dt_proj K = 96 prefetched inside
+    the scan, the 4-wave GEMMs at N = 6144 / 1536, at the 8 192-bp context (segmented scan for the single window) and at 512 bp.
+    fp32 against the C oracle to north_star's 1e-4; bf16 against its bf16-emulating mode."""
+    from oracle.c_oracle import COracle
+    cfg = make_config("pc2-large", n_layer=nl)
+    assert (cfg.d_model, cfg.d_inner, cfg.dt_rank) == (1536, 3072, 96)
+    sd = synthetic_state_dict(cfg, seed=23, stress=True)
+    p = L // 2 - 1
+    ids = rand_ids(B, L, 3, mask=p)
+    sel = [p, 0, L - 1]
+    m = build(cfg, sd, dtype)
+    eng = m._engine()
+    eng.profile(1)
+    out = m(input_ids=ids.to(DEV), output_hidden_states=True, positions=sel)
+    torch.cuda.synchronize()
+    st = {k: v[0] for k, v in eng.profile_read().items()}
+    eng.profile(False)
+    assert st["gemm_x_proj"] == 0 and st["conv1d_bidir"] == nl, st           # the fused conv + x_proj kernel ran, not the three-launch fallback
+    lg, hid = out.logits.cpu().numpy(), out.hidden_states[-1].float().cpu().numpy()
+    if dtype == torch.float32:
+        lg_ref, hid_ref = COracle(sd, cfg, blas=True).forward(ids.numpy(), want_hidden=True)
+        e_l = np.abs(lg - lg_ref[:, sel]).max() / np.abs(lg_ref).max()
+        e_h = np.abs(hid - hid_ref[:, sel]).max() / np.abs(hid_ref).max()
+        print(f"PlantCAD2-Large geometry fp32 L={L}: logits {e_l:.2e} hidden {e_h:.2e}")
+        assert e_l < 1e-4 and e_h < 1e-4
+        assert (lg[:, 0, 3:7].argmax(-1) == lg_ref[:, p, 3:7].argmax(-1)).all()
+    else:
+        lg_ref, hid_ref = COracle(sd, cfg, blas=True, dtype=torch.bfloat16, emulate_bf16=True).forward(ids.numpy(), want_hidden=True)
+        e_l = np.abs(lg - lg_ref[:, sel]).max() / np.abs(lg_ref).max()
+        e_h = np.abs(hid - hid_ref[:, sel]).max() / np.abs(hid_ref).max()
+        print(f"PlantCAD2-Large geometry bf16 L={L}: logits {e_l:.2e} hidden {e_h:.2e} (vs the bf16-emulating oracle)")
+        assert e_l < 3e-2 and e_h < 3e-2 and np.isfinite(lg).all()
+
+
 @pytest.mark.parametrize("dtype,D,L,B", [(torch.float32, 256, 4096, 1), (torch.bfloat16, 384, 8192, 2), (torch.bfloat16, 768, 2048, 3),
-                                          (torch.float32, 128, 2080, 2)])
+                                          (torch.float32, 128, 2080, 2),
+                                          # 512-bp windows in tiny batches (the reference's notebook runs B = 1): segments of 64 steps
+                                          (torch.float32, 1024, 512, 1), (torch.bfloat16, 1024, 512, 3), (torch.float32, 384, 300, 2)])
 def test_segmented_scan_equals_single_walk(dtype, D, L, B):
     """long windows, few strands: the scan cuts every strand into segments run by separate workgroups (zero-state pass, carry,
     real pass; csrc/kernels.hpp::scan_segments).  Same function as one workgroup walking the whole strand (`scan_segments` = 0):
@@ -216,7 +255,7 @@ def test_segmented_scan_equals_single_walk(dtype, D, L, B):
     cfg = make_config("x", d_model=D, n_layer=2)
     sd = synthetic_state_dict(cfg, seed=31)
     ids = rand_ids(B, L, 3, mask=L // 2).to(DEV)
-    pos = [L // 2, 0, L - 1, 1031]
+    pos = [L // 2, 0, L - 1, min(1031, L - 2)]
     a = build(cfg, sd, dtype)(input_ids=ids, output_hidden_states=True, positions=pos)
     b = build(cfg, sd, dtype, scan_segments=0)(input_ids=ids, output_hidden_states=True, positions=pos)
     la, lb = a.logits.float().cpu(), b.logits.float().cpu()

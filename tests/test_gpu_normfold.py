@@ -1,4 +1,4 @@
-"""-m gpu: the "norm_fold" layer form (include/pcad.h pcad_set_option; the engine's default): the add + RMSNorm launch between two blocks folded into
+"""-m gpu: the "norm_fold" layer form (include/pcad.h pcad_set_option; the bf16 engine's default): the add + RMSNorm launch between two blocks folded into
 out_proj's epilogue (fp32 residual read-modify-write + rounded copy + per-row partial sums of squares) and in_proj (norm weight
 folded into W_in at bind time, rstd applied before rounding).  Same value in exact arithmetic as the reference's
 rms_norm_fn(..., prenorm=True, residual_in_fp32=True) between out_proj and in_proj, so: the fp32
@@ -87,13 +87,16 @@ def test_norm_fold_falls_back_on_partial_tiles_and_all_hidden():
     cfg = make_config("x", d_model=256, n_layer=3)
     sd = synthetic_state_dict(cfg, seed=4, stress=True)
     ids = rand_ids(2, 64, 2).to(DEV)
-    # the option is the engine's default; norm_fold=0 runs the reference's add + RMSNorm launch per block
+    # the option is the bf16 engine's default (the fp32 engine's default is the reference order); norm_fold=0 runs the reference's
+    # add + RMSNorm launch per block
     _, n_def = folded_launches(build(cfg, sd, torch.bfloat16), ids)
     _, n_off = folded_launches(build(cfg, sd, torch.bfloat16, norm_fold=0), ids)
+    _, n_f32 = folded_launches(build(cfg, sd, torch.float32), ids)
     assert n_def["gemm_out_proj_res"] == 2 and n_def["add_rmsnorm"] == 0 and n_off["gemm_out_proj_res"] == 0 and n_off["add_rmsnorm"] == 3
+    assert n_f32["gemm_out_proj_res"] == 0 and n_f32["add_rmsnorm"] == 3
     cfg.materialize_all_hidden_states = True
-    a = build(cfg, sd, torch.float32, norm_fold=1)(input_ids=ids, output_hidden_states=True).hidden_states
-    b = build(cfg, sd, torch.float32, norm_fold=0)(input_ids=ids, output_hidden_states=True).hidden_states
+    a = build(cfg, sd, torch.bfloat16, norm_fold=1)(input_ids=ids, output_hidden_states=True).hidden_states
+    b = build(cfg, sd, torch.bfloat16, norm_fold=0)(input_ids=ids, output_hidden_states=True).hidden_states
     assert len(a) == len(b) == 4 and all(torch.equal(x, y) for x, y in zip(a, b))
 
 

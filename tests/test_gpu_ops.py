@@ -72,7 +72,10 @@ def test_causal_conv1d_fp32(ops, L):
 @pytest.mark.parametrize("S,L,E,R,dtype", [(3, 24, 128, 8, torch.float32), (2, 512, 768, 24, torch.float32),
                                            (2, 203, 256, 16, torch.float32), (1, 1, 128, 8, torch.float32),
                                            (2, 5, 128, 8, torch.float32), (4, 512, 2048, 64, torch.bfloat16),
-                                           (3, 77, 768, 24, torch.bfloat16), (2, 133, 1536, 48, torch.float32)])
+                                           (3, 77, 768, 24, torch.bfloat16), (2, 133, 1536, 48, torch.float32),
+                                           # dt_rank 65..96 (PlantCAD2 Large: d_inner 3072, dt_rank 96): the 8-fragment variant, one Wx slab
+                                           (2, 512, 3072, 96, torch.bfloat16), (3, 200, 512, 80, torch.float32),
+                                           (2, 77, 1024, 96, torch.bfloat16), (1, 384, 3072, 96, torch.float32), (2, 5, 256, 65, torch.float32)])
 def test_conv_xproj_fused(ops, S, L, E, R, dtype):
     """pcad_conv_xproj_bidir — the kernel the engine actually runs for conv1d+SiLU and x_proj (convx.hip): both directions
     against causal_conv1d_fn + einsum of the oracle (mamba_inner's head).  fp32: 1e-5 (conv) / 3e-5 (x_dbl, K = E sums);
@@ -141,7 +144,10 @@ def test_selective_scan_fp32(ops, L):
 
 
 @pytest.mark.parametrize("L,R,dtype", [(512, 64, torch.float32), (70, 24, torch.float32), (33, 48, torch.float32),
-                                       (256, 64, torch.bfloat16), (45, 24, torch.bfloat16)])
+                                       (256, 64, torch.bfloat16), (45, 24, torch.bfloat16),
+                                       # dt_rank 65..96: K of the in-kernel dt_proj padded to 96 (PlantCAD2 Large), up to 128 generically
+                                       (512, 96, torch.bfloat16), (100, 80, torch.float32), (64, 96, torch.float32), (39, 80, torch.bfloat16),
+                                       (48, 128, torch.float32)])
 def test_selective_scan_fused_dtproj(ops, L, R, dtype):
     """engine form: delta = dt_proj.weight @ dt_low on MFMA inside the scan (mamba_inner_fn tail), both directions."""
     u, _, A, Bm, Cm, D, z, db = _scan_inputs(L + R, 2, 128, L)

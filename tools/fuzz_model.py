@@ -13,12 +13,12 @@ rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 bad = 0
 t0 = time.time()
 for case in range(n):
-    D = int(rng.choice([64, 128, 192, 256, 384, 512]))
+    D = int(rng.choice([64, 128, 192, 256, 384, 512, 768]))
     nl = int(rng.integers(1, 4))
     B = int(rng.integers(1, 6))
     L = int(rng.choice([1, 2, 3, 5, 7, 8, 9, 15, 16, 17, 31, 33, 63, 64, 65, 100, 127, 128, 129, 200, 255, 257, 300]))
     bf16 = bool(rng.integers(0, 2))
-    ssm = dict(d_state=16, d_conv=4, expand=2, dt_rank=int(rng.choice([D // 16, max(1, D // 16 - 1), min(64, D // 16 + 3)])), bias=False, conv_bias=True)
+    ssm = dict(d_state=16, d_conv=4, expand=2, dt_rank=int(rng.choice([D // 16, max(1, D // 16 - 1), min(64, D // 16 + 3), 80, 96, 70])), bias=False, conv_bias=True)
     cfg = make_config("x", d_model=D, n_layer=nl, ssm_cfg=ssm)
     sd = synthetic_state_dict(cfg, seed=int(rng.integers(0, 1 << 30)), stress=True)
     ids = torch.from_numpy(rng.integers(0, 8, size=(B, L)))          # every token id incl. PAD / MASK / UNK / the pad row

@@ -32,13 +32,15 @@ __global__ __launch_bounds__(256, 1) void mfma_only(float* out, long long* cyc, 
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     long long t0 = __builtin_readcyclecounter();
+    // accumulators pinned to the accumulator file with inline-asm MFMAs ("+a"): the builtin form made hipcc shuttle every
+    // accumulator through v_accvgpr_read / v_accvgpr_mov and pad with s_nop (round 3's 27 cycles per MFMA was that instruction
+    // stream, not the pipe: VERDICT r3 #5a); this loop is 16 back-to-back v_mfma and one s_cbranch.
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                acc[i * 4 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a[i]), __builtin_bit_cast(bf16x8_t, b[j]),
-                                                                         acc[i * 4 + j], 0, 0, 0);
+                asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[i * 4 + j]) : "v"(a[i]), "v"(b[j]));
     }
     long long t1 = __builtin_readcyclecounter();
     float s = 0.f;

@@ -90,15 +90,15 @@ class Sampler(threading.Thread):
             time.sleep(0.02)
 
 
-def measure(name, fn, seconds=3.0):
+def measure(name, fn, seconds=3.0, inner=8):
     import torch
     fn(); torch.cuda.synchronize()
     s = Sampler(); s.start()
     t0 = time.perf_counter(); n = 0
     while time.perf_counter() - t0 < seconds:
-        for _ in range(8):
+        for _ in range(inner):
             fn()
-        torch.cuda.synchronize(); n += 8
+        torch.cuda.synchronize(); n += inner
     dt = time.perf_counter() - t0
     s.stop = True; s.join()
     p = s.p[len(s.p) // 4:]                     # drop the ramp
@@ -130,7 +130,19 @@ def main():
     ids = np.random.default_rng(0).integers(3, 7, size=(1024, 512), dtype=np.int32); ids[:, 255] = 1
     ids = torch.from_numpy(ids).to(dev)
     measure("idle (sleep)", lambda: time.sleep(0.05), 1.5)
-    measure("whole forward, 1024 windows", lambda: eng.forward(ids, positions=[255]), 6.0)
+    measure("whole forward, 1024 windows (norm_fold)", lambda: eng.forward(ids, positions=[255]), 6.0)
+    # the ENGINE's own launches (instantiations, layouts, 524288-row launch size), one kernel class at a time: every idempotent
+    # launch of the class is repeated 24x inside the forward (pcad_set_option debug_repeat_class / debug_repeat), so the class is
+    # > 85 % of the measured interval; classes: include/pcad.h pcad_kernel_class
+    eng.set_option("norm_fold", 0)
+    measure("whole forward, 1024 windows (norm_fold=0)", lambda: eng.forward(ids, positions=[255]), 5.0)
+    eng.set_option("debug_repeat", 24)
+    for cls, name in ((1, "engine in_proj x24"), (2, "engine conv+x_proj x24"), (4, "engine forward scan x24"), (5, "engine out_proj x24")):
+        eng.set_option("debug_repeat_class", cls)
+        measure(name + " (per forward)", lambda: eng.forward(ids, positions=[255]), 5.0, inner=1)
+    eng.set_option("debug_repeat_class", -1)
+    eng.set_option("debug_repeat", 1)
+    eng.set_option("norm_fold", 1)
     M = 262144
     x = torch.randn(M, 1024, device=dev).bfloat16(); w_in = (torch.randn(4096, 1024, device=dev) / 32).bfloat16()
     measure("in_proj GEMM 262144x4096x1024", lambda: ops.linear(x, w_in))
