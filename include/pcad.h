@@ -105,8 +105,8 @@ void   pcad_destroy(pcad_handle h);
  *                 never by pcad_forward_all_hidden (+4.5 % end to end, same-box A/B, profiles/r04_ab_runs.txt);
  *                 0 (default for the fp32 model, whose 1e-4 parity budget would pay for accumulating onto the residual: 2.2e-5 of
  *                 max after 32 layers instead of 1.3e-6): the reference's operation order (one add + RMSNorm launch per block).
- *   "scan_segments"  1 (default): when a launch has at most 768 scan waves (PlantCAD2's 8 192-bp windows in small batches, or
- *                 fewer than ~12 windows of 512 bp at l32) the scan of every strand is cut into up to 8 segments that run as
+ *   "scan_segments"  1 (default): when a launch has few scan waves (at most 768 for L >= 2 048: PlantCAD2's 8 192-bp windows in small
+ *                 batches; at most 512 for shorter windows: up to 8 windows of 512 bp at l32) the scan of every strand is cut into up to 8 segments that run as
  *                 separate workgroups (zero-state pass, carry, real pass: ~1.8x the arithmetic for up to 8x the parallelism;
  *                 results equal up to fp32 rounding of the carried decay product);  0: one workgroup walks the whole strand.
  *                 Never used by the benchmark batch (1 024 windows: 65 536 waves).

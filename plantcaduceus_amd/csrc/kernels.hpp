@@ -119,14 +119,16 @@ hipError_t launch_scan(const void* u, const void* z, int64_t ldz, const void* de
 // walk, and a single wave per SIMD already keeps the VALU ~65 % busy, so cutting only pays when most SIMDs would otherwise idle
 // (measured: 1 536 waves at L = 8 192 are 15 % FASTER uncut).  Cut when the launch has at most 768 waves (0.75 per SIMD): into
 // enough segments for ~2 300 waves, at most 8; long strands (L >= 2 048) into segments of at least 512 steps (16 blocks of 32),
-// short ones (the reference's 512-bp windows in batches below ~12: notebooks/examples.ipynb:141-170 runs B = 1) into segments of
-// at least 64 steps, where the chip is so empty that two 64-step passes beat one 512-step walk (round 4: bench --batch 1 / 8).
+// short ones (the reference's 512-bp windows in batches of at most 8 at l32: notebooks/examples.ipynb:141-170 runs B = 1) into
+// segments of at least 64 steps when the launch has at most 512 waves, where the chip is so empty that two 64-step passes beat one
+// 512-step walk (profiles/r04j_small_batch.txt, seq/s without -> with: l32 B = 1 61 -> 107, B = 8 455 -> 548; l20 B = 1 119 -> 257,
+// B = 8 929 -> 1682; at 768 waves - l20 B = 32 - it loses 13 %, hence the lower bound for short strands).
 inline int scan_segments(int S, int L, int E, int* seg_blocks) {
     const int64_t waves = (int64_t)S * (E / 64);
     const int nblk = (L + 31) / 32;
     const int min_blocks = L >= 2048 ? 16 : 2;
     int G = 1;
-    if (L >= 256 && waves > 0 && waves <= 768) {
+    if (L >= 256 && waves > 0 && waves <= (L >= 2048 ? 768 : 512)) {
         G = (int)((2304 + waves - 1) / waves);
         if (G > 8) G = 8;
         if (G > nblk / min_blocks) G = nblk / min_blocks;

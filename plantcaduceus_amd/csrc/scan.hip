@@ -478,7 +478,8 @@ hipError_t launch_scan(const void* u, const void* z, int64_t ldz, const void* de
     if (dt == BF16) {
         if (fused && Rp == 64 && lddt % 8 == 0 && uyb && L % 8 == 0 && zblk)      // the engine's case: every layout known at compile time
             return launch_scan_t<bf16_t, true, 64, true, true>(u, z, ldz, dt_low, lddt, Wdt, Rp, bc, A2, a_scale, Dskip, dbias, y, S, L, E, reverse, accumulate, s, uyb, zblk, seg_ws, walk_len);
-        if (fused && Rp == 96 && lddt % 8 == 0 && uyb && L % 8 == 0 && zblk)      // the engine's case at dt_rank 65..96 (PlantCAD2 Large)
+        static const bool nopre96 = dev_env("PCAD_SCAN_NOPRE96") != nullptr;       // PCAD_DEV=1 A/B: the non-prefetching walk instead
+        if (!nopre96 && fused && Rp == 96 && lddt % 8 == 0 && uyb && L % 8 == 0 && zblk)      // the engine's case at dt_rank 65..96 (PlantCAD2 Large)
             return launch_scan_t<bf16_t, true, 96, true, true>(u, z, ldz, dt_low, lddt, Wdt, Rp, bc, A2, a_scale, Dskip, dbias, y, S, L, E, reverse, accumulate, s, uyb, zblk, seg_ws, walk_len);
         if (fused && Rp == 64 && lddt % 8 == 0 && uyb && L % 8 == 0)
             return launch_scan_t<bf16_t, true, 64, true>(u, z, ldz, dt_low, lddt, Wdt, Rp, bc, A2, a_scale, Dskip, dbias, y, S, L, E, reverse, accumulate, s, uyb, zblk, seg_ws, walk_len);

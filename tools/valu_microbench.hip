@@ -12,8 +12,8 @@
 #include <vector>
 typedef float f2 __attribute__((ext_vector_type(2)));
 
-template <int MODE, int NFMA>
-__global__ __launch_bounds__(256) void k(float* out, long long* cyc, int iters, float seed) {
+template <int MODE, int NFMA, int THREADS = 256>
+__global__ __launch_bounds__(THREADS) void k(float* out, long long* cyc, int iters, float seed) {
     float e[8]; f2 p[8]; float f[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) { e[i] = seed * (i + 1) * 1e-3f - 0.5f; f[i] = seed + i; p[i] = f2{seed + i, seed - i}; }
@@ -110,17 +110,22 @@ static double read_sclk(const std::string& card) {
     return mhz;
 }
 
+// one_block_per_cu: 256 blocks of 256 * waves_per_simd threads, i.e. exactly one block per CU - the dispatcher cannot give one CU more
+// work than another, so wall time = every CU's time (with 256-thread blocks, 4 per CU on average, the spread of blocks over CUs is
+// uneven and the wall clock follows the fullest CU: that, not a lower clock, is where round 3's "1.5-1.6 GHz" came from)
 template <int MODE, int NFMA>
-void run_power(const char* name, int waves_per_simd, const std::string& card) {
-    const int blocks = 256 * waves_per_simd;
+void run_power(const char* name, int waves_per_simd, const std::string& card, bool one_block_per_cu = false) {
+    const bool big = one_block_per_cu && waves_per_simd == 4;
+    const int threads = big ? 1024 : 256;
+    const int blocks = big ? 256 : 256 * waves_per_simd;
     float* out; long long* cyc;
-    hipMalloc(&out, sizeof(float) * blocks * 256); hipMalloc(&cyc, sizeof(long long) * blocks);
-    k<MODE, NFMA><<<blocks, 256>>>(out, cyc, 100, 1.0f);
+    hipMalloc(&out, sizeof(float) * blocks * threads); hipMalloc(&cyc, sizeof(long long) * blocks);
+    if (big) k<MODE, NFMA, 1024><<<blocks, 1024>>>(out, cyc, 100, 1.0f); else k<MODE, NFMA><<<blocks, 256>>>(out, cyc, 100, 1.0f);
     hipDeviceSynchronize();
     const int iters = 4000000;                                             // seconds, not milliseconds
     hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
     hipEventRecord(a);
-    k<MODE, NFMA><<<blocks, 256>>>(out, cyc, iters, 1.0f);
+    if (big) k<MODE, NFMA, 1024><<<blocks, 1024>>>(out, cyc, iters, 1.0f); else k<MODE, NFMA><<<blocks, 256>>>(out, cyc, iters, 1.0f);
     hipEventRecord(b);
     std::vector<double> pw, ck;
     while (hipEventQuery(b) == hipErrorNotReady) {
@@ -136,8 +141,8 @@ void run_power(const char* name, int waves_per_simd, const std::string& card) {
     double pa = 0, pm = 0; size_t n0 = pw.size() / 4; for (size_t i = n0; i < pw.size(); ++i) { pa += pw[i]; if (pw[i] > pm) pm = pw[i]; }
     double ca = 0; size_t c0 = ck.size() / 4; for (size_t i = c0; i < ck.size(); ++i) ca += ck[i];
     const double groups = (double)iters * 8;
-    printf("%-28s waves/SIMD=%d  %.0f ms: %.2f SIMD-cycles@2.4GHz per group; effective clock %.2f GHz (s_memtime / wall); power %.0f W avg, "
-           "%.0f max over %zu samples; sclk %.0f MHz avg\n", name, waves_per_simd, ms, ms * 1e-3 * 2.4e9 / groups / waves_per_simd,
+    printf("%-28s waves/SIMD=%d%s  %.0f ms: %.2f SIMD-cycles@2.4GHz per group; effective clock %.2f GHz (s_memtime / wall); power %.0f W avg, "
+           "%.0f max over %zu samples; sclk %.0f MHz avg\n", name, waves_per_simd, big ? " (1 block of 1024 per CU)" : "", ms, ms * 1e-3 * 2.4e9 / groups / waves_per_simd,
            avg / (ms * 1e-3) / 1e9, pw.size() > n0 ? pa / (pw.size() - n0) : -1.0, pm, pw.size(), ck.size() > c0 ? ca / (ck.size() - c0) : -1.0);
     hipFree(out); hipFree(cyc);
 }
@@ -153,6 +158,11 @@ int main(int argc, char** argv) {
             run_power<2, 0>("pk_fma only", w, card);
             run_power<9, 0>("scan pair mix (2 exp + 4 pk)", w, card);
         }
+        run_power<0, 0>("exp only", 4, card, true);
+        run_power<1, 0>("fma only", 4, card, true);
+        run_power<2, 0>("pk_fma only", 4, card, true);
+        run_power<7, 0>("pk_mul only", 4, card, true);
+        run_power<9, 0>("scan pair mix (2 exp + 4 pk)", 4, card, true);
         return 0;
     }
     for (int w : {1, 2, 4}) {
