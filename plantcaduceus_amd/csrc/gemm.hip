@@ -635,11 +635,9 @@ template <> struct MmaAcc<float> {
 // 64-bit scalar base + 32-bit lane offset + immediate.  The compiler does not know these are memory operations: every consumer
 // sits behind an explicit s_waitcnt (see the call sites).
 template <int OFF> __device__ __forceinline__ void gload_a128(f32x4& dst, uint32_t vo, const float* sb) {
-#ifdef PCAD_RES_NT
+    // nt: every residual element is read once and written once per launch (a 2 GiB tensor): the streaming hint keeps it from
+    // displacing the W tile and the A lines other CUs re-use (out_proj + residual 2.055 -> 2.015 ms in six interleaved pairs, r04k / r04l)
     asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3 nt" : "=a"(dst) : "v"(vo), "s"(sb), "n"(OFF));
-#else
-    asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=a"(dst) : "v"(vo), "s"(sb), "n"(OFF));
-#endif
 }
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 template <int OFF> __device__ __forceinline__ void gload_v32(float& dst, uint32_t vo, const float* sb) {
@@ -900,13 +898,8 @@ __global__ __launch_bounds__(GEMMQ_THREADS, 1) void gemm256q_kernel(const T* __r
                 asm volatile("" : "+v"(t0), "+v"(t1), "+v"(t2), "+v"(t3));
                 if constexpr (EPI == EPI_RES) {
                     float* rdst = res_tb + (i * 2 + jg) * 1024 + lane * 4;
-#ifdef PCAD_RES_NT
                     __builtin_nontemporal_store(t0, reinterpret_cast<f32x4*>(rdst));       __builtin_nontemporal_store(t1, reinterpret_cast<f32x4*>(rdst + 256));
                     __builtin_nontemporal_store(t2, reinterpret_cast<f32x4*>(rdst + 512)); __builtin_nontemporal_store(t3, reinterpret_cast<f32x4*>(rdst + 768));
-#else
-                    *reinterpret_cast<f32x4*>(rdst) = t0;       *reinterpret_cast<f32x4*>(rdst + 256) = t1;
-                    *reinterpret_cast<f32x4*>(rdst + 512) = t2; *reinterpret_cast<f32x4*>(rdst + 768) = t3;
-#endif
 #pragma unroll
                     for (int rr = 0; rr < 4; ++rr)
                         ss[i] = __builtin_fmaf(t0[rr], t0[rr], __builtin_fmaf(t1[rr], t1[rr], __builtin_fmaf(t2[rr], t2[rr], __builtin_fmaf(t3[rr], t3[rr], ss[i]))));
@@ -997,22 +990,6 @@ __global__ __launch_bounds__(GEMMQ_THREADS, 1) void gemm256q_kernel(const T* __r
         asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-#ifdef PCAD_RES_PREFETCH
-        if constexpr (EPI == EPI_RES) {
-            // last K-tile of the tile: pull the NEXT tile's residual (64 KiB per wave, fragment layout = contiguous) towards L2 with 8
-            // throw-away loads of one dword per 128-byte line, so that the tile-start loads into the accumulators are cache hits
-            // spread over this k-step instead of one HBM burst when every CU starts its next tile
-            if (kt + 1 == nkt && tile + gstride < nblk) {
-                int64_t nm0; int nn0;
-                tile_coords(tile + gstride, nm0, nn0);
-                const float* nb = res_tile_base(nm0, nn0);
-                const uint32_t pvo = (uint32_t)lane * 128u;
-                float dummy;
-                gload_v32<0>(dummy, pvo, nb);         gload_v32<0>(dummy, pvo, nb + 2048);  gload_v32<0>(dummy, pvo, nb + 4096);  gload_v32<0>(dummy, pvo, nb + 6144);
-                gload_v32<0>(dummy, pvo, nb + 8192);  gload_v32<0>(dummy, pvo, nb + 10240); gload_v32<0>(dummy, pvo, nb + 12288); gload_v32<0>(dummy, pvo, nb + 14336);
-            }
-        }
-#endif
         // k-step 1: MFMAs on (g, k-step 1); reads (g+1, k-step 0); DMAs W(g+2) into the W stage just freed
         kstep(fa1, fw1, fa0, fw0, sa_n, sw ^ 1, 0, false, sw, std::integral_constant<int, 0>{});
         w_advance();
@@ -1156,7 +1133,9 @@ hipError_t launch_gemm_nt_res(const void* A, int64_t lda, const void* W, int64_t
     // (Tried and removed, profiles/r04_ab_runs.txt r04d / r04e / r04g: delaying block b by ((b / 8) % 8) eighths of a tile so that an
     // eighth of the CUs is in its epilogue at a time - no effect with the fragment layout, 2.096 vs 2.097 ms.  Ablations: residual
     // loads from cache 1.94 ms, no write-back 1.90, neither 1.71 = the plain out_proj; i.e. the 4.3 GB of extra traffic costs
-    // 0.37 ms, about half of its HBM time, the rest is hidden behind the mainloops.)
+    // 0.37 ms, about half of its HBM time, the rest is hidden behind the mainloops.  Also removed: pulling the NEXT tile's residual
+    // towards L2 with 8 throw-away loads per wave during a tile's last K-tile (so that the tile-start loads hit) - out_proj + residual
+    // 2.05 -> 2.29 ms: the extra requests in the mainloop cost more than the tile-start latency they hide, r04l.)
     const GemmEpi epi{nullptr, res, ssq};
     if (dt == BF16) return launch_gemm256_t<bf16_t>(A, lda, W, ldw, C, N, M, N, K, s, a_blocked, nullptr, 0, false, EPI_RES, epi);
     return launch_gemm256_t<float>(A, lda, W, ldw, C, N, M, N, K, s, a_blocked, nullptr, 0, false, EPI_RES, epi);

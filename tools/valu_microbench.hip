@@ -110,9 +110,11 @@ static double read_sclk(const std::string& card) {
     return mhz;
 }
 
-// one_block_per_cu: 256 blocks of 256 * waves_per_simd threads, i.e. exactly one block per CU - the dispatcher cannot give one CU more
-// work than another, so wall time = every CU's time (with 256-thread blocks, 4 per CU on average, the spread of blocks over CUs is
-// uneven and the wall clock follows the fullest CU: that, not a lower clock, is where round 3's "1.5-1.6 GHz" came from)
+// one_block_per_cu: 256 blocks of 256 * waves_per_simd threads, i.e. exactly one block per CU - every CU has the same work.  It gives
+// the same wall-clock costs as four 256-thread blocks per CU (exp 8.6, fma 3.6, pk_fma 5.0, pk_mul 4.8, pair mix 34.2 cycles at the
+// 2.4 GHz the card reports), while the "s_memtime of wave 0 / wall" figure drops to 0.7-1.9 "GHz": with several waves per SIMD the
+// oldest wave wins the issue arbitration and finishes its iterations early, so its own cycle count is NOT the kernel's.  Round 3 read
+// that figure (1.5-1.6 at 4 waves per SIMD) as a throttled clock; the card's sclk says 2.38-2.40 GHz at 560-1040 W.
 template <int MODE, int NFMA>
 void run_power(const char* name, int waves_per_simd, const std::string& card, bool one_block_per_cu = false) {
     const bool big = one_block_per_cu && waves_per_simd == 4;
@@ -141,7 +143,7 @@ void run_power(const char* name, int waves_per_simd, const std::string& card, bo
     double pa = 0, pm = 0; size_t n0 = pw.size() / 4; for (size_t i = n0; i < pw.size(); ++i) { pa += pw[i]; if (pw[i] > pm) pm = pw[i]; }
     double ca = 0; size_t c0 = ck.size() / 4; for (size_t i = c0; i < ck.size(); ++i) ca += ck[i];
     const double groups = (double)iters * 8;
-    printf("%-28s waves/SIMD=%d%s  %.0f ms: %.2f SIMD-cycles@2.4GHz per group; effective clock %.2f GHz (s_memtime / wall); power %.0f W avg, "
+    printf("%-28s waves/SIMD=%d%s  %.0f ms: %.2f SIMD-cycles@2.4GHz per group; wave-0 s_memtime / wall %.2f GHz (a clock only at 1 wave per SIMD: the oldest wave is served first and finishes early); power %.0f W avg, "
            "%.0f max over %zu samples; sclk %.0f MHz avg\n", name, waves_per_simd, big ? " (1 block of 1024 per CU)" : "", ms, ms * 1e-3 * 2.4e9 / groups / waves_per_simd,
            avg / (ms * 1e-3) / 1e9, pw.size() > n0 ? pa / (pw.size() - n0) : -1.0, pm, pw.size(), ck.size() > c0 ? ca / (ck.size() - c0) : -1.0);
     hipFree(out); hipFree(cyc);
