@@ -38,13 +38,15 @@ if ROOT not in sys.path:
 
 PEAK = {"bf16": 2500.0, "f32": 157.3}     # dense MFMA TFLOP/s, MI355X_MICROARCH.md chip-level table
 PEAK_HBM = 8000.0                          # GB/s spec
-# SIMD time per wave-instruction at 4 waves/SIMD, expressed in cycles of the 2.4 GHz NOMINAL clock (wall time x 2.4e9), measured
-# with tools/valu_microbench.hip and committed as profiles/r03_valu_microbench.txt: v_exp_f32 8.48, v_pk_mul_f32 5.21,
-# v_pk_fma_f32 5.35, and the scan's own state-pair mix (2 v_exp_f32 + 2 v_pk_mul_f32 + 2 v_pk_fma_f32) 34.73 per pair.  These are
-# TIME costs: the dense-VALU microbenchmark itself runs at an effective 1.5-1.6 GHz (power-limited), so the same numbers in
-# real shader cycles are 5.7 / 3.3 / 3.5 — what bounds the scan is the energy of its instruction stream, not issue slots.
-CYC_EXP, CYC_PK = 8.48, 5.28
-CYC_PAIR_MIX = 34.73
+# SIMD cycles per wave-instruction at 4 waves/SIMD, measured with tools/valu_microbench.hip (wall time x 2.4 GHz; the card reports
+# 2.38-2.40 GHz at 560-1040 W during those runs: profiles/r04k_valu_power.txt): v_exp_f32 8.62, v_pk_mul_f32 4.80, v_pk_fma_f32 5.01,
+# v_fma_f32 3.63, and the scan's own state-pair mix (2 v_exp_f32 + 2 v_pk_mul_f32 + 2 v_pk_fma_f32) 34.16 per pair (a little less than
+# the sum of its parts, 36.86: the transcendental unit overlaps the packed pipe by ~7 %).  Round 3 took the cycle count of ONE wave
+# of each block divided by the wall time for an "effective clock" of 1.5-1.6 GHz and called these time costs: with several waves per
+# SIMD the oldest wave finishes early, so that ratio is not a clock (DESIGN.md §0 "What round 4 corrects").
+CYC_EXP, CYC_PK_MUL, CYC_PK_FMA = 8.62, 4.80, 5.01
+CYC_PK = 0.5 * (CYC_PK_MUL + CYC_PK_FMA)
+CYC_PAIR_MIX = 34.16
 SIMDS, CLOCK = 1024, 2.4e9
 
 
@@ -112,6 +114,7 @@ def algorithmic_work(cfg, rows, esz):
                                bytes=esz * (rows * E * 3.0 + rows * Rp) + 4 * rows * 2 * N,
                                bytes_8d=esz * rows * (1.5 * E + X),
                                valu_floor_cycles=rows * (E / 64.0) * (N / 2) * CYC_PAIR_MIX,
+                               valu_floor_cycles_sum=rows * (E / 64.0) * N * (CYC_EXP + CYC_PK_MUL + CYC_PK_FMA),
                                trans_cycles=rows * (E / 64.0) * N * CYC_EXP)
     # "norm_fold": out_proj + fp32 residual read-modify-write + rounded copy + row statistics in ONE launch (§8(d) shares: the
     # out_proj term LE + LD plus the add+norm term 4LD, of which the u read moves to in_proj's operand)
@@ -418,12 +421,16 @@ def main():
                     #   trans_floor_frac = the 16 v_exp_f32 alone
                     cyc = avg_s * SIMDS * CLOCK
                     res["roofline"]["valu_floor_frac"] = work[dom]["valu_floor_cycles"] / cyc
+                    res["roofline"]["valu_floor_frac_from_instruction_counts"] = work[dom]["valu_floor_cycles_sum"] / cyc
                     res["roofline"]["trans_floor_frac"] = work[dom]["trans_cycles"] / cyc
                     res["roofline"]["note"] = ("frac = SURVEY.md §8(d) share (1.5*E*s + (R+2N)*s bytes per row per direction launch) / "
                                                "launch time / 8 TB/s; the kernel is VALU/transcendental-bound, not HBM-bound: "
                                                "valu_floor_frac / trans_floor_frac give its distance from the arithmetic floor "
-                                               "(8 state pairs x %.2f nominal-2.4-GHz cycles for 2 v_exp_f32 + 4 packed ops, profiles/r03_valu_microbench.txt; "
-                                               "v_exp_f32 alone %.2f)" % (CYC_PAIR_MIX, CYC_EXP))
+                                               "(8 state pairs x %.2f cycles at 2.4 GHz for 2 v_exp_f32 + 4 packed ops measured as one mix, "
+                                               "profiles/r04k_valu_power.txt; ..._from_instruction_counts: the same 16 + 32 instructions priced one by "
+                                               "one, v_exp_f32 %.2f + v_pk_mul_f32 %.2f + v_pk_fma_f32 %.2f per state; the launch itself clocks at "
+                                               "~2.1 GHz with the board at 96 %% of its power cap, profiles/r04k_power_probe.txt)"
+                                               % (CYC_PAIR_MIX, CYC_EXP, CYC_PK_MUL, CYC_PK_FMA))
             res["roofline"]["rows_per_launch"] = rows
             # HBM traffic per launch from the PMC counters (separate rocprofv3 --pmc passes; summary committed under profiles/).
             # Only filled when the committed profile was measured on THIS build of the kernels (source hash match).
