@@ -173,7 +173,7 @@ int    pcad_forward_all_hidden(pcad_handle h, const int32_t* ids, int B, int L,
 enum pcad_kernel_class {
     PCAD_K_NORM = 0, PCAD_K_GEMM_IN, PCAD_K_CONV, PCAD_K_GEMM_X, PCAD_K_SCAN, PCAD_K_GEMM_OUT, PCAD_K_HEAD,
     PCAD_K_GEMM_OUT_RES,   /* "norm_fold": out_proj + residual add + row statistics in one launch */
-    PCAD_K_RSTD,           /* "norm_fold": layer-0 embedding + the per-layer reduction of the row statistics */
+    PCAD_K_RSTD,           /* "norm_fold": the per-layer reduction of the row statistics (the layer-0 embedding kernel counts as PCAD_K_NORM) */
     PCAD_NUM_KERNEL_CLASSES
 };
 typedef struct pcad_kernel_stat {

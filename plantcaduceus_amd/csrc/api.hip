@@ -483,7 +483,7 @@ static int forward_impl(pcad_handle h, const int32_t* ids, int B, int L, const i
         const int32_t* ids_c = ids + (int64_t)c.b0 * L;
         if (c.fold) {
             if (li == 0) {      // res = Emb[token] (fp32, fragment layout), u = the same rows in the model dtype (plain), rstd
-                ProfScope ps(e, PCAD_K_RSTD, s);
+                ProfScope ps(e, PCAD_K_NORM, s);
                 HIP_TRY(launch_embed_rmsnorm(ids_c, e->emb, e->comp, W.norm_w, c.w.u, c.w.res, c.Bc, L, D, eps, dt, rdt, s, c.w.rstd));
             }
             return PCAD_OK;     // later layers: the previous out_proj's epilogue already produced res, round(res) and rstd
