@@ -206,6 +206,17 @@ def test_bench_work_formulas_match_survey_8d():
                     + 2 * 2.0 * rows * cfg.dt_rank * cfg.d_inner)
         assert abs(fl_layer * cfg.n_layer / f - 1) < 1e-9
     assert len(bench.source_hash()) == 16
+    # the norm-folded out_proj carries the add+norm's share of §8(d) (minus the u read, which moves into in_proj's operand count):
+    # folded layer = reference-order layer in algorithmic bytes
+    cfg = make_config("l32")
+    w = bench.algorithmic_work(cfg, 1024, 2)
+    assert w["gemm_out_proj_res"]["bytes_8d"] == w["gemm_out_proj"]["bytes_8d"] + w["add_rmsnorm"]["bytes_8d"]
+    assert w["gemm_out_proj_res"]["flops"] == w["gemm_out_proj"]["flops"]
+    # what the last-layer shortcut does not execute at the benchmark's position (255 of 512: both walks stop after 264 steps)
+    fl_skip, scan_skip = bench.executed_fraction_last_layer(cfg, 512, 255, True)
+    f, _ = bench.per_sequence_work(cfg, 512, 2)
+    assert abs(scan_skip - (1 - 264 / 512)) < 1e-12 and 0.009 < fl_skip / f < 0.013
+    assert bench.executed_fraction_last_layer(cfg, 512, 255, False) == (0.0, 0.0)
 
 
 def test_effective_batch_keeps_an_explicit_batch_size():
