@@ -10,6 +10,9 @@ from plantcaduceus_amd.modeling_caduceus import CaduceusForMaskedLM
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+# "fold" as a third argument: geometries on which the norm-folded layer form engages (d_model % 256 == 0, 2 B L % 256 == 0), the
+# option forced on for both dtypes - tile counts from 1 to a few hundred, fewer tiles than CUs, 1..4 layers
+FOLD = len(sys.argv) > 3 and sys.argv[3] == "fold"
 bad = 0
 t0 = time.time()
 for case in range(n):
@@ -17,12 +20,19 @@ for case in range(n):
     nl = int(rng.integers(1, 4))
     B = int(rng.integers(1, 6))
     L = int(rng.choice([1, 2, 3, 5, 7, 8, 9, 15, 16, 17, 31, 33, 63, 64, 65, 100, 127, 128, 129, 200, 255, 257, 300]))
+    if FOLD:
+        D = int(rng.choice([256, 512, 768, 1024]))
+        nl = int(rng.integers(1, 5))
+        L = int(rng.choice([32, 64, 128, 256, 384, 512, 640]))
+        B = int(rng.integers(1, 9)) * (128 // np.gcd(128, L))            # 2 B L a multiple of 256
     bf16 = bool(rng.integers(0, 2))
     ssm = dict(d_state=16, d_conv=4, expand=2, dt_rank=int(rng.choice([D // 16, max(1, D // 16 - 1), min(64, D // 16 + 3), 80, 96, 70])), bias=False, conv_bias=True)
     cfg = make_config("x", d_model=D, n_layer=nl, ssm_cfg=ssm)
     sd = synthetic_state_dict(cfg, seed=int(rng.integers(0, 1 << 30)), stress=True)
     ids = torch.from_numpy(rng.integers(0, 8, size=(B, L)))          # every token id incl. PAD / MASK / UNK / the pad row
     dt = torch.bfloat16 if bf16 else torch.float32
+    if FOLD:
+        cfg.engine_options = {"norm_fold": 1}
     m = CaduceusForMaskedLM(cfg); m.load_state_dict(sd, strict=False); m.tie_weights(); m = m.to(dt).to("cuda:0")
     out = m(input_ids=ids.to("cuda:0"), output_hidden_states=True)
     lg, hid = out.logits.cpu(), out.hidden_states[-1].float().cpu()
