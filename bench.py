@@ -394,7 +394,8 @@ def main():
             nl = cfg.n_layer
             full_out = nl - 1 if shortcut else nl                # full-size out_proj launches per chunk (the shortcut's is a 2B-row GEMM)
             folded = "gemm_out_proj_res" in kern
-            per_chunk = {"add_rmsnorm": 1 if folded else nl, "rstd_reduce": nl - 1 if folded else 0, "gemm_in_proj": nl, "conv1d_bidir": nl,
+            # folded: layer 0 = the embedding kernel + the table gather of its in_proj output (both counted as add_rmsnorm), no GEMM
+            per_chunk = {"add_rmsnorm": 2 if folded else nl, "rstd_reduce": nl - 1 if folded else 0, "gemm_in_proj": nl - 1 if folded else nl, "conv1d_bidir": nl,
                          "conv_xproj_fused": nl, "gemm_x_proj": 2 * nl, "selective_scan": 2 * nl,
                          "gemm_out_proj": (0 if shortcut else 1) if folded else full_out,
                          "gemm_out_proj_res": nl - 1 if folded else 0, "final_head": 0}     # launches per chunk

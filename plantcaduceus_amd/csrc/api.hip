@@ -78,6 +78,7 @@ struct pcad_engine {
     bool bound = false;
     int32_t* status = nullptr;   // caller-owned device word for asynchronous input-validation flags (pcad_set_status_buffer)
     std::vector<LayerWeights> layers;
+    void* xz_tab0 = nullptr;    // [V, 2E] dtype: layer 0's in_proj output per token id (norm-folded form), built at bind time
     void* emb = nullptr;        // [V, D] dtype
     float* emb_f32 = nullptr;   // [V, D] fp32 copy of the dtype-rounded table
     float* normf_w = nullptr;
@@ -112,6 +113,7 @@ void carve_weights(pcad_engine* e, Carver& c) {
     e->emb_f32 = (float*)c.take(V * D * 4);
     e->normf_w = (float*)c.take(D * 4);
     e->comp = (int32_t*)c.take(8 * 4);
+    e->xz_tab0 = c.take(V * 2 * E * esz);
     e->layers.resize(e->nl);
     for (auto& L : e->layers) {
         L.norm_w = (float*)c.take(D * 4);
@@ -388,6 +390,8 @@ int pcad_bind_weights(pcad_handle h, const pcad_tensor* tensors, int n, void* ar
             HIP_TRY(launch_pack_convw(L.dir[0].conv_w, L.dir[0].conv_b, L.dir[1].conv_w, L.dir[1].conv_b, L.convw, E, dt, s));
     }
 #undef NEED
+    // layer 0's in_proj (norm-folded form) as a table over the V token ids: emb and layer 0's folded in_proj weight are packed above
+    HIP_TRY(launch_embed_inproj_table(e->emb, e->layers[0].W_in_f, e->xz_tab0, V, D, 2 * E, e->cfg.eps, dt, s));
     e->bound = true;
     return PCAD_OK;
 }
@@ -449,7 +453,7 @@ static int forward_impl(pcad_handle h, const int32_t* ids, int B, int L, const i
     // value no kernel of THIS forward produced turns the outputs into NaN instead of silently reusing the previous call's data
     if (e->poison) HIP_TRY(hipMemsetAsync(workspace, 0xFF, need, cs));
 
-    // Norm-folded layer form (default; pcad_set_option("norm_fold", 0) restores the reference's order).  The reference's block is
+    // Norm-folded layer form (pcad_set_option("norm_fold", 0) restores the reference's order).  The reference's block is
     //     res = h + res (fp32);  u = round(res * rstd(res) * w_norm);  xz = round(u . W_in^T);  ...;  h = round(y . W_out^T)
     // (rms_norm_fn(..., prenorm=True, residual_in_fp32=True)).  Folded: out_proj's epilogue does
     // res += y . W_out^T in fp32 (the accumulators start as the residual values), writes round(res) and per-row partial sums of
@@ -475,6 +479,7 @@ static int forward_impl(pcad_handle h, const int32_t* ids, int B, int L, const i
     // board power and clocks.  Only launches that are idempotent are repeated (in_proj, conv + x_proj, the forward-direction scan,
     // the reference-order out_proj); outputs are unchanged.
     auto reps = [&](int cls) -> int { return e->rep_class == cls ? e->rep_count : 1; };
+    static const bool tab0 = dev_env("PCAD_NO_TAB0") == nullptr;     // layer 0's in_proj as a table look-up (phase_P); PCAD_DEV=1 A/B switch
     auto phase_N = [&](Lane& c, int li) -> int {        // residual add + norm (layer 0: RCPS embedding + norm)
         hipStream_t s = cs;
         const LayerWeights& W = e->layers[li];
@@ -482,9 +487,9 @@ static int forward_impl(pcad_handle h, const int32_t* ids, int B, int L, const i
         const int64_t rows = (int64_t)S * L;
         const int32_t* ids_c = ids + (int64_t)c.b0 * L;
         if (c.fold) {
-            if (li == 0) {      // res = Emb[token] (fp32, fragment layout), u = the same rows in the model dtype (plain), rstd
+            if (li == 0) {      // res = Emb[token] (fp32, fragment layout) [+ u = the same rows in the model dtype and rstd when layer 0's in_proj runs as a GEMM]
                 ProfScope ps(e, PCAD_K_NORM, s);
-                HIP_TRY(launch_embed_rmsnorm(ids_c, e->emb, e->comp, W.norm_w, c.w.u, c.w.res, c.Bc, L, D, eps, dt, rdt, s, c.w.rstd));
+                HIP_TRY(launch_embed_rmsnorm(ids_c, e->emb, e->comp, W.norm_w, tab0 ? nullptr : c.w.u, c.w.res, c.Bc, L, D, eps, dt, rdt, s, c.w.rstd));
             }
             return PCAD_OK;     // later layers: the previous out_proj's epilogue already produced res, round(res) and rstd
         }
@@ -507,6 +512,12 @@ static int forward_impl(pcad_handle h, const int32_t* ids, int B, int L, const i
         const int S = 2 * c.Bc;
         const int64_t rows = (int64_t)S * L;
         // in_proj (tied between directions: once per strand)
+        // Layer 0 of the norm-folded form: the operand rows are the V = 8 embedding rows themselves, so in_proj's output is a look-up
+        // (table built at bind time): one copy kernel instead of 1 / n_layer of the in_proj GEMMs.  PCAD_DEV=1 PCAD_NO_TAB0=1: the GEMM.
+        if (c.fold && li == 0 && tab0) {
+            ProfScope ps(e, PCAD_K_NORM, s);
+            HIP_TRY(launch_embed_xz_gather(ids + (int64_t)c.b0 * L, e->comp, e->xz_tab0, c.w.xz, c.w.zb, c.Bc, L, E, dt, s));
+        } else
         for (int rep = 0; rep < reps(PCAD_K_GEMM_IN); ++rep)
         { ProfScope ps(e, PCAD_K_GEMM_IN, s);
         if (c.fold) HIP_TRY(launch_gemm_nt_two(c.w.u, D, W.W_in_f, D, c.w.xz, c.w.zb, E, true, rows, 2 * E, D, dt, s, c.w.rstd));

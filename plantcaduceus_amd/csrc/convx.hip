@@ -13,7 +13,8 @@
 //     result rounded to the model dtype and written into conv stage it & 1 in the MFMA A-fragment image (XOR swizzle);
 //   * MFMA of K-tile it-1 (matrix pipe): wave = 32 rows, x_dbl += c . Wx^T from conv stage (it-1) & 1, accumulators stay
 //     in registers across K-tiles; the same waves copy that conv stage to the blocked xc tensors the scan reads (1 KiB
-//     contiguous per store instruction).
+//     contiguous per store instruction).  The causal waves convolve first and multiply / copy second, the anti-causal waves the
+//     other way round (the two waves of a SIMD are one of each).
 // Epilogue: dt_low [rows, 64] (model dtype) and B_t | C_t [rows, 32] (fp32) per direction, as the split-epilogue GEMM wrote.
 // HBM traffic per row: read E*s (x) + write 2*E*s (xc) instead of read 3*E*s + write 2*E*s, and one launch instead of three.
 // Measured: instruction-issue bound (VALU busy 44 %, ~500 wave-instructions per K-tile of which the conv
@@ -268,7 +269,11 @@ __global__ __launch_bounds__(CX_THREADS, 2) void convx_kernel(const T* __restric
         constexpr bool REVC = decltype(rev_tag)::value;       // static window indices (no dynamic register indexing)
         const char* raw = smem + par * CX_RAW_BYTES;
         const float* cw = reinterpret_cast<const float*>(smem + CX_OFF_CW + par * CX_CW_BYTES) + (REVC ? 5 * KC : 0) + c8 * CPC;
-        if (with_mfma) mfma_half(1 - par, 0);
+        // phase-shifted directions (round 4, -1.5 % in 3 of 3 interleaved pairs, r04u): the anti-causal waves run the MFMAs + copy-out of
+        // K-tile it-1 first and convolve K-tile it second, the causal waves the other way round, so that on every SIMD (one wave of each
+        // direction) one wave's VALU phase faces the other's LDS / MFMA / store phase.  (Before: both interleaved MFMA half 0, conv
+        // half 0, MFMA half 1, conv half 1, copy-out in the same order.)
+        if (with_mfma && REVC) { mfma_half(1 - par, 0); mfma_half(1 - par, 1); copy_out(kt - 1, 1 - par); }
         char* ct = smem + CX_OFF_C + par * 2 * CX_TILE_BYTES + (REVC ? CX_TILE_BYTES : 0);
         const f32x2_t nl2e = {-kLog2e, -kLog2e}, one = {1.0f, 1.0f};
         // The 16-byte chunk is convolved in two halves of HC channels (8-byte LDS accesses: same LDS cycles, half the live
@@ -337,9 +342,8 @@ __global__ __launch_bounds__(CX_THREADS, 2) void convx_kernel(const T* __restric
         };
         conv_half(0);
         __builtin_amdgcn_sched_barrier(0);
-        if (with_mfma) mfma_half(1 - par, 1);
         conv_half(1);
-        if (with_mfma) copy_out(kt - 1, 1 - par);
+        if (with_mfma && !REVC) { __builtin_amdgcn_sched_barrier(0); mfma_half(1 - par, 0); mfma_half(1 - par, 1); copy_out(kt - 1, 1 - par); }
     };
 
     // prologue: taps(0), raw(0)

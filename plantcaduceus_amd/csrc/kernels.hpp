@@ -154,6 +154,12 @@ hipError_t launch_pack2d(const void* src, int src_dt, int64_t src_ld, void* dst,
 // dst[r, c] (dst_dt) = src[r, c] * scale[c]: in_proj weight with the RMSNorm weight folded into its columns (norm-folded form)
 hipError_t launch_pack_scale_cols(const void* src, int src_dt, int64_t src_ld, const float* scale, void* dst, int dst_dt,
                                   int64_t dst_ld, int rows, int cols, hipStream_t s);
+// Layer 0 of the norm-folded form.  Its in_proj operand is one of the V embedding rows, so its output is one of V rows:
+//   tab [V, N2] (dtype dt) = round((emb [V, D] . Wf [N2, D]^T) * rstd(emb row))                 (bind time)
+//   x, z [2 B L, E] blocked = rows of tab gathered by token (rc strand by index arithmetic)    (instead of the layer-0 in_proj launch)
+hipError_t launch_embed_inproj_table(const void* emb, const void* Wf, void* tab, int V, int D, int N2, float eps, int dt, hipStream_t s);
+hipError_t launch_embed_xz_gather(const int32_t* ids, const int32_t* comp8, const void* tab, void* x, void* z, int B, int L, int E, int dt,
+                                  hipStream_t s);
 // A2[e, n] = -exp(A_log[e, n]) * log2(e)   (A_log read through its storage dtype)
 hipError_t launch_pack_A(const void* A_log, int src_dt, float* A2, int64_t n, float scale, hipStream_t s);
 

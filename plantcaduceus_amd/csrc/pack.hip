@@ -76,6 +76,67 @@ hipError_t launch_pack_scale_cols(const void* src, int src_dt, int64_t src_ld, c
     return hipGetLastError();
 }
 
+// ---- layer 0 of the norm-folded form: in_proj's operand is one of the V embedding rows, so its output is one of V rows ------------
+//   tab[tok][n] = round( (sum_k emb[tok][k] * Wf[n][k]) * rstd(emb[tok]) ),   rstd = rsqrt(mean_k emb[tok][k]^2 + eps)
+// (bind time; fp32 sums in index order; emb and Wf already in the model dtype)
+template <typename T>
+__global__ __launch_bounds__(256) void embed_inproj_table_kernel(const T* __restrict__ emb, const T* __restrict__ Wf, T* __restrict__ tab,
+                                                                 int D, int N2, float eps) {
+    const int n = blockIdx.x * 256 + threadIdx.x, tok = blockIdx.y;
+    if (n >= N2) return;
+    const T* er = emb + (int64_t)tok * D;
+    const T* wr = Wf + (int64_t)n * D;
+    float acc = 0.f, ss = 0.f;
+    for (int k = 0; k < D; ++k) {
+        const float ev = Elem<T>::load(er + k);
+        acc = __builtin_fmaf(ev, Elem<T>::load(wr + k), acc);
+        ss = __builtin_fmaf(ev, ev, ss);
+    }
+    Elem<T>::store(tab + (int64_t)tok * N2 + n, acc * rsqrtf(ss / (float)D + eps));
+}
+
+hipError_t launch_embed_inproj_table(const void* emb, const void* Wf, void* tab, int V, int D, int N2, float eps, int dt, hipStream_t s) {
+    dim3 grid((unsigned)((N2 + 255) / 256), (unsigned)V), block(256);
+    if (dt == BF16) hipLaunchKernelGGL(embed_inproj_table_kernel<bf16_t>, grid, block, 0, s, (const bf16_t*)emb, (const bf16_t*)Wf, (bf16_t*)tab, D, N2, eps);
+    else hipLaunchKernelGGL(embed_inproj_table_kernel<float>, grid, block, 0, s, (const float*)emb, (const float*)Wf, (float*)tab, D, N2, eps);
+    return hipGetLastError();
+}
+
+// x / z of layer 0 (both blocked [rows8, E]) gathered from the table: row (strand s, position t) copies tab[token(s, t)][0, E) to x
+// and [E, 2E) to z; the rc strand's token is the complement of the reversed ids (RCPSEmbedding by index arithmetic, as in norm.hip).
+// One wave per row, 16-byte accesses; E * elem a multiple of 128 bytes.
+template <typename T>
+__global__ __launch_bounds__(256) void embed_xz_gather_kernel(const int32_t* __restrict__ ids, const int32_t* __restrict__ comp8,
+                                                              const T* __restrict__ tab, T* __restrict__ x, T* __restrict__ z, int B, int L, int E) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= (int64_t)2 * B * L) return;
+    const int s = (int)(row / L), t = (int)(row - (int64_t)s * L);
+    int tok;
+    if (s < B) tok = ids[(int64_t)s * L + t];
+    else tok = comp8[ids[(int64_t)(s - B) * L + (L - 1 - t)] & 7];
+    const char* src = reinterpret_cast<const char*>(tab + (int64_t)(tok & 7) * 2 * E);
+    const int64_t rowb = (int64_t)E * sizeof(T), pieces = rowb >> 7;
+    char* xb = reinterpret_cast<char*>(x);
+    char* zb = reinterpret_cast<char*>(z);
+    for (int64_t cb = (int64_t)lane * 16; cb < rowb; cb += 64 * 16) {
+        const int64_t o = blocked_off(row, cb, pieces);
+        *reinterpret_cast<u32x4*>(xb + o) = *reinterpret_cast<const u32x4*>(src + cb);
+        *reinterpret_cast<u32x4*>(zb + o) = *reinterpret_cast<const u32x4*>(src + rowb + cb);
+    }
+}
+
+hipError_t launch_embed_xz_gather(const int32_t* ids, const int32_t* comp8, const void* tab, void* x, void* z, int B, int L, int E, int dt,
+                                  hipStream_t s) {
+    const int64_t rows = (int64_t)2 * B * L;
+    if (rows <= 0) return hipSuccess;
+    if ((E * (dt == BF16 ? 2 : 4)) % 128) return hipErrorInvalidValue;
+    dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+    if (dt == BF16) hipLaunchKernelGGL(embed_xz_gather_kernel<bf16_t>, grid, block, 0, s, ids, comp8, (const bf16_t*)tab, (bf16_t*)x, (bf16_t*)z, B, L, E);
+    else hipLaunchKernelGGL(embed_xz_gather_kernel<float>, grid, block, 0, s, ids, comp8, (const float*)tab, (float*)x, (float*)z, B, L, E);
+    return hipGetLastError();
+}
+
 hipError_t launch_pack_A(const void* A_log, int src_dt, float* A2, int64_t n, float scale, hipStream_t s) {
     if (n <= 0) return hipSuccess;
     dim3 grid((unsigned)((n + 255) / 256)), block(256);

@@ -54,7 +54,8 @@ def test_norm_fold_fp32_matches_oracle(D, nl, B, L):
     ref = O.forward_strands(ids, O.params_from_state_dict(sd, cfg))
     m = build(cfg, sd, torch.float32, norm_fold=1)
     out, n = folded_launches(m, ids.to(DEV), output_hidden_states=True)
-    assert n["gemm_out_proj_res"] == nl - 1 and n["add_rmsnorm"] == 1 and n["rstd_reduce"] == nl - 1, n     # add_rmsnorm: the layer-0 embedding kernel
+    # add_rmsnorm: the layer-0 embedding kernel + the table gather that replaces layer 0's in_proj
+    assert n["gemm_out_proj_res"] == nl - 1 and n["add_rmsnorm"] == 2 and n["rstd_reduce"] == nl - 1 and n["gemm_in_proj"] == nl - 1, n
     lg, hid = out.logits.cpu(), out.hidden_states[-1].cpu()
     scale = ref["logits"].abs().max()
     e_l = ((lg - ref["logits"]).abs().max() / scale).item()
@@ -92,7 +93,7 @@ def test_norm_fold_falls_back_on_partial_tiles_and_all_hidden():
     _, n_def = folded_launches(build(cfg, sd, torch.bfloat16), ids)
     _, n_off = folded_launches(build(cfg, sd, torch.bfloat16, norm_fold=0), ids)
     _, n_f32 = folded_launches(build(cfg, sd, torch.float32), ids)
-    assert n_def["gemm_out_proj_res"] == 2 and n_def["add_rmsnorm"] == 1 and n_off["gemm_out_proj_res"] == 0 and n_off["add_rmsnorm"] == 3
+    assert n_def["gemm_out_proj_res"] == 2 and n_def["add_rmsnorm"] == 2 and n_off["gemm_out_proj_res"] == 0 and n_off["add_rmsnorm"] == 3
     assert n_f32["gemm_out_proj_res"] == 0 and n_f32["add_rmsnorm"] == 3
     cfg.materialize_all_hidden_states = True
     a = build(cfg, sd, torch.bfloat16, norm_fold=1)(input_ids=ids, output_hidden_states=True).hidden_states
