@@ -46,7 +46,9 @@ def folded_launches(m, ids, **kw):
 
 
 # rows = 2 * B * L must be whole 256-row tiles and d_model % 256 == 0 for the folded form to engage
-@pytest.mark.parametrize("D,nl,B,L", [(256, 3, 2, 64), (512, 2, 1, 128), (256, 4, 3, 128), (1024, 2, 1, 512), (768, 2, 2, 192)])
+# (256, 2, 32, 100): whole tiles with a window length that is not a multiple of 8 (masked conv halo, generic scan addressing)
+@pytest.mark.parametrize("D,nl,B,L", [(256, 3, 2, 64), (512, 2, 1, 128), (256, 4, 3, 128), (1024, 2, 1, 512), (768, 2, 2, 192),
+                                      (256, 2, 32, 100)])
 def test_norm_fold_fp32_matches_oracle(D, nl, B, L):
     cfg = make_config("x", d_model=D, n_layer=nl)
     sd = synthetic_state_dict(cfg, seed=D + nl, stress=True)          # non-unit norm weights: the W_in fold is exercised
