@@ -101,7 +101,8 @@ void   pcad_destroy(pcad_handle h);
  *                 when the weights are bound) and multiplies by the row's rstd before it rounds.  Same value in exact arithmetic
  *                 as rms_norm_fn(prenorm=True, residual_in_fp32=True); rounding points move (the mixer output is not rounded
  *                 before it is added; in_proj's operand is round(res) instead of round(res * rstd * w)).  Used for chunks whose
- *                 GEMMs are whole 256 x 256 tiles (d_model % 256 == 0, token-rows % 256 == 0) with an fp32 residual stream,
+ *                 token-rows are whole 256-row tiles (a d_model that is not a multiple of 256 - PlantCaduceus_l20's 384 - is padded
+ *                 to the next one inside the workspace) with an fp32 residual stream,
  *                 never by pcad_forward_all_hidden (+4.5 % end to end, same-box A/B, profiles/r04_ab_runs.txt);
  *                 0 (default for the fp32 model, whose 1e-4 parity budget would pay for accumulating onto the residual: 2.2e-5 of
  *                 max after 32 layers instead of 1.3e-6): the reference's operation order (one add + RMSNorm launch per block).

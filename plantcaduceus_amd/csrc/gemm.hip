@@ -1116,11 +1116,12 @@ hipError_t launch_gemm_nt_two(const void* A, int64_t lda, const void* W, int64_t
 
 bool gemm_fold_shapes_ok(int64_t M, int D, int E, int dt) {
     const int64_t esz = dt == BF16 ? 2 : 4;
-    // in_proj [M, D] x [2E, D]^T (two blocked outputs), out_proj [M, E] x [D, E]^T; the fp32 residual [M, D] and the lane
-    // offsets of its accesses stay below 2^32 bytes
-    const bool in_ok = dt == BF16 ? quad_ok<bf16_t>(D, D, M, 2 * E, true, E) : quad_ok<float>(D, D, M, 2 * E, true, E);
-    const bool out_ok = dt == BF16 ? quad_ok<bf16_t>(E, E, M, D, false, 0) : quad_ok<float>(E, E, M, D, false, 0);
-    return in_ok && out_ok && (D * esz) % ROWB == 0 && (E * esz) % ROWB == 0 && D % 128 == 0 && (int64_t)16 * D * 4 < ((int64_t)1 << 31);
+    const int Dp = fold_padded_width(D);
+    // in_proj [M, D (rows Dp apart)] x [2E, D]^T (two blocked outputs), out_proj [M, E] x [Dp, E]^T (weight rows past D are zero);
+    // every tensor below 2^32 bytes
+    const bool in_ok = dt == BF16 ? quad_ok<bf16_t>(Dp, D, M, 2 * E, true, E) : quad_ok<float>(Dp, D, M, 2 * E, true, E);
+    const bool out_ok = dt == BF16 ? quad_ok<bf16_t>(E, E, M, Dp, false, 0) : quad_ok<float>(E, E, M, Dp, false, 0);
+    return in_ok && out_ok && (D * esz) % ROWB == 0 && (E * esz) % ROWB == 0 && M * (int64_t)Dp * 4 < ((int64_t)1 << 32);
 }
 
 hipError_t launch_gemm_nt_res(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, float* res, float* ssq, int64_t M,

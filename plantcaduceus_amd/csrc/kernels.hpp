@@ -32,10 +32,11 @@ hipError_t launch_add_rmsnorm(const void* x, const void* res_in, const float* w,
                               int64_t rows, int D, float eps, int dt, int rdt, hipStream_t s);
 // layer-0 variant: x = Emb[strand token] gathered on the fly (RCPS strands by index arithmetic).
 // rstd_out != nullptr: the norm-folded form - y (may be nullptr) = the un-normalised embedding row, rstd_out[row] = its rstd, and
-// res_out (fp32) is written in the 4-wave GEMM's fragment layout (common.hpp res_frag_off; 2 B L % 256 == 0, D % 256 == 0).
+// res_out (fp32) is written in the 4-wave GEMM's fragment layout (common.hpp res_frag_off; 2 B L % 256 == 0) as a tensor of
+// Dp = round_up(D, 256) columns whose padding columns are zeroed; y rows are Dp elements apart.
 hipError_t launch_embed_rmsnorm(const int32_t* ids, const void* emb, const int32_t* comp8, const float* w,
                                 void* y, void* res_out, int B, int L, int D, float eps, int dt, int rdt,
-                                hipStream_t s, float* rstd_out = nullptr);
+                                hipStream_t s, float* rstd_out = nullptr, int Dp = 0);    // Dp: padded width of res / y rows (0: D)
 // rstd[row] = rsqrt(sum of the np partial sums of squares of the row / D + eps)
 hipError_t launch_rstd(const float* ssq, float* rstd, int64_t rows, int np, int D, float eps, hipStream_t s);
 // final add + norm_f + RC re-assembly + tied RCPS LM head, only at the requested positions (a shared list `pos`,
@@ -46,7 +47,7 @@ hipError_t launch_final_head(const void* h, const void* res, const float* w, con
                              const float* emb_f32, const int32_t* comp8, void* hidden_out, float* logits_out,
                              int B, int L, int D, float eps, Positions pos, const int32_t* pos_per_seq, int dt, int rdt,
                              hipStream_t s, bool h_compact = false, const int32_t* ids = nullptr, int32_t* status = nullptr,
-                             bool res_frag = false);       // res_frag: fp32 residual in the fragment layout (common.hpp res_frag_off)
+                             int res_frag = 0);            // res_frag != 0: fp32 residual in the fragment layout (common.hpp res_frag_off) of that (padded) width
 // hidden_states[i] (block input = previous mixer output / embedding) assembled in RCPS layout.
 hipError_t launch_assemble_hidden(const void* h, void* out, int B, int L, int D, int dt, hipStream_t s);
 hipError_t launch_embed_only(const int32_t* ids, const void* emb, const int32_t* comp8, void* h, int B, int L,
@@ -79,6 +80,7 @@ hipError_t launch_gemm_nt_res(const void* A, int64_t lda, const void* W, int64_t
                               int N, int K, int dt, hipStream_t s, bool a_blocked);
 // whether a chunk of M token-rows of a (D, E) model can run the folded form (whole 256 x 256 tiles for both projections)
 bool gemm_fold_shapes_ok(int64_t M, int D, int E, int dt);
+inline int fold_padded_width(int D) { return (D + 255) / 256 * 256; }     // width of res / u in the folded form (l20: 384 -> 512)
 
 // conv.hip --------------------------------------------------------------------------------------
 // out_blocked: yf / yr in the blocked layout (common.hpp::blocked_off), buffers padded to a multiple of 8 rows.

@@ -22,7 +22,7 @@ __global__ __launch_bounds__(256) void add_rmsnorm_kernel(const T* __restrict__ 
                                                           RT* __restrict__ res_out, int64_t rows, int D, float eps,
                                                           const int32_t* __restrict__ ids,
                                                           const int32_t* __restrict__ comp8, int B, int L,
-                                                          float* __restrict__ rstd_out = nullptr) {
+                                                          float* __restrict__ rstd_out = nullptr, int Dp = 0) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -53,12 +53,21 @@ __global__ __launch_bounds__(256) void add_rmsnorm_kernel(const T* __restrict__ 
 #pragma unroll
             for (int i = 0; i < 8; ++i) ss += v[j][i] * v[j][i];
             if constexpr (FOLD) {          // the fp32 residual stream in the 4-wave GEMM's fragment layout: 8 columns = two quads
-                const int64_t o = res_frag_off(row, c * 8, D);
+                const int64_t o = res_frag_off(row, c * 8, Dp);
                 float* ro = reinterpret_cast<float*>(res_out);
                 *reinterpret_cast<f32x4*>(ro + o) = f32x4{v[j][0], v[j][1], v[j][2], v[j][3]};
                 *reinterpret_cast<f32x4*>(ro + o + 256) = f32x4{v[j][4], v[j][5], v[j][6], v[j][7]};
             } else if (res_out != nullptr) {
                 store8<RT>(res_out + row * D + c * 8, v[j]);
+            }
+        } else if constexpr (FOLD) {
+            // d_model that is not a multiple of 256 (l20: 384): the residual tensor is Dp = round_up(D, 256) columns wide (the folded
+            // out_proj runs whole 256-column tiles against zero weight rows); its padding columns must start as zeros
+            if (c < (Dp >> 3)) {
+                const int64_t o = res_frag_off(row, c * 8, Dp);
+                float* ro = reinterpret_cast<float*>(res_out);
+                *reinterpret_cast<f32x4*>(ro + o) = f32x4{0.f, 0.f, 0.f, 0.f};
+                *reinterpret_cast<f32x4*>(ro + o + 256) = f32x4{0.f, 0.f, 0.f, 0.f};
             }
         }
     }
@@ -69,7 +78,7 @@ __global__ __launch_bounds__(256) void add_rmsnorm_kernel(const T* __restrict__ 
 #pragma unroll
         for (int j = 0; j < MAXC; ++j) {
             const int c = lane + 64 * j;
-            if (y != nullptr && c < nchunk) store8<T>(y + row * D + c * 8, v[j]);
+            if (y != nullptr && c < nchunk) store8<T>(y + row * Dp + c * 8, v[j]);       // u: rows of Dp elements (padding never read)
         }
         return;
     }
@@ -115,17 +124,17 @@ hipError_t launch_rstd(const float* ssq, float* rstd, int64_t rows, int np, int 
 template <typename T, typename RT, bool EMBED>
 static hipError_t launch_norm_t(const T* x, const RT* res_in, const float* w, T* y, RT* res_out, int64_t rows, int D,
                                 float eps, const int32_t* ids, const int32_t* comp8, int B, int L, hipStream_t s,
-                                float* rstd_out = nullptr) {
+                                float* rstd_out = nullptr, int Dp = 0) {
     if (rows <= 0) return hipSuccess;
     dim3 grid((unsigned)((rows + 3) / 4)), block(256);
     if constexpr (EMBED) {
         if (rstd_out != nullptr) {            // layer 0 of the norm-folded form
             if (D <= 512)
-                hipLaunchKernelGGL((add_rmsnorm_kernel<T, RT, 1, true, true>), grid, block, 0, s, x, res_in, w, y, res_out, rows, D, eps, ids, comp8, B, L, rstd_out);
+                hipLaunchKernelGGL((add_rmsnorm_kernel<T, RT, 1, true, true>), grid, block, 0, s, x, res_in, w, y, res_out, rows, D, eps, ids, comp8, B, L, rstd_out, Dp);
             else if (D <= 1024)
-                hipLaunchKernelGGL((add_rmsnorm_kernel<T, RT, 2, true, true>), grid, block, 0, s, x, res_in, w, y, res_out, rows, D, eps, ids, comp8, B, L, rstd_out);
+                hipLaunchKernelGGL((add_rmsnorm_kernel<T, RT, 2, true, true>), grid, block, 0, s, x, res_in, w, y, res_out, rows, D, eps, ids, comp8, B, L, rstd_out, Dp);
             else
-                hipLaunchKernelGGL((add_rmsnorm_kernel<T, RT, 4, true, true>), grid, block, 0, s, x, res_in, w, y, res_out, rows, D, eps, ids, comp8, B, L, rstd_out);
+                hipLaunchKernelGGL((add_rmsnorm_kernel<T, RT, 4, true, true>), grid, block, 0, s, x, res_in, w, y, res_out, rows, D, eps, ids, comp8, B, L, rstd_out, Dp);
             return hipGetLastError();
         }
     }
@@ -144,17 +153,18 @@ static hipError_t launch_norm_t(const T* x, const RT* res_in, const float* w, T*
 template <bool EMBED>
 static hipError_t dispatch_norm(const void* x, const void* res_in, const float* w, void* y, void* res_out,
                                 int64_t rows, int D, float eps, int dt, int rdt, const int32_t* ids,
-                                const int32_t* comp8, int B, int L, hipStream_t s, float* rstd_out = nullptr) {
+                                const int32_t* comp8, int B, int L, hipStream_t s, float* rstd_out = nullptr, int Dp = 0) {
     if (D % 8 || D > 2048) return hipErrorInvalidValue;
+    if (Dp == 0) Dp = D;
     if (dt == BF16 && rdt == F32)
         return launch_norm_t<bf16_t, float, EMBED>((const bf16_t*)x, (const float*)res_in, w, (bf16_t*)y,
-                                                    (float*)res_out, rows, D, eps, ids, comp8, B, L, s, rstd_out);
+                                                    (float*)res_out, rows, D, eps, ids, comp8, B, L, s, rstd_out, Dp);
     if (dt == BF16 && rdt == BF16)
         return launch_norm_t<bf16_t, bf16_t, EMBED>((const bf16_t*)x, (const bf16_t*)res_in, w, (bf16_t*)y,
-                                                     (bf16_t*)res_out, rows, D, eps, ids, comp8, B, L, s, rstd_out);
+                                                     (bf16_t*)res_out, rows, D, eps, ids, comp8, B, L, s, rstd_out, Dp);
     if (dt == F32 && rdt == F32)
         return launch_norm_t<float, float, EMBED>((const float*)x, (const float*)res_in, w, (float*)y,
-                                                   (float*)res_out, rows, D, eps, ids, comp8, B, L, s, rstd_out);
+                                                   (float*)res_out, rows, D, eps, ids, comp8, B, L, s, rstd_out, Dp);
     return hipErrorInvalidValue;
 }
 
@@ -164,8 +174,8 @@ hipError_t launch_add_rmsnorm(const void* x, const void* res_in, const float* w,
 }
 
 hipError_t launch_embed_rmsnorm(const int32_t* ids, const void* emb, const int32_t* comp8, const float* w, void* y,
-                                void* res_out, int B, int L, int D, float eps, int dt, int rdt, hipStream_t s, float* rstd_out) {
-    return dispatch_norm<true>(emb, nullptr, w, y, res_out, (int64_t)2 * B * L, D, eps, dt, rdt, ids, comp8, B, L, s, rstd_out);
+                                void* res_out, int B, int L, int D, float eps, int dt, int rdt, hipStream_t s, float* rstd_out, int Dp) {
+    return dispatch_norm<true>(emb, nullptr, w, y, res_out, (int64_t)2 * B * L, D, eps, dt, rdt, ids, comp8, B, L, s, rstd_out, Dp);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -218,7 +228,7 @@ __global__ __launch_bounds__(128) void final_head_kernel(const T* __restrict__ h
             float r[8];
             load8<T>(h + hrow * D + c * 8, v[j]);
             if (res_frag) {                  // norm-folded form: fp32 residual in the GEMM's fragment layout (RT == float)
-                const float* rp = reinterpret_cast<const float*>(res) + res_frag_off(row, c * 8, D);
+                const float* rp = reinterpret_cast<const float*>(res) + res_frag_off(row, c * 8, res_frag);      // res_frag = padded width Dp
                 const f32x4 a = *reinterpret_cast<const f32x4*>(rp), b = *reinterpret_cast<const f32x4*>(rp + 256);
                 r[0] = a[0]; r[1] = a[1]; r[2] = a[2]; r[3] = a[3]; r[4] = b[0]; r[5] = b[1]; r[6] = b[2]; r[7] = b[3];
             } else {
@@ -304,12 +314,12 @@ static hipError_t launch_final_t(const void* h, const void* res, const float* w,
 hipError_t launch_final_head(const void* h, const void* res, const float* w, const void* /*emb*/,
                              const float* emb_f32, const int32_t* comp8, void* hidden_out, float* logits_out, int B,
                              int L, int D, float eps, Positions pos, const int32_t* pos_per_seq, int dt, int rdt,
-                             hipStream_t s, bool h_compact, const int32_t* ids, int32_t* status, bool res_frag) {
+                             hipStream_t s, bool h_compact, const int32_t* ids, int32_t* status, int res_frag) {
     if (D % 8 || D > 2048) return hipErrorInvalidValue;
     if (h_compact && (pos_per_seq || pos.n == 0)) return hipErrorInvalidValue;
-    if (res_frag && (rdt != F32 || D % 256 || ((int64_t)2 * B * L) % 256)) return hipErrorInvalidValue;
+    if (res_frag && (rdt != F32 || res_frag % 256 || res_frag < D || ((int64_t)2 * B * L) % 256)) return hipErrorInvalidValue;
     const int hc = h_compact ? 1 : 0;
-    const int rf = res_frag ? 1 : 0;
+    const int rf = res_frag;
     if (dt == BF16 && rdt == F32)
         return launch_final_t<bf16_t, float>(h, res, w, emb_f32, comp8, hidden_out, logits_out, B, L, D, eps, pos, pos_per_seq, s, hc, ids, status, rf);
     if (dt == BF16 && rdt == BF16)
