@@ -1,6 +1,9 @@
 #!/bin/bash
 # developer tool (GPU box): interleaved same-box A/B of engine options / builds.   tools/ab_opts.sh <tag> <rounds> "<spec>" ...
-#   spec = "name|ENV=.. ENV=..|bench args"   e.g.  "fold|PCAD_LIB=/x.so|--opt norm_fold=1"    ("r3" as name: the r3tree checkout)
+#   spec = "name|ENV=.. ENV=..|bench args"   e.g.  "fold|PCAD_LIB=/x.so|--opt norm_fold=1"
+#   ("r3" as name: bench.py of a `git worktree add r3tree <round-3 commit>` checkout with its own built libpcad.so, i.e. a whole
+#    earlier tree on the same box; builds of THIS tree with extra flags come from tools/build_variant.sh and go in through PCAD_LIB,
+#    with PCAD_ALLOW_STALE=1 when the variant was built before the last `make` refreshed build_hash.h)
 TAG="$1"; R="$2"; shift 2
 ROOT="${GRAFT_REPO_ROOT:-$(pwd)}"; O="$ROOT/gpurun_out/$TAG"; mkdir -p "$O"; cd "$ROOT"
 show() { python3 -c "
