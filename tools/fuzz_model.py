@@ -21,7 +21,7 @@ for case in range(n):
     B = int(rng.integers(1, 6))
     L = int(rng.choice([1, 2, 3, 5, 7, 8, 9, 15, 16, 17, 31, 33, 63, 64, 65, 100, 127, 128, 129, 200, 255, 257, 300]))
     if FOLD:
-        D = int(rng.choice([256, 512, 768, 1024]))
+        D = int(rng.choice([256, 512, 768, 1024, 320, 384, 448]))       # incl. widths padded to the next multiple of 256
         nl = int(rng.integers(1, 5))
         L = int(rng.choice([32, 64, 128, 256, 384, 512, 640]))
         B = int(rng.integers(1, 9)) * (128 // np.gcd(128, L))            # 2 B L a multiple of 256
