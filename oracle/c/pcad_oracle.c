@@ -13,11 +13,17 @@
  * the fixtures described in oracle/caduceus_oracle.py.
  *
  * Parallelisation: the 2B-strand batch walks the stack layer by layer and every operator is an OpenMP
- * parallel loop (GEMM: weight-panel x row-block tiles; conv/norm: token rows; scan: strand x 16-channel
+ * parallel loop (GEMM: weight-panel x row-block tiles; conv/norm: token rows; scan: strand x 32-channel
  * blocks), so even a small sample uses all host cores.  Plain blocked loops the compiler vectorises, no
- * intrinsics: a scalar-source port.  The projections can be routed to the host BLAS instead (oracle_set_gemm).
+ * intrinsics: a scalar-source port.  The channel loops only vectorise with branch-free exp / log / softplus
+ * and -fno-trapping-math (oracle/c/Makefile) - until round 4 they silently did not, and the scan ran scalar
+ * (3x slower; outputs are bit-identical to that build).  The projections can be routed to the host BLAS
+ * instead (oracle_set_gemm).  ORACLE_TIMING=1 prints the per-operator wall time of a forward.
  */
+#define _POSIX_C_SOURCE 199309L
 #include <math.h>
+#include <stdio.h>
+#include <time.h>
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
@@ -77,12 +83,12 @@ int oracle_num_threads(void) {
 #endif
 }
 
-/* expf with a Cephes-style polynomial so that the channel loop vectorises (rel. error ~1e-7) */
+/* expf with a Cephes-style polynomial, written branch-free (clamp + final select) so that the channel loops vectorise
+ * (rel. error ~1e-7; exactly 0 below -87 like the branchy form it replaces) */
 static inline float vexpf(float x) {
-    if (x < -87.0f) return 0.0f;
-    if (x > 88.0f) x = 88.0f;
-    const float fx = floorf(x * 1.44269504088896341f + 0.5f);
-    const float r = (x - fx * 0.693359375f) - fx * -2.12194440e-4f;
+    const float xc = x > 88.0f ? 88.0f : (x < -87.0f ? -87.0f : x);
+    const float fx = floorf(xc * 1.44269504088896341f + 0.5f);
+    const float r = (xc - fx * 0.693359375f) - fx * -2.12194440e-4f;
     float p = 1.9875691500E-4f;
     p = p * r + 1.3981999507E-3f;
     p = p * r + 8.3334519073E-3f;
@@ -92,7 +98,8 @@ static inline float vexpf(float x) {
     p = p * r * r + r + 1.0f;
     union { float f; int32_t i; } u;
     u.i = ((int32_t)fx + 127) << 23;
-    return p * u.f;
+    const float v = p * u.f;
+    return x < -87.0f ? 0.0f : v;
 }
 
 /* logf for normal positive x, Cephes polynomial (vectorisable; rel. error ~1e-7) */
@@ -101,8 +108,10 @@ static inline float vlogf(float x) {
     u.f = x;
     int32_t e = ((u.i >> 23) & 255) - 126;
     u.i = (u.i & 0x007fffff) | 0x3f000000;   /* mantissa in [0.5, 1) */
-    float m = u.f;
-    if (m < 0.707106781186547524f) { e -= 1; m = m + m - 1.0f; } else { m = m - 1.0f; }
+    const float m0 = u.f;
+    const int lo = m0 < 0.707106781186547524f;
+    e -= lo;
+    const float m = lo ? m0 + m0 - 1.0f : m0 - 1.0f;
     const float z = m * m;
     float y = 7.0376836292E-2f;
     y = y * m - 1.1514610310E-1f;
@@ -216,65 +225,87 @@ static void conv_silu(const float* xz, const float* cw, const float* cb, float* 
         for (int t = 0; t < L; ++t) {
             const float* base = xz + (size_t)s * L * 2 * E;
             float* o = xc + ((size_t)s * L + t) * E;
-            for (int c = 0; c < E; ++c) {
-                float a = cb[c];
-                for (int k = 0; k < 4; ++k) {
-                    const int tt = d == 0 ? t - 3 + k : t + 3 - k;
-                    if (tt >= 0 && tt < L) a += cw[c * 4 + k] * base[(size_t)tt * 2 * E + c];
-                }
-                o[c] = rb ? rbf(silu_f(a)) : silu_f(a);
+            /* taps outermost (same order of additions per channel: bias, then k = 0..3) so that the channel loops vectorise */
+            for (int c = 0; c < E; ++c) o[c] = cb[c];
+            for (int k = 0; k < 4; ++k) {
+                const int tt = d == 0 ? t - 3 + k : t + 3 - k;
+                if (tt < 0 || tt >= L) continue;
+                const float* xr = base + (size_t)tt * 2 * E;
+                for (int c = 0; c < E; ++c) o[c] += cw[c * 4 + k] * xr[c];
             }
+            if (rb) for (int c = 0; c < E; ++c) o[c] = rbf(silu_f(o[c]));
+            else for (int c = 0; c < E; ++c) o[c] = silu_f(o[c]);
         }
 }
 
-/* selective scan of one direction, accumulated into y (gated by silu(z)); channel blocks of VL lanes,
- * sequential in t; parallel over (strand, channel block) */
+/* selective scan of one direction, accumulated into y (gated by silu(z)); sequential in t; parallel over (strand, block of CB
+ * channels).  Rows of a strand are E floats apart, so a walk over t touches a new page per array per step: the per-(t, c) inputs of
+ * TS steps are staged into a local tile first (independent loads, vectorised softplus / SiLU), the recurrence then runs out of
+ * that tile, and the tile's outputs are written back - same operations in the same order per element as the plain loop nest. */
+#define CB 32
+#define TS 32
 static void scan_dir(const float* xc, const float* delta, const float* dbl, const float* xz, const float* A,
                      const float* dt_b, const float* Dskip, float* y, int S, int L, int E, int R, int d, int rb, int acc) {
     const int XP = R + 2 * NST;
 #pragma omp parallel for collapse(2) schedule(static)
     for (int s = 0; s < S; ++s)
-        for (int c0 = 0; c0 < E; c0 += VL) {
+        for (int c0 = 0; c0 < E; c0 += CB) {
             const size_t r0 = (size_t)s * L;
-            float st[NST][VL], ab[NST][VL];
+            const int nc = E - c0 < CB ? E - c0 : CB;
+            float st[NST][CB], ab[NST][CB];
+            float dvt[TS][CB], dut[TS][CB], yt[TS][CB], gt[TS][CB];
             memset(st, 0, sizeof(st));
+            memset(ab, 0, sizeof(ab));
             for (int n = 0; n < NST; ++n)
-                for (int l = 0; l < VL; ++l) ab[n][l] = A[(size_t)(c0 + l) * NST + n];
-            for (int step = 0; step < L; ++step) {
-                const size_t t = r0 + (d == 0 ? step : L - 1 - step);
-                const float* Bt = dbl + t * XP + R;
-                const float* Ct = Bt + NST;
-                float dv[VL], du[VL], yv[VL];
-                for (int l = 0; l < VL; ++l) {
-                    const int c = c0 + l;
-                    dv[l] = softplus_f(delta[t * E + c] + dt_b[c]);
-                    const float uv = xc[t * E + c];
-                    du[l] = dv[l] * uv;
-                    yv[l] = Dskip[c] * uv;
-                }
-                for (int n = 0; n < NST; ++n) {
-                    const float bn = Bt[n], cn = Ct[n];
-                    for (int l = 0; l < VL; ++l) {
-                        const float a = vexpf(dv[l] * ab[n][l]);
-                        st[n][l] = a * st[n][l] + du[l] * bn;
-                        yv[l] += st[n][l] * cn;
+                for (int l = 0; l < nc; ++l) ab[n][l] = A[(size_t)(c0 + l) * NST + n];
+            for (int step0 = 0; step0 < L; step0 += TS) {
+                const int nts = L - step0 < TS ? L - step0 : TS;
+                for (int i = 0; i < nts; ++i) {
+                    const size_t t = r0 + (d == 0 ? step0 + i : L - 1 - (step0 + i));
+                    const float* dl = delta + t * E + c0;
+                    const float* ur = xc + t * E + c0;
+                    const float* zr = xz + t * 2 * E + E + c0;
+                    for (int l = 0; l < nc; ++l) {
+                        const float dv = softplus_f(dl[l] + dt_b[c0 + l]);
+                        const float uv = ur[l];
+                        dvt[i][l] = dv;
+                        dut[i][l] = dv * uv;
+                        yt[i][l] = Dskip[c0 + l] * uv;
+                        gt[i][l] = silu_f(zr[l]);
                     }
                 }
-                for (int l = 0; l < VL; ++l) {
-                    const int c = c0 + l;
-                    const float g = yv[l] * silu_f(xz[t * 2 * E + E + c]);      /* each direction rounded, then summed */
-                    if (acc) y[t * E + c] = rb ? rbf(y[t * E + c] + rbf(g)) : y[t * E + c] + g;
-                    else y[t * E + c] = rb ? rbf(g) : g;
+                for (int i = 0; i < nts; ++i) {
+                    const size_t t = r0 + (d == 0 ? step0 + i : L - 1 - (step0 + i));
+                    const float* Bt = dbl + t * XP + R;
+                    const float* Ct = Bt + NST;
+                    for (int n = 0; n < NST; ++n) {
+                        const float bn = Bt[n], cn = Ct[n];
+                        for (int l = 0; l < CB; ++l) {
+                            const float a = vexpf(dvt[i][l] * ab[n][l]);
+                            st[n][l] = a * st[n][l] + dut[i][l] * bn;
+                            yt[i][l] += st[n][l] * cn;
+                        }
+                    }
+                }
+                for (int i = 0; i < nts; ++i) {
+                    const size_t t = r0 + (d == 0 ? step0 + i : L - 1 - (step0 + i));
+                    float* yr = y + t * E + c0;
+                    for (int l = 0; l < nc; ++l) {
+                        const float g = yt[i][l] * gt[i][l];                        /* each direction rounded, then summed */
+                        if (acc) yr[l] = rb ? rbf(yr[l] + rbf(g)) : yr[l] + g;
+                        else yr[l] = rb ? rbf(g) : g;
+                    }
                 }
             }
         }
 }
 
-/*
- * ids [B, L] int32 -> logits [B, L, 8] (may be NULL), hidden [B, L, 2D] (may be NULL).
- * hidden[b,l] = cat(Hf[b,l], reverse_channels(Hr[b,L-1-l])); logits = Hf.Emb^T + Hr[L-1-l].Emb[comp]^T.
- * returns 0, or -1 on allocation failure.
- */
+/* ORACLE_TIMING=1: per-operator wall time of one forward on stderr (where the CPU baseline's time goes) */
+static double now_s(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
+enum { T_NORM, T_INPROJ, T_ROUND, T_CONV, T_XPROJ, T_DTPROJ, T_SCAN, T_OUTPROJ, T_HEAD, T_MISC, T_N };
+static const char* const t_names[T_N] = {"add_rmsnorm", "in_proj", "round", "conv_silu", "x_proj", "dt_proj", "scan", "out_proj", "head", "misc"};
+#define TIMED(slot, stmt) do { const double _t0 = now_s(); stmt; tsum[slot] += now_s() - _t0; } while (0)
+
 int oracle_forward(const oracle_model* m, const int32_t* ids, int B, int L, float* logits, float* hidden) {
     const int D = m->d_model, E = m->d_inner, R = m->dt_rank, XP = R + 2 * NST, S = 2 * B;
     const size_t rows = (size_t)S * L;
@@ -304,39 +335,44 @@ int oracle_forward(const oracle_model* m, const int32_t* ids, int B, int L, floa
         memcpy(h + (size_t)r * D, m->emb + (size_t)(tok[r] & 7) * D, sizeof(float) * D);
 
     const int rb = m->emulate_bf16;
-    round_rows(h, rows * D, rb);
+    double tsum[T_N] = {0};
+    const double t_begin = now_s();
+    TIMED(T_ROUND, round_rows(h, rows * D, rb));
     for (int li = 0; li < m->n_layer; ++li) {
         const oracle_layer* ly = &m->layers[li];
-        add_rmsnorm(h, res, li > 0, ly->norm_w, u, (int64_t)rows, D, m->eps, rb);
-        linear_nt(u, D, ly->in_proj, D, xz, 2 * E, (int)rows, 2 * E);
-        round_rows(xz, rows * 2 * E, rb);
-        memset(y, 0, sizeof(float) * rows * E);
+        TIMED(T_NORM, add_rmsnorm(h, res, li > 0, ly->norm_w, u, (int64_t)rows, D, m->eps, rb));
+        TIMED(T_INPROJ, linear_nt(u, D, ly->in_proj, D, xz, 2 * E, (int)rows, 2 * E));
+        TIMED(T_ROUND, round_rows(xz, rows * 2 * E, rb));
+        TIMED(T_MISC, memset(y, 0, sizeof(float) * rows * E));
         for (int d = 0; d < 2; ++d) {
-            conv_silu(xz, ly->conv_w[d], ly->conv_b[d], xc, S, L, E, d, rb);
-            linear_nt(xc, E, ly->x_proj[d], E, dbl, XP, (int)rows, XP);
-            round_rows(dbl, rows * XP, rb);
-            linear_nt(dbl, XP, ly->dt_w[d], R, delta, E, (int)rows, E);
-            round_rows(delta, rows * E, rb);
+            TIMED(T_CONV, conv_silu(xz, ly->conv_w[d], ly->conv_b[d], xc, S, L, E, d, rb));
+            TIMED(T_XPROJ, linear_nt(xc, E, ly->x_proj[d], E, dbl, XP, (int)rows, XP));
+            TIMED(T_ROUND, round_rows(dbl, rows * XP, rb));
+            TIMED(T_DTPROJ, linear_nt(dbl, XP, ly->dt_w[d], R, delta, E, (int)rows, E));
+            TIMED(T_ROUND, round_rows(delta, rows * E, rb));
 #pragma omp parallel for schedule(static)
             for (int i = 0; i < E * NST; ++i) A[i] = -expf(ly->A_log[d][i]);
-            scan_dir(xc, delta, dbl, xz, A, ly->dt_b[d], ly->Dskip[d], y, S, L, E, R, d, rb, !m->ref_order);
+            TIMED(T_SCAN, scan_dir(xc, delta, dbl, xz, A, ly->dt_b[d], ly->Dskip[d], y, S, L, E, R, d, rb, !m->ref_order));
             if (m->ref_order) {      /* each Mamba call ends in its own (tied) out_proj, output stored in the model dtype */
                 float* o = d == 0 ? h : h2;
-                linear_nt(y, E, ly->out_proj, E, o, D, (int)rows, D);
-                round_rows(o, rows * D, rb);
+                TIMED(T_OUTPROJ, linear_nt(y, E, ly->out_proj, E, o, D, (int)rows, D));
+                TIMED(T_ROUND, round_rows(o, rows * D, rb));
             }
         }
         if (m->ref_order) {          /* BiMambaWrapper "add": out_fwd + out_rev */
+            const double t0 = now_s();
 #pragma omp parallel for schedule(static)
             for (int64_t i = 0; i < (int64_t)(rows * D); ++i) h[i] += h2[i];
+            tsum[T_MISC] += now_s() - t0;
         } else {
-            linear_nt(y, E, ly->out_proj, E, h, D, (int)rows, D);    /* tied out_proj folded, as the engine does */
+            TIMED(T_OUTPROJ, linear_nt(y, E, ly->out_proj, E, h, D, (int)rows, D));    /* tied out_proj folded, as the engine does */
         }
-        round_rows(h, rows * D, rb);
+        TIMED(T_ROUND, round_rows(h, rows * D, rb));
     }
     float* Hall = u;   /* final normalised hidden [S, L, D] */
-    add_rmsnorm(h, res, 1, m->norm_f, Hall, (int64_t)rows, D, m->eps, rb);
+    TIMED(T_NORM, add_rmsnorm(h, res, 1, m->norm_f, Hall, (int64_t)rows, D, m->eps, rb));
 
+    const double t_head = now_s();
 #pragma omp parallel for collapse(2) schedule(static)
     for (int b = 0; b < B; ++b)
         for (int l = 0; l < L; ++l) {
@@ -356,6 +392,12 @@ int oracle_forward(const oracle_model* m, const int32_t* ids, int B, int L, floa
                 }
             }
         }
+    tsum[T_HEAD] = now_s() - t_head;
+    if (getenv("ORACLE_TIMING")) {
+        fprintf(stderr, "oracle_forward B=%d L=%d: %.2f s |", B, L, now_s() - t_begin);
+        for (int i = 0; i < T_N; ++i) fprintf(stderr, " %s %.2f", t_names[i], tsum[i]);
+        fprintf(stderr, "\n");
+    }
     free(buf);
     free(tok);
     return 0;

@@ -17,6 +17,7 @@ import torch
 
 from oracle.c_oracle import COracle
 from plantcaduceus_amd.checkpoint import make_config, synthetic_state_dict
+from oracle_cache import oracle_forward
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -49,7 +50,7 @@ def test_full_depth_fp32(size, n):
     cfg = make_config(size)
     sd = synthetic_state_dict(cfg, seed=21, stress=True)      # distinct fwd/rev parameters, non-unit norm weights / D
     ids = windows(n, 5)
-    lg_ref, hid_ref = COracle(sd, cfg, blas=True).forward(ids, want_hidden=True)
+    lg_ref, hid_ref = oracle_forward((size, 21, True), sd, cfg, ids, want_hidden=True)
     m = hip_model(cfg, sd, torch.float32)
     out = m(input_ids=torch.from_numpy(ids).to(DEV), output_hidden_states=True)
     lg = out.logits.cpu().numpy()
@@ -76,7 +77,7 @@ def test_full_depth_bf16_both_orders(size, n):
     p_hip = softmax4(lg[:, 3:7])
 
     def oracle(**kw):
-        return softmax4(COracle(sd, cfg, blas=True, **kw).forward(ids)[0][:, P, 3:7])
+        return softmax4(oracle_forward((size, 1234, False), sd, cfg, ids, **kw)[0][:, P, 3:7])
     p_ref = oracle(dtype=torch.bfloat16, emulate_bf16=True, ref_order=True)     # the reference's order
     p_eng = oracle(dtype=torch.bfloat16, emulate_bf16=True, ref_order=False)    # the engine's order
     p_f32 = oracle()
@@ -112,8 +113,8 @@ def test_full_depth_bf16_engine_options_against_reference_order():
     ids = windows(n, 0)
     tids = torch.from_numpy(ids).to(DEV)
 
-    def oracle(**kw):
-        return softmax4(COracle(sd, cfg, blas=True, **kw).forward(ids)[0][:, P, 3:7])
+    def oracle(**kw):       # the same two runs as test_full_depth_bf16_both_orders[l32-16]: shared through the memo
+        return softmax4(oracle_forward(("l32", 1234, False), sd, cfg, ids, **kw)[0][:, P, 3:7])
     p_ref = oracle(dtype=torch.bfloat16, emulate_bf16=True, ref_order=True)
     p_eng = oracle(dtype=torch.bfloat16, emulate_bf16=True, ref_order=False)
     floor = np.abs(p_ref - p_eng).max()                      # what reordering alone does to a bf16 restatement
@@ -139,8 +140,9 @@ def test_full_depth_fp32_norm_fold():
     fp32 precision - measured 2.2e-5 of max on the hidden states against 1.3e-6 - and only the bf16 model folds by default)."""
     cfg = make_config("l32")
     sd = synthetic_state_dict(cfg, seed=21, stress=True)
-    ids = windows(8, 5)
-    lg_ref, hid_ref = COracle(sd, cfg, blas=True).forward(ids, want_hidden=True)
+    ids16 = windows(16, 5)                                   # test_full_depth_fp32[l32-16]'s oracle run, first 8 windows of it
+    lg_ref, hid_ref = (a[:8] for a in oracle_forward(("l32", 21, True), sd, cfg, ids16, want_hidden=True))
+    ids = ids16[:8]
     out = hip_model(cfg, sd, torch.float32, norm_fold=1)(input_ids=torch.from_numpy(ids).to(DEV), output_hidden_states=True)
     lg, hid = out.logits.cpu().numpy(), out.hidden_states[-1].cpu().numpy()
     e_l = np.abs(lg - lg_ref).max() / np.abs(lg_ref).max()

@@ -160,3 +160,23 @@ def test_c_port_blas_gemm_hook_matches_plain():
     lg1, h1 = COracle(sd, cfg, blas=True).forward(ids, want_hidden=True)
     assert np.abs(lg1 - lg0).max() / np.abs(lg0).max() < 1e-5
     assert np.abs(h1 - h0).max() / np.abs(h0).max() < 1e-5
+
+
+def test_oracle_memo_of_the_gpu_tests_returns_the_direct_result():
+    """tests/oracle_cache.py (the memo the -m gpu parity tests share): same arrays as a direct COracle run, one run per distinct
+    (checkpoint key, windows, mode), a logits-only entry is recomputed when the hidden states are asked for."""
+    from oracle.c_oracle import COracle
+    import oracle_cache
+    cfg = make_config("x", d_model=128, n_layer=2)
+    sd = synthetic_state_dict(cfg, seed=3)
+    ids = np.random.default_rng(4).integers(3, 7, size=(3, 40)).astype(np.int64)
+    direct = COracle(sd, cfg, blas=True, dtype=torch.bfloat16, emulate_bf16=True).forward(ids, want_hidden=True)
+    oracle_cache._CACHE.clear()
+    a = oracle_cache.oracle_forward(("x", 3), sd, cfg, ids, dtype=torch.bfloat16, emulate_bf16=True)
+    assert a[1] is None and np.array_equal(a[0], direct[0]) and len(oracle_cache._CACHE) == 1
+    assert oracle_cache.oracle_forward(("x", 3), sd, cfg, ids, dtype=torch.bfloat16, emulate_bf16=True) is a
+    b = oracle_cache.oracle_forward(("x", 3), sd, cfg, ids, want_hidden=True, dtype=torch.bfloat16, emulate_bf16=True)
+    assert np.array_equal(b[1], direct[1]) and len(oracle_cache._CACHE) == 1
+    c = oracle_cache.oracle_forward(("x", 3), sd, cfg, ids)                        # another mode: its own entry
+    assert len(oracle_cache._CACHE) == 2 and not np.array_equal(c[0], a[0])
+    oracle_cache._CACHE.clear()
