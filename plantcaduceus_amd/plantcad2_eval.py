@@ -43,7 +43,7 @@ def masked_probs(model, tokenizer, sequences: Sequence[str], mask_idx: Union[int
             cur = ids_all[b0:b0 + batch_size].to(device)
             lg = model(input_ids=cur, positions=idx).logits if fast else model(input_ids=cur).logits[:, idx, :]
             out.append(torch.softmax(lg[..., cols].float(), dim=-1).reshape(-1, 4).cpu().numpy())
-    check_model_inputs(model)          # the engine validates token ids on the device; raise here, where results are read back
+    check_model_inputs(model, collective=False)   # the engine validates token ids on the device; raise here, where results are read back (unsharded loop: local bits)
     return np.vstack(out) if out else np.zeros((0, 4), dtype=np.float32)
 
 
@@ -58,7 +58,7 @@ def unmasked_probs(sequences: Sequence[str], tokenizer, model, device, batch_siz
         for b0 in range(0, len(seqs), batch_size):
             lg = model(input_ids=ids_all[b0:b0 + batch_size].to(device)).logits[..., cols]
             out[b0:b0 + batch_size] = torch.softmax(lg.float(), dim=-1).cpu().numpy()
-    check_model_inputs(model)
+    check_model_inputs(model, collective=False)
     return out
 
 

@@ -187,16 +187,17 @@ def iter_device_batches(sequences, start: int, stop: int, pad_to: int, batch_siz
             yield cur.to(device, non_blocking=True)
 
 
-def check_model_inputs(model):
+def check_model_inputs(model, collective: bool = True):
     """Raise the engine's deferred IndexError (token id / position out of range, detected on the device) where results are read.
     Inside a process group the status bits are OR-ed over the ranks first, so that EVERY rank raises (a single rank raising
-    between two collectives would leave its peers waiting in the next one until the watchdog fires)."""
+    between two collectives would leave its peers waiting in the next one until the watchdog fires).  collective=False: this
+    rank's own bits only - for host loops that are NOT sharded (every caller of a collective must be called by every rank)."""
     chk = getattr(model, "check_status", None)
     if not callable(chk):
         return
     rank, ws = sharding.world()
     get = getattr(model, "status_bits", None)
-    if ws > 1 and callable(get):
+    if collective and ws > 1 and callable(get):
         import torch.distributed as dist
         mine = int(get())
         dev = torch.cuda.current_device() if dist.get_backend() == "nccl" else "cpu"
