@@ -5,7 +5,9 @@ The embedding extraction is the accelerated path (`embeddings.extract_embeddings
 ensemble.  `xgboost` is not a dependency here: `XGBJsonClassifier` reads the XGBoost JSON model format that
 `XGBClassifier.save_model("*.json")` writes (learner.gradient_booster.model.trees: left_children, right_children,
 split_indices, split_conditions, default_left; leaf value in split_conditions; binary:logistic with base_score in
-probability space) and evaluates it with vectorised numpy.  The 16 classifier JSONs of the reference are large blobs
+probability space) and evaluates it natively on all host cores (`hostlib.xgb_margin`, host/xgb_eval.c: C + OpenMP, the stand-in for
+XGBoost's C++ predictor; `margin_numpy` is the same walk in vectorised numpy, kept as the cross-check and as the path when no C
+compiler is available).  The 16 classifier JSONs of the reference are large blobs
 that are absent from the reference checkout, so this reader is pinned by hand-built models in tests/test_xgb.py, not
 by the real files.  Same flags, cache files (`<prefix>_embeddings.npz` / `<prefix>_chunk_<i>_embeddings.npz`, key
 `test`) and output (`<prefix>_predictions.tsv`, columns label, prediction) as the reference script.
@@ -43,14 +45,55 @@ class XGBJsonClassifier:
         if booster.get("name", "gbtree") != "gbtree":
             raise ValueError("only gbtree boosters are supported")
         self.trees = []
-        for t in booster["model"]["trees"]:
-            self.trees.append(dict(
+        for ti, t in enumerate(booster["model"]["trees"]):
+            tree = dict(
                 left=np.asarray(t["left_children"], dtype=np.int64), right=np.asarray(t["right_children"], dtype=np.int64),
                 feat=np.asarray(t["split_indices"], dtype=np.int64), cond=np.asarray(t["split_conditions"], dtype=np.float32),
-                dleft=np.asarray(t["default_left"], dtype=bool)))
+                dleft=np.asarray(t["default_left"], dtype=bool))
+            self._validate_tree(ti, tree)
+            self.trees.append(tree)
+        # the same arrays concatenated over trees: what the native evaluator walks (host/xgb_eval.c)
+        sizes = [len(t["left"]) for t in self.trees]
+        self._off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+        cat = (lambda k, dt: np.concatenate([t[k] for t in self.trees]).astype(dt) if self.trees else np.zeros(0, dtype=dt))
+        self._flat = (cat("left", np.int32), cat("right", np.int32), cat("feat", np.int32), cat("cond", np.float32), cat("dleft", np.uint8))
         return self
 
+    def _validate_tree(self, ti: int, t):
+        """Every node reachable from the root exactly once, children and split features in range: the native walk trusts this."""
+        n = len(t["left"])
+        if n == 0 or not (len(t["right"]) == len(t["feat"]) == len(t["cond"]) == len(t["dleft"]) == n):
+            raise ValueError(f"tree {ti}: empty or ragged node arrays")
+        seen = np.zeros(n, dtype=bool)
+        stack = [0]
+        while stack:
+            k = stack.pop()
+            if not 0 <= k < n or seen[k]:
+                raise ValueError(f"tree {ti}: node {k} out of range or reached twice")
+            seen[k] = True
+            l, r = int(t["left"][k]), int(t["right"][k])
+            if l == -1:
+                continue
+            if r == -1 or (self.n_features and not 0 <= int(t["feat"][k]) < self.n_features):
+                raise ValueError(f"tree {ti}: node {k} has one child or a split feature outside [0, {self.n_features})")
+            stack += [l, r]
+
     def margin(self, X: np.ndarray) -> np.ndarray:
+        """base margin + sum of leaf values, float64 [rows]: natively on all host cores when libpcad_host.so can be built / loaded
+        (bit-identical to `margin_numpy`: same comparisons, same order of additions)."""
+        X = np.asarray(X, dtype=np.float32)
+        nf = self.n_features or (int(self._flat[2].max()) + 1 if len(self._flat[2]) else 0)
+        if X.ndim != 2 or X.shape[1] < nf:
+            raise ValueError(f"embeddings must be [rows, >= {nf}] (got {X.shape})")
+        try:
+            from . import hostlib
+            hostlib.load_library()
+        except Exception as ex:                       # no gcc / read-only tree: the numpy walk computes the same numbers
+            logging.warning("libpcad_host.so unavailable (%s): evaluating the XGBoost ensemble in numpy", ex)
+            return self.margin_numpy(X)
+        return hostlib.xgb_margin(X, nf, self._off, *self._flat, self.base_margin)
+
+    def margin_numpy(self, X: np.ndarray) -> np.ndarray:
         X = np.asarray(X, dtype=np.float32)
         out = np.full(X.shape[0], self.base_margin, dtype=np.float64)
         rows = np.arange(X.shape[0])

@@ -117,6 +117,44 @@ def test_xgb_evaluator_vs_scalar_walk_on_random_forests(tmp_path):
 import pytest  # noqa: E402
 
 
+def test_native_evaluator_equals_numpy_walk_bit_for_bit(tmp_path):
+    """libpcad_host.so (host/xgb_eval.c, C + OpenMP: what `margin` runs) against `margin_numpy` on random forests with missing
+    values, wider-than-needed feature rows, a single-leaf tree, zero rows; bit-identical float64 margins."""
+    from plantcaduceus_amd import hostlib
+    assert hostlib.load_library().pcad_host_version() >= 1
+    rng = np.random.default_rng(11)
+    F = 40
+    trees = [_random_tree(rng, F, depth=int(rng.integers(0, 7))) for _ in range(120)]
+    trees.append(_tree([-1], [-1], [0], [0.25], [0]))                      # a stump that is a single leaf
+    path = tmp_path / "forest.json"
+    json.dump(_model_json(trees, F, base_score="7.3E-1"), open(path, "w"))
+    clf = xgb_predict.XGBJsonClassifier().load_model(str(path))
+    X = rng.normal(size=(1000, F + 3)).astype(np.float32)                  # callers may pass wider rows
+    X[rng.random(X.shape) < 0.15] = np.nan
+    a, b = clf.margin(X), clf.margin_numpy(X)
+    assert a.dtype == np.float64 and np.array_equal(a, b)
+    assert clf.margin(X[:0]).shape == (0,)
+    np.testing.assert_array_equal(clf.margin(X[:65]), b[:65])              # one full row block + 1
+    with pytest.raises(ValueError):
+        clf.margin(X[:, :F - 1])                                           # fewer features than the model splits on
+
+
+def test_malformed_trees_are_rejected_at_load(tmp_path):
+    """the native walk trusts the arrays, so load_model validates them: child index out of range, a cycle, a split feature
+    outside num_feature."""
+    good = _tree([1, -1, -1], [2, -1, -1], [0, 0, 0], [0.5, 1.0, 2.0], [0, 0, 0])
+    for bad in (dict(good, left_children=[5, -1, -1]), dict(good, right_children=[0, -1, -1]),
+                dict(good, split_indices=[9, 0, 0]), dict(good, right_children=[-1, -1, -1])):
+        path = tmp_path / "bad.json"
+        json.dump(_model_json([bad], 4), open(path, "w"))
+        with pytest.raises(ValueError):
+            xgb_predict.XGBJsonClassifier().load_model(str(path))
+    json.dump(_model_json([good], 4), open(tmp_path / "good.json", "w"))
+    xgb_predict.XGBJsonClassifier().load_model(str(tmp_path / "good.json"))
+
+
+
+
 @pytest.mark.gpu
 def test_predict_cli_on_gpu_from_snapshot(tmp_path, golden_dir):
     """reference src/predict_XGBoost.py:28-67 end to end on the GPU, nothing mocked: snapshot directory -> embeddings through
