@@ -86,7 +86,10 @@ void   pcad_destroy(pcad_handle h);
 /* Options (call before pcad_workspace_bytes / pcad_forward):
  *   "chunk_seqs"  windows per pass through the layer stack (0 = default: as many as the kernels' unsigned 32-bit in-tensor
  *                 offsets allow, (2^32 - 2 MiB) / (d_inner * elem) token-rows = 1 023 windows of 512 bp at l32 bf16, the batch
- *                 split evenly into the fewest such chunks).  Results do not depend on it (rows are independent); the
+ *                 split evenly into the fewest such chunks).  Results do not depend on it (rows are independent) - bit for bit
+ *                 whenever every chunking runs the same layer form, which holds for window lengths that are multiples of 128
+ *                 (every shipped use); for other lengths "norm_fold" engages per chunk (whole 256-row tiles only), so two
+ *                 chunkings of a bf16 batch can differ by bf16 rounding; the
  *                 workspace does: ~30 MB per window at l32 bf16, i.e. up to ~30 GB for one 1 023-window chunk (a batch of
  *                 1 024 runs as two chunks of 512 in a 15.3 GB workspace) - always size it with pcad_workspace_bytes.
  *   "last_layer_shortcut"  1 (default): when pcad_forward is given a list of positions, the LAST layer's scans stop at the
