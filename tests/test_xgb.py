@@ -155,6 +155,107 @@ def test_malformed_trees_are_rejected_at_load(tmp_path):
 
 
 
+class _StubXGBClassifier:
+    """stands in for xgboost.XGBClassifier in the train-CLI test: `fit` "learns" one stump on the feature whose class means differ
+    most, `save_model` writes it in XGBoost's JSON format, `predict_proba` evaluates the same stump."""
+    last_params = None
+
+    def __init__(self, **params):
+        type(self).last_params = params
+
+    def fit(self, X, y, eval_set=None):
+        X, y = np.asarray(X, dtype=np.float32), np.asarray(y)
+        assert eval_set is not None and len(eval_set) == 1 and len(eval_set[0]) == 2
+        d = X[y == 1].mean(0) - X[y == 0].mean(0)
+        self.f = int(np.abs(d).argmax())
+        self.thr = float(np.float32((X[y == 1, self.f].mean() + X[y == 0, self.f].mean()) / 2))
+        self.lo, self.hi = (-2.0, 2.0) if d[self.f] > 0 else (2.0, -2.0)
+        self.nf = X.shape[1]
+        return self
+
+    def save_model(self, path):
+        t = _tree([1, -1, -1], [2, -1, -1], [self.f, 0, 0], [self.thr, self.lo, self.hi], [0, 0, 0])
+        json.dump(_model_json([t], self.nf), open(path, "w"))
+
+    def predict_proba(self, X):
+        m = np.where(np.asarray(X, dtype=np.float32)[:, self.f] < np.float32(self.thr), self.lo, self.hi)
+        p = 1 / (1 + np.exp(-m))
+        return np.stack([1 - p, p], 1)
+
+
+def test_train_cli_plumbing(tmp_path, monkeypatch, golden_dir):
+    """reference src/train_XGBoost.py main() flow with its file names: train / valid embeddings cache, trainer call with the reference's
+    hyper-parameters (xgboost stubbed: it is not installed here), saved JSON re-read by the native evaluator for the test table,
+    predictions / metrics files, the -test_only re-run that needs neither trainer nor model forward, and the error path when
+    xgboost is missing AFTER the caches were written."""
+    import sys
+    import types
+    from plantcaduceus_amd import xgb_train
+    cfg = make_config("x", d_model=64, n_layer=1)
+    model = O.OracleForMaskedLM(O.params_from_state_dict(synthetic_state_dict(cfg, seed=1), cfg))
+    model.config = cfg
+    monkeypatch.setattr(zero_shot, "load_model_and_tokenizer", lambda d, dev: (model, CaduceusTokenizer()))
+    src = pd.read_csv(os.path.join(golden_dir, "example_snp.tsv"), delimiter="\t")
+    paths = {}
+    for name, rows, labels in (("tr", slice(0, 12), [0, 1] * 6), ("va", slice(12, 18), [1, 0] * 3), ("te", slice(18, 23), [0, 1, 1, 0, 1])):
+        paths[name] = tmp_path / f"{name}.tsv"
+        pd.DataFrame({"sequences": src["sequences"].iloc[rows], "label": labels}).to_csv(paths[name], sep="\t", index=False)
+    out = tmp_path / "out"
+    argv = ["-train", str(paths["tr"]), "-valid", str(paths["va"]), "-test", str(paths["te"]), "-model", "unused", "-output", str(out),
+            "-device", "cpu", "-batchSize", "4", "-seed", "7"]
+    # (1) no xgboost: the embeddings are cached first, then a clear error
+    monkeypatch.setitem(sys.modules, "xgboost", None)
+    with pytest.raises(RuntimeError, match="xgboost"):
+        xgb_train.main(argv)
+    z = np.load(out / "train_valid_embeddings.npz")
+    assert z["train"].shape == (12, 64) and z["valid"].shape == (6, 64)
+    assert (out / "te_embeddings.npz").exists() and not (out / "seed_7_XGBoost.json").exists()
+    # (2) with a trainer: caches reused (the model must not run again), everything written under the reference's names
+    stub = types.ModuleType("xgboost")
+    stub.XGBClassifier = _StubXGBClassifier
+    monkeypatch.setitem(sys.modules, "xgboost", stub)
+    monkeypatch.setattr(model, "forward", lambda *a, **k: (_ for _ in ()).throw(AssertionError("cache not used")))
+    xgb_train.main(argv)
+    assert _StubXGBClassifier.last_params == dict(n_estimators=1000, max_depth=6, learning_rate=0.1, n_jobs=-1, random_state=7)
+    assert sorted(os.listdir(out)) == sorted(
+        ["train_valid_embeddings.npz", "te_embeddings.npz", "seed_7_XGBoost.json", "seed_7_valid_predictions.npz",
+         "seed_7_va_metrics.txt", "seed_7_va_metrics.png", "seed_7_te_predictions.npz", "seed_7_te_metrics.txt", "seed_7_te_metrics.png"])
+    clf = xgb_predict.XGBJsonClassifier().load_model(str(out / "seed_7_XGBoost.json"))
+    want = clf.predict_proba(np.load(out / "te_embeddings.npz")["test"])[:, 1]
+    got = np.load(out / "seed_7_te_predictions.npz")["predictions"]
+    np.testing.assert_allclose(got, want, rtol=1e-6)
+    txt = open(out / "seed_7_te_metrics.txt").read().splitlines()
+    assert txt[0].startswith("ROC AUC: ") and txt[1].startswith("PRAUC: ") and len(txt[0].split(": ")[1]) == 4
+    # (3) -test_only, chunked: no trainer, no training tables; predictions equal the unchunked run's
+    monkeypatch.setitem(sys.modules, "xgboost", None)
+    monkeypatch.undo()
+    monkeypatch.setattr(zero_shot, "load_model_and_tokenizer", lambda d, dev: (model, CaduceusTokenizer()))
+    os.remove(out / "te_embeddings.npz")
+    xgb_train.main(["-test", str(paths["te"]), "-model", "unused", "-output", str(out), "-device", "cpu", "-seed", "7", "-test_only",
+                    "-save_memory", "-chunk_size", "2"])
+    assert all((out / f"te_chunk_{i}_embeddings.npz").exists() for i in (0, 2, 4))
+    np.testing.assert_allclose(np.load(out / "seed_7_te_predictions.npz")["predictions"], want, rtol=1e-6)
+    with pytest.raises(FileNotFoundError):
+        xgb_train.main(["-test", str(paths["te"]), "-model", "unused", "-output", str(tmp_path / "empty"), "-device", "cpu", "-test_only"])
+
+
+def test_train_cli_metrics_follow_sklearn():
+    """ROC AUC / PRAUC of evaluate_model against sklearn.metrics (what the reference calls), ties included."""
+    sk = pytest.importorskip("sklearn.metrics")
+    from plantcaduceus_amd import xgb_train
+    rng = np.random.default_rng(3)
+    y = rng.integers(0, 2, size=400)
+    s = np.round(rng.random(400) * 0.6 + 0.3 * y, 2)                      # many tied scores
+    roc_auc, prauc = xgb_train.evaluate_model(s, y)
+    fpr, tpr, _ = sk.roc_curve(y, s)
+    assert abs(roc_auc - sk.auc(fpr, tpr)) < 1e-12 and abs(prauc - sk.average_precision_score(y, s)) < 1e-12
+    f2, t2, p2, r2 = xgb_train._curves(s, y)                             # the plotted points: every distinct threshold
+    fpr_all, tpr_all, _ = sk.roc_curve(y, s, drop_intermediate=False)
+    pr, rc, _ = sk.precision_recall_curve(y, s)
+    assert np.allclose(f2, fpr_all) and np.allclose(t2, tpr_all)
+    assert np.allclose(p2, pr) and np.allclose(r2, rc)
+
+
 @pytest.mark.gpu
 def test_predict_cli_on_gpu_from_snapshot(tmp_path, golden_dir):
     """reference src/predict_XGBoost.py:28-67 end to end on the GPU, nothing mocked: snapshot directory -> embeddings through
@@ -184,3 +285,44 @@ def test_predict_cli_on_gpu_from_snapshot(tmp_path, golden_dir):
     assert np.abs(emb - ref).max() / np.abs(ref).max() < 2e-2          # bf16 model (dtype policy) vs fp32 oracle, 2 layers
     want = xgb_predict.XGBJsonClassifier().load_model(str(clf)).predict_proba(emb)[:, 1]
     np.testing.assert_allclose(res["prediction"].to_numpy(), want, rtol=1e-5)
+
+
+@pytest.mark.gpu
+def test_train_cli_on_gpu_from_snapshot(tmp_path, golden_dir, monkeypatch):
+    """reference src/train_XGBoost.py main() on the GPU from a snapshot directory: train / valid / test embeddings through the HIP
+    path (checked against the oracle on the same checkpoint), the trainer stubbed (xgboost is not installed), the saved JSON
+    evaluated natively for the test table, then the -test_only re-run from the caches."""
+    import sys
+    import types
+    from plantcaduceus_amd import xgb_train
+    from plantcaduceus_amd.checkpoint import make_synthetic_checkpoint
+    d = str(tmp_path / "snap")
+    cfg, sd = make_synthetic_checkpoint(d, "x", seed=22, stress=False, d_model=128, n_layer=2)
+    src = pd.read_csv(os.path.join(golden_dir, "example_snp.tsv"), delimiter="\t")
+    rng = np.random.default_rng(1)
+    paths = {}
+    for name, rows in (("tr", slice(0, 40)), ("va", slice(40, 60)), ("te", slice(60, 90))):
+        paths[name] = tmp_path / f"{name}.tsv"
+        seqs = src["sequences"].iloc[rows]
+        pd.DataFrame({"sequences": seqs, "label": rng.permutation(np.arange(len(seqs)) % 2)}).to_csv(paths[name], sep="\t", index=False)
+    stub = types.ModuleType("xgboost")
+    stub.XGBClassifier = _StubXGBClassifier
+    monkeypatch.setitem(sys.modules, "xgboost", stub)
+    out = tmp_path / "out"
+    xgb_train.main(["-train", str(paths["tr"]), "-valid", str(paths["va"]), "-test", str(paths["te"]), "-model", d, "-output", str(out),
+                    "-device", "cuda:0", "-batchSize", "16"])
+    z = np.load(out / "train_valid_embeddings.npz")
+    assert z["train"].shape == (40, 128) and z["valid"].shape == (20, 128)
+    om = O.OracleForMaskedLM(O.params_from_state_dict(sd, cfg))
+    from plantcaduceus_amd import embeddings
+    ref = embeddings.extract_embeddings(om, src["sequences"].iloc[40:60].tolist(), "cpu", 255, CaduceusTokenizer(), batch_size=8)
+    assert np.abs(z["valid"] - ref).max() / np.abs(ref).max() < 2e-2      # bf16 model (dtype policy) vs fp32 oracle, 2 layers
+    clf = xgb_predict.XGBJsonClassifier().load_model(str(out / "seed_42_XGBoost.json"))
+    te = np.load(out / "te_embeddings.npz")["test"]
+    want = clf.predict_proba(te)[:, 1]
+    np.testing.assert_allclose(np.load(out / "seed_42_te_predictions.npz")["predictions"], want, rtol=1e-6)
+    assert (out / "seed_42_va_metrics.txt").exists() and (out / "seed_42_te_metrics.txt").exists()
+    monkeypatch.setitem(sys.modules, "xgboost", None)                     # the re-run needs no trainer
+    os.remove(out / "seed_42_te_predictions.npz")
+    xgb_train.main(["-test", str(paths["te"]), "-model", d, "-output", str(out), "-device", "cuda:0", "-test_only"])
+    np.testing.assert_allclose(np.load(out / "seed_42_te_predictions.npz")["predictions"], want, rtol=1e-6)
