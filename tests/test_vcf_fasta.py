@@ -235,3 +235,49 @@ def test_fasta_index_blank_line_inside_record(tmp_path):
     assert ix.index["c1"][2] == 8
     assert ix.fetch("c1", 6, 12) == "GTACGT" and ix.fetch("c2", 2, 6) == "AACC" and ix.length("c1") == 14
     ix.close()
+
+
+def test_format_vcf_matches_the_slop_getfasta_pipeline(tmp_path):
+    """reference src/format_VCF.sh:35-44 (`awk | bedtools slop -l 255 -r 256 | bedtools getfasta -bedOut -tab`) restated: columns, the
+    clipped interval at both chromosome ends, case kept, multi-allelic ALT passed through, header lines skipped; the written .fai
+    equals what the index reader accepts; the table feeds zero_shot's -input-table reader."""
+    import numpy as np
+    import pandas as pd
+    from plantcaduceus_amd import format_vcf, zero_shot
+    rng = np.random.default_rng(0)
+    chr1 = "".join(rng.choice(list("ACGTacgt"), size=1000))
+    chr2 = "".join(rng.choice(list("ACGT"), size=300))
+    fa = tmp_path / "ref.fa"
+    with open(fa, "w") as f:
+        for name, s in (("chr1", chr1), ("chr2", chr2)):
+            f.write(f">{name} some description\n")
+            f.writelines(s[i:i + 60] + "\n" for i in range(0, len(s), 60))
+    recs = [("chr1", 500, "A", "G"), ("chr1", 10, "C", "T"), ("chr1", 990, "G", "A,C"), ("chr2", 150, "T", "C"), ("chr1", 256, "A", "T")]
+    vcf = tmp_path / "in.vcf"
+    with open(vcf, "w") as f:
+        f.write("##fileformat=VCFv4.2\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\n")
+        for c, p, r, a in recs:
+            f.write(f"{c}\t{p}\t.\t{r}\t{a}\t.\t.\t.\n")
+    out = tmp_path / "table.tsv"
+    assert format_vcf.main([str(vcf), str(fa), str(out)]) == 0
+    lines = open(out).read().splitlines()
+    assert lines[0] == "chr\tstart\tend\tpos\tref\talt\tsequences" and len(lines) == 1 + len(recs)
+    seqs = {"chr1": chr1, "chr2": chr2}
+    for ln, (c, p, r, a) in zip(lines[1:], recs):
+        start, end = max(0, p - 1 - 255), min(len(seqs[c]), p + 256)
+        assert ln == f"{c}\t{start}\t{end}\t{p}\t{r}\t{a}\t{seqs[c][start:end]}"
+    full = lines[1].split("\t")
+    assert len(full[6]) == 512 and full[6][255] == chr1[499]                 # the variant base sits at index 255 of a full window
+    assert len(lines[2].split("\t")[6]) == 10 + 256 and len(lines[3].split("\t")[6]) == 255 + 1 + 10     # clipped, not padded
+    # the .fai written beside the FASTA is what samtools would write for this file, and the reader takes it
+    fai = [ln.split("\t") for ln in open(str(fa) + ".fai").read().splitlines()]
+    assert fai == [["chr1", "1000", "23", "60", "61"], ["chr2", "300", str(23 + 1017 + 23), "60", "61"]]
+    assert zero_shot.FastaIndex(str(fa)).fetch("chr2", 100, 110) == chr2[100:110]
+    df = pd.read_csv(out, delimiter="\t")
+    assert list(df.columns) == list(format_vcf.HEADER) and df["sequences"].iloc[0] == chr1[244:756]
+    import pytest
+    with open(vcf, "a") as f:
+        f.write("chr9\t5\t.\tA\tG\t.\t.\t.\n")
+    with pytest.raises(KeyError):
+        format_vcf.format_vcf(str(vcf), str(fa), str(out))
+    assert format_vcf.main(["only-one-arg"]) == 1
