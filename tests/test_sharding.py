@@ -207,3 +207,54 @@ def test_deferred_input_error_raises_on_every_rank(tmp_path):
     mp.spawn(_status_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     for r in range(2):
         assert "status bits 1" in (tmp_path / f"s{r}.txt").read_text()
+
+
+def _train_cli_worker(rank, ws, port, outdir, tables):
+    """one rank of a `torchrun`-style launch of `python -m plantcaduceus_amd.xgb_train` (env rendezvous, gloo, -device cpu)"""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(ws), LOCAL_RANK=str(rank))
+    from oracle import caduceus_oracle as O
+    from plantcaduceus_amd import xgb_train, zero_shot
+    from plantcaduceus_amd.checkpoint import make_config, synthetic_state_dict
+    from plantcaduceus_amd.tokenization_caduceus import CaduceusTokenizer
+    torch.set_num_threads(2)
+    cfg = make_config("x", d_model=32, n_layer=1)
+    model = O.OracleForMaskedLM(O.params_from_state_dict(synthetic_state_dict(cfg, seed=1), cfg))
+    model.config = cfg
+    zero_shot.load_model_and_tokenizer = lambda d, dev: (model, CaduceusTokenizer())
+    xgb_train.main(["-test", tables, "-model", "unused", "-output", outdir, "-device", "cpu", "-tokenIdx", "11", "-seed", "3",
+                    "-test_only", "-save_memory", "-chunk_size", "4"])
+    assert not dist.is_initialized()                       # every rank left the group (rank 0 before its host-side writing)
+    open(os.path.join(outdir, f"done_{rank}"), "w").close()
+
+
+def test_train_cli_two_ranks_equal_single_process(tmp_path):
+    """the train / test command under a 2-rank launch: each chunk's embeddings come from both ranks' blocks through one all-gather,
+    only rank 0 writes, both ranks return; files equal the single-process run's."""
+    import json
+    import pandas as pd
+    from plantcaduceus_amd import xgb_predict
+    rng = np.random.default_rng(5)
+    table = tmp_path / "te.tsv"
+    pd.DataFrame({"sequences": ["".join(rng.choice(list("ACGT"), size=24)) for _ in range(10)],
+                  "label": [0, 1] * 5}).to_csv(table, sep="\t", index=False)
+    tree = dict(left_children=[1, -1, -1], right_children=[2, -1, -1], split_indices=[5, 0, 0], split_conditions=[0.0, -1.0, 1.5],
+                default_left=[0, 0, 0], base_weights=[0.0] * 3, parents=[2147483647, 0, 0])
+    model_json = {"learner": {"objective": {"name": "binary:logistic"},
+                              "learner_model_param": {"base_score": "5E-1", "num_class": "0", "num_feature": "32"},
+                              "gradient_booster": {"name": "gbtree", "model": {"trees": [tree], "tree_info": [0]}}}, "version": [2, 0, 3]}
+    outs = {}
+    for name, ws in (("two", 2), ("one", 1)):
+        out = tmp_path / name
+        os.makedirs(out)
+        json.dump(model_json, open(out / "seed_3_XGBoost.json", "w"))
+        mp.spawn(_train_cli_worker, args=(ws, _free_port(), str(out), str(table)), nprocs=ws, join=True)
+        assert all((out / f"done_{r}").exists() for r in range(ws))
+        outs[name] = out
+    for f in ("te_chunk_0_embeddings.npz", "te_chunk_4_embeddings.npz", "te_chunk_8_embeddings.npz"):
+        np.testing.assert_array_equal(np.load(outs["two"] / f)["test"], np.load(outs["one"] / f)["test"])
+    p2, p1 = (np.load(outs[k] / "seed_3_te_predictions.npz")["predictions"] for k in ("two", "one"))
+    np.testing.assert_array_equal(p2, p1)
+    assert p2.shape == (10,) and open(outs["two"] / "seed_3_te_metrics.txt").read() == open(outs["one"] / "seed_3_te_metrics.txt").read()
+    clf = xgb_predict.XGBJsonClassifier().load_model(str(outs["one"] / "seed_3_XGBoost.json"))
+    emb = np.concatenate([np.load(outs["one"] / f"te_chunk_{i}_embeddings.npz")["test"] for i in (0, 4, 8)])
+    np.testing.assert_allclose(p1, clf.predict_proba(emb)[:, 1], rtol=1e-6)
