@@ -48,6 +48,7 @@ CYC_EXP, CYC_PK_MUL, CYC_PK_FMA = 8.62, 4.80, 5.01
 CYC_PK = 0.5 * (CYC_PK_MUL + CYC_PK_FMA)
 CYC_PAIR_MIX = 34.16
 SIMDS, CLOCK = 1024, 2.4e9
+CPU_REPEATS = 2                            # timed runs of the CPU baseline after one warm-up run (value = best, value_median beside it)
 
 
 def parse():
@@ -226,6 +227,68 @@ def box_state(torch):
     return out
 
 
+def _power_file(torch):
+    """hwmon power file (microwatts) of THIS process's GPU, or None."""
+    import ctypes
+    import glob
+    try:
+        hip = ctypes.CDLL("libamdhip64.so")
+        buf = ctypes.create_string_buffer(64)
+        hip.hipDeviceGetPCIBusId(buf, 64, torch.cuda.current_device())
+        bdf = buf.value.decode().lower()
+        for card in sorted(glob.glob("/sys/class/drm/card*")):
+            if bdf and bdf in os.path.realpath(os.path.join(card, "device")).lower():
+                for pat in ("/device/hwmon/hwmon*/power1_input", "/device/hwmon/hwmon*/power1_average"):
+                    for f in glob.glob(card + pat):
+                        float(open(f).read())
+                        return f
+    except Exception:
+        pass
+    return None
+
+
+class PowerSampler:
+    """Board power of this process's GPU sampled from sysfs on a host thread (default 20 Hz) while the timed region runs:
+    energy per window = mean power x wall time / windows.  The thread sleeps between reads; the step loop is host-idle
+    (it waits in synchronize), so the samples cost the measurement nothing."""
+
+    def __init__(self, torch, period=0.05):
+        import threading
+        self.file = _power_file(torch)
+        self.period = period
+        self.samples = []
+        self._stop = threading.Event()
+        self._thr = threading.Thread(target=self._run, daemon=True) if self.file else None
+
+    def _run(self):
+        while not self._stop.is_set():
+            try:
+                self.samples.append(float(open(self.file).read()) * 1e-6)
+            except Exception:
+                pass
+            self._stop.wait(self.period)
+
+    def start(self):
+        if self._thr:
+            self._thr.start()
+
+    def stop(self):
+        self._stop.set()
+        if self._thr:
+            self._thr.join(timeout=1.0)
+
+    def summary(self, seconds, windows):
+        if not self.samples:
+            return None
+        import statistics
+        mean = sum(self.samples) / len(self.samples)
+        return {"energy_J_per_window": mean * seconds / max(1, windows), "mean_power_W": round(mean, 1),
+                "max_power_W": round(max(self.samples), 1), "median_power_W": round(statistics.median(self.samples), 1),
+                "samples": len(self.samples), "period_s": self.period,
+                "note": "board power (sysfs hwmon of this GPU) sampled on a host thread during the timed region x wall time / "
+                        "windows of THIS rank; includes HBM and fabric, not the host"}
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -259,12 +322,10 @@ def main():
     tdt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     esz = 2 if args.dtype == "bf16" else 4
     sd = synthetic_state_dict(cfg, seed=1234, stress=False)
+    cfg.engine_options = {k: int(v) for k, v in (kv.split("=", 1) for kv in args.opt)}     # applied before the weights are bound
     eng = Engine(cfg, sd, tdt, device)
     if args.chunk_seqs:
         eng.set_option("chunk_seqs", args.chunk_seqs)
-    for kv in args.opt:
-        k, v = kv.split("=", 1)
-        eng.set_option(k, int(v))
 
     B, L, p = args.batch, args.seqlen, 255 if args.seqlen > 255 else args.seqlen // 2
     D = cfg.d_model
@@ -312,20 +373,39 @@ def main():
         out = step()
     if not args.no_profile:
         eng.profile(max(1, args.profile_stride))
+    sampler = PowerSampler(torch) if rank == 0 else None
     fence()
+    if sampler:
+        sampler.start()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step()
+    torch.cuda.synchronize()
+    dt_own = time.perf_counter() - t0                          # this rank's own K steps (before it waits for the others)
     if rank == 0:
-        box["end_of_timed_region"] = box_state(torch)          # read while the last step is still running (before the fence)
+        box["end_of_timed_region"] = box_state(torch)
     fence()
     dt = time.perf_counter() - t0
+    if sampler:
+        sampler.stop()
     eng.profile(False)
     eng.check_status()               # deferred input validation of the engine (device-side; raises on invalid ids / positions)
+    ranks_seen, per_rank = [rank], [B * args.steps / dt_own]
     if dist_on:
         t = torch.tensor([dt], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        # who actually took part: every rank contributes (rank, device ordinal, its own seq/s) through the SAME RCCL group the
+        # timed all-gathers used; rank 0 prints them, so an N-GPU line proves N ranks on N devices exchanged data
+        mine = torch.tensor([float(rank), float(torch.cuda.current_device()), B * args.steps / dt_own], dtype=torch.float64, device=device)
+        allr = torch.empty((world, 3), dtype=torch.float64, device=device)
+        dist.all_gather_into_tensor(allr, mine)
+        allr = allr.cpu().tolist()
+        ranks_seen = [int(r[0]) for r in allr]
+        per_rank = [r[2] for r in allr]
+        # and the data path itself: block r of the gathered result must be rank r's own rows (bench windows differ per rank)
+        own = out[rank * B:(rank + 1) * B]
+        assert torch.isfinite(own).all()
     assert torch.isfinite(out).all()
 
     stats = {} if args.no_profile else eng.profile_read()
@@ -352,7 +432,15 @@ def main():
                        "parallelism": "dp%d (batch-sharded, all_gather of [B,%d])" % (world, width)},
             "build_hash": eng.lib.pcad_build_hash().decode(),
             "distributed_branch_executed": bool(dist_on),
+            "rccl_ranks_seen": ranks_seen if dist_on else None,
+            "per_rank_seq_per_s": [round(v, 2) for v in per_rank],
+            "engine_options": dict(kv.split("=", 1) for kv in args.opt),
         }
+        if sampler:
+            en = sampler.summary(dt, B * args.steps)
+            if en:
+                res["energy"] = en
+                res["energy_J_per_window"] = round(en["energy_J_per_window"], 4)
         # ---- whole step against the chip peaks, from SURVEY.md §8(d)'s per-sequence counts ----------------------
         fl_seq, by_seq = per_sequence_work(cfg, L, esz)
         opts = dict(kv.split("=", 1) for kv in args.opt)
@@ -410,13 +498,15 @@ def main():
                                    "algorithmic_flops_per_launch": work[dom]["flops"]}
             else:
                 a = work[dom]["bytes_8d"] / avg_s / 1e9
-                res["roofline"] = {"kernel": dom, "bound": "hbm", "achieved": a, "peak": PEAK_HBM, "unit": "GB/s",
+                res["roofline"] = {"kernel": dom, "bound": "valu" if "valu_floor_cycles" in work[dom] else "hbm",
+                                   "achieved": a, "peak": PEAK_HBM, "unit": "GB/s",
                                    "frac": a / PEAK_HBM, "traffic": None,
                                    "algorithmic_bytes_per_launch": work[dom]["bytes_8d"],
                                    "executed_bytes": work[dom]["bytes"]}
                 if "valu_floor_cycles" in work[dom]:
-                    # the contract's bound is hbm|mfma; this kernel's limiter is neither: VALU issue + the quarter-rate
-                    # transcendental unit (PMC: VALU busy ~77 %, MFMA busy < 2 %).  Reported next to the HBM fraction:
+                    # this kernel's limiter is neither HBM nor MFMA: VALU issue + the quarter-rate transcendental unit (PMC: VALU
+                    # busy ~0.9, MFMA busy < 2 %), hence bound = "valu"; achieved / peak / frac stay the HBM figures the contract
+                    # asks for (algorithmic bytes per launch / launch time / 8 TB/s), and next to them:
                     #   valu_floor_frac  = (16 v_exp_f32 + 32 packed fp32 ops per (t, 64-channel wave) at the microbenchmarked time
                     #                      of that mix, NOTHING else) / (launch time x 1024 SIMDs x 2.4 GHz nominal)
                     #   trans_floor_frac = the 16 v_exp_f32 alone
@@ -446,6 +536,7 @@ def main():
                     if key:
                         prow = float(pj.get("rows_per_launch", 65536))
                         res["roofline"]["traffic"] = int(pj["classes"][key]["traffic_bytes_per_launch"] * rows / prow)
+                        res["roofline"]["traffic_measured"] = "offline"     # separate rocprofv3 --pmc passes on this build, not this run
                         res["roofline"]["traffic_source"] = (
                             "profiled offline on this build (src_hash %s): %s, measured at %d rows per launch%s"
                             % (sh, os.path.basename(hit[-1]), prow, "" if prow == rows else ", scaled to %d" % rows))
@@ -467,16 +558,26 @@ def main():
                 co = COracle(sd, cfg, blas=True)
                 threads = co.threads
                 if ncpu < 0:
-                    ncpu = max(2, threads // 8)                   # bounded sample: ~10-30 s of all-core CPU work
+                    ncpu = max(2, threads // 16)                  # bounded: warm-up + CPU_REPEATS runs stay within ~30 s of all-core work
                 sample = ids_np[:ncpu]
                 t1 = time.perf_counter()
-                lg, hd = co.forward(sample, want_hidden=args.workload == "embed")
-                tc = time.perf_counter() - t1
+                co.forward(ids_np[:1])                            # warm-up: OpenMP team, BLAS threads, first touch of the buffers
+                t_warm = time.perf_counter() - t1
+                times = []
+                for _ in range(CPU_REPEATS):
+                    t1 = time.perf_counter()
+                    lg, hd = co.forward(sample, want_hidden=args.workload == "embed")
+                    times.append(time.perf_counter() - t1)
+                import statistics
+                tc, tmed = min(times), statistics.median(times)
                 res["cpu_baseline"] = {"value": ncpu / tc, "unit": "sequences/s", "cores": threads, "kind": "port",
+                                       "value_median": ncpu / tmed, "repeats": len(times), "run_s": [round(t, 2) for t in times],
+                                       "warmup_s": round(t_warm, 2),
                                        "GFLOP/s": fl_seq * ncpu / tc / 1e9,
                                        "sample": "%d of the same synthetic %d-bp windows, PlantCaduceus_%s fp32, oracle/c "
                                                  "(C + OpenMP norm/conv/scan on all cores, the four projections through the "
-                                                 "host BLAS sgemm via numpy), %.1f s" % (ncpu, L, args.model, tc)}
+                                                 "host BLAS sgemm via numpy): one 1-window warm-up run, then %d timed runs; value = "
+                                                 "best (%.1f s), value_median = median" % (ncpu, L, args.model, len(times), tc)}
                 # cross-check while we are here: GPU result vs the CPU port on the sample
                 gp = out[:ncpu].float().cpu().numpy()
                 if args.workload == "embed":
@@ -487,7 +588,7 @@ def main():
                     cp = lg[np.arange(ncpu), pos_np[:ncpu] if pos_np is not None else p][:, 3:7]
                     res["cpu_baseline"]["argmax_agree"] = float((gp.argmax(1) == cp.argmax(1)).mean())
                 # the plain-C GEMM variant of the same port (no BLAS), on a smaller sample
-                n2 = max(2, ncpu // 4)
+                n2 = max(2, ncpu // 2)
                 t1 = time.perf_counter()
                 COracle(sd, cfg).forward(ids_np[:n2])
                 t2 = time.perf_counter() - t1

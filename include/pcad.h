@@ -106,9 +106,24 @@ void   pcad_destroy(pcad_handle h);
  *                 before it is added; in_proj's operand is round(res) instead of round(res * rstd * w)).  Used for chunks whose
  *                 token-rows are whole 256-row tiles (a d_model that is not a multiple of 256 - PlantCaduceus_l20's 384 - is padded
  *                 to the next one inside the workspace) with an fp32 residual stream,
- *                 never by pcad_forward_all_hidden (+4.5 % end to end, same-box A/B, profiles/r04_ab_runs.txt);
+ *                 never by pcad_forward_all_hidden (+4.5 % end to end, same-box A/B, profiles/r04_ab_runs.txt).  Decided once
+ *                 per pcad_forward call: every chunk of the batch runs folded or none does.  The form needs extra weight copies
+ *                 (+37 % of the arena at l32) that are carved and packed only if the options in force at
+ *                 pcad_weight_arena_bytes / pcad_bind_weights time ask for it: set "norm_fold" 1 on an fp32 model BEFORE those
+ *                 calls (afterwards pcad_forward refuses); turning it off later is always possible;
  *                 0 (default for the fp32 model, whose 1e-4 parity budget would pay for accumulating onto the residual: 2.2e-5 of
  *                 max after 32 layers instead of 1.3e-6): the reference's operation order (one add + RMSNorm launch per block).
+ *   "reference_order"  one switch over the options above, for users who want every rounding point where the reference has it
+ *                 (BiMambaWrapper "add" of two Mamba calls, rms_norm_fn(prenorm=True, residual_in_fp32=True), mamba_inner_fn):
+ *                 0 (default): the engine's defaults ("gate_each" 0, "norm_fold" default, layer 0's in_proj as a table);
+ *                 1: "gate_each" 1 + "norm_fold" 0 (hence no layer-0 table) - the only reordering left is the tied out_proj applied
+ *                    once to y_fwd + y_rev (linearity) instead of once per direction;
+ *                 2: strict - additionally each direction's scan output gets its own tied out_proj launch, each result is stored in
+ *                    the model dtype, and the two are added and rounded, exactly BiMambaWrapper's `out + out_rev`: the rounding
+ *                    points of oracle/c "ref_order".  What remains different from the reference is fp32 summation order inside the
+ *                    GEMMs / scan and the exp / log implementations - the noise any two BLAS libraries have between them.
+ *                 Cost at l32 bf16 (same box, profiles/r05_*): see INTEGRATION.md "Operation order".  Setting "gate_each" /
+ *                 "norm_fold" afterwards overrides the respective part; level 2 is ignored while "norm_fold" is forced to 1.
  *   "scan_segments"  1 (default): when a launch has few scan waves (at most 768 for L >= 2 048: PlantCAD2's 8 192-bp windows in small
  *                 batches; at most 512 for shorter windows: up to 8 windows of 512 bp at l32) the scan of every strand is cut into up to 8 segments that run as
  *                 separate workgroups (zero-state pass, carry, real pass: ~1.8x the arithmetic for up to 8x the parallelism;
@@ -132,7 +147,8 @@ int    pcad_set_option(pcad_handle h, const char* key, int64_t value);
 enum pcad_status_bits { PCAD_STATUS_BAD_TOKEN = 1, PCAD_STATUS_BAD_POSITION = 2 };
 int    pcad_set_status_buffer(pcad_handle h, int32_t* status);
 
-/* Bytes of caller-owned device memory that pcad_bind_weights packs the model into. */
+/* Bytes of caller-owned device memory that pcad_bind_weights packs the model into (depends on "norm_fold" / "reference_order" as set
+ * when it is called: query it after the options, right before binding). */
 size_t pcad_weight_arena_bytes(pcad_handle h);
 
 /* Pack the reference-named tensors (fp32 or bf16, device pointers) into `arena` in the engine's layouts

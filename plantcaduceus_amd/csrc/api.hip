@@ -73,10 +73,13 @@ struct pcad_engine {
     bool blocked;   // xc and y in the blocked layout (common.hpp::blocked_off); PCAD_PLAIN_LAYOUT=1 turns it off (A/B knob)
     bool segments = true;  // pcad_set_option("scan_segments", 0): never cut the scan of long strands into segments
     bool shortcut = true;  // pcad_set_option("last_layer_shortcut", 0): run the last layer in full even when only a few positions are evaluated
+    int ref_order = 0;      // pcad_set_option("reference_order", 0 / 1 / 2): see include/pcad.h; 2 = each direction's tied out_proj on its own
     int norm_fold = -1;     // pcad_set_option("norm_fold", 0 / 1); -1 (default): on for the bf16 model, off for the fp32 model (forward_impl)
     int rep_class = -1, rep_count = 1;   // pcad_set_option("debug_repeat_class" / "debug_repeat"): measurement aid, see forward_impl
     bool poison = false;   // pcad_set_option("poison_workspace", 1): debug — fill the workspace with 0xFF (NaN patterns) before every forward
     bool bound = false;
+    bool fold_packed = false;   // the norm-folded form's extra weight copies (W_in_f, xz_tab0, padded W_out) exist in the arena: decided
+                                // from the options in force when pcad_weight_arena_bytes / pcad_bind_weights run (fold_wanted)
     int32_t* status = nullptr;   // caller-owned device word for asynchronous input-validation flags (pcad_set_status_buffer)
     std::vector<LayerWeights> layers;
     void* xz_tab0 = nullptr;    // [V, 2E] dtype: layer 0's in_proj output per token id (norm-folded form), built at bind time
@@ -108,21 +111,30 @@ struct Carver {
     }
 };
 
+// whether the options ask for the norm-folded layer form on this model at all (per-forward shape conditions come on top)
+bool fold_wanted(const pcad_engine* e) {
+    const bool want = e->norm_fold == 1 || (e->norm_fold < 0 && e->cfg.dtype == PCAD_BF16);
+    return want && e->rdt == F32 && e->xzsplit && e->blocked;
+}
+
 void carve_weights(pcad_engine* e, Carver& c) {
     const size_t D = e->D, E = e->E, N = e->N, V = e->V, esz = e->esz;
+    // the folded form's copies (a second in_proj weight per layer, the layer-0 table, out_proj padded to 256 rows) are carved only
+    // when the fold can engage: +37 % of the arena at l32 that an fp32 model or "norm_fold" 0 / "reference_order" never reads
+    const bool pf = fold_wanted(e);
     e->emb = c.take(V * D * esz);
     e->emb_f32 = (float*)c.take(V * D * 4);
     e->normf_w = (float*)c.take(D * 4);
     e->comp = (int32_t*)c.take(8 * 4);
-    e->xz_tab0 = c.take(V * 2 * E * esz);
+    e->xz_tab0 = pf ? c.take(V * 2 * E * esz) : nullptr;
     e->layers.resize(e->nl);
     for (auto& L : e->layers) {
         L.norm_w = (float*)c.take(D * 4);
         L.convw = (float*)c.take(convx_packed_bytes((int)E, e->cfg.dtype));
         L.W_in = c.take(2 * E * D * esz);
-        L.W_in_f = c.take(2 * E * D * esz);
+        L.W_in_f = pf ? c.take(2 * E * D * esz) : nullptr;
         L.W_out = c.take(D * E * esz);
-        L.W_out_p = (size_t)fold_padded_width((int)D) != D ? c.take((size_t)fold_padded_width((int)D) * E * esz) : L.W_out;
+        L.W_out_p = pf && (size_t)fold_padded_width((int)D) != D ? c.take((size_t)fold_padded_width((int)D) * E * esz) : L.W_out;
         for (int d = 0; d < 2; ++d) {
             DirWeights& w = L.dir[d];
             w.conv_w = (float*)c.take(E * 4 * 4);
@@ -280,6 +292,15 @@ int pcad_set_option(pcad_handle h, const char* key, int64_t value) {
         h->gate_once = value == 0;
     } else if (k == "norm_fold") {
         h->norm_fold = value < 0 ? -1 : (value != 0 ? 1 : 0);
+    } else if (k == "reference_order") {
+        // one switch for "every rounding point where the reference has it" (BiMambaWrapper + rms_norm_fn + mamba_inner_fn):
+        //   1  = gate_each 1 + norm_fold 0 (which also means no layer-0 in_proj table): only the tied out_proj fold remains
+        //   2  = 1 + each direction's out_proj computed and stored in the model dtype, then summed and rounded ("add" strategy)
+        //   0  = the engine's defaults
+        if (value < 0 || value > 2) return fail(PCAD_ERR_INVALID, "reference_order=%lld out of range (0, 1, 2)", (long long)value);
+        h->ref_order = (int)value;
+        h->gate_once = value == 0;
+        h->norm_fold = value == 0 ? -1 : 0;
     } else if (k == "debug_repeat_class") {
         if (value < -1 || value >= PCAD_NUM_KERNEL_CLASSES) return fail(PCAD_ERR_INVALID, "debug_repeat_class=%lld out of range", (long long)value);
         h->rep_class = (int)value;
@@ -364,7 +385,7 @@ int pcad_bind_weights(pcad_handle h, const pcad_tensor* tensors, int n, void* ar
         const std::string mf = lp + "mixer.submodule.mamba_fwd.";
         NEED(t_in, mf + "in_proj.weight", (int64_t)2 * E * D);
         HIP_TRY(launch_pack2d(t_in->data, t_in->dtype, D, L.W_in, dt, D, 2 * E, D, 2 * E, D, s));
-        HIP_TRY(launch_pack_scale_cols(t_in->data, t_in->dtype, D, L.norm_w, L.W_in_f, dt, D, 2 * E, D, s));
+        if (L.W_in_f) HIP_TRY(launch_pack_scale_cols(t_in->data, t_in->dtype, D, L.norm_w, L.W_in_f, dt, D, 2 * E, D, s));
         NEED(t_out, mf + "out_proj.weight", (int64_t)D * E);
         HIP_TRY(launch_pack2d(t_out->data, t_out->dtype, E, L.W_out, dt, E, D, E, D, E, s));
         if (L.W_out_p != L.W_out) HIP_TRY(launch_pack2d(t_out->data, t_out->dtype, E, L.W_out_p, dt, E, D, E, fold_padded_width(D), E, s));
@@ -395,7 +416,8 @@ int pcad_bind_weights(pcad_handle h, const pcad_tensor* tensors, int n, void* ar
     }
 #undef NEED
     // layer 0's in_proj (norm-folded form) as a table over the V token ids: emb and layer 0's folded in_proj weight are packed above
-    HIP_TRY(launch_embed_inproj_table(e->emb, e->layers[0].W_in_f, e->xz_tab0, V, D, 2 * E, e->cfg.eps, dt, s));
+    if (e->xz_tab0) HIP_TRY(launch_embed_inproj_table(e->emb, e->layers[0].W_in_f, e->xz_tab0, V, D, 2 * E, e->cfg.eps, dt, s));
+    e->fold_packed = fold_wanted(e);
     e->bound = true;
     return PCAD_OK;
 }
@@ -476,11 +498,19 @@ static int forward_impl(pcad_handle h, const int32_t* ids, int B, int L, const i
     // is padded to the next one with zero out_proj weight rows and zero residual columns) and the residual stream is fp32; never
     // for pcad_forward_all_hidden
     // (hidden_states[i] are the mixer outputs h, which the folded form never materialises).
-    auto fold_for = [&](const Lane& c) -> bool {
-        const bool want = e->norm_fold == 1 || (e->norm_fold < 0 && dt == BF16);
-        return want && !all_hidden && rdt == F32 && e->xzsplit && e->blocked &&
-               gemm_fold_shapes_ok((int64_t)2 * c.Bc * L, D, E, dt);
-    };
+    // Decided ONCE per forward - every chunk folds or none does - so that a result never depends on how the batch was cut
+    // into chunks (an uneven split of odd-length windows could otherwise give one chunk whole 256-row tiles and another not).
+    if (fold_wanted(e) && !e->fold_packed) {
+        if (e->norm_fold == 1)
+            return fail(PCAD_ERR_INVALID, "pcad_forward: \"norm_fold\" 1 was set after pcad_bind_weights; the folded form's weight copies are "
+                                          "packed at bind time - set the option before pcad_weight_arena_bytes / pcad_bind_weights");
+    }
+    bool fold_all = fold_wanted(e) && e->fold_packed && !all_hidden;
+    for (int ck = 0; ck < nchunks && fold_all; ++ck) {
+        const int Bc = (B - ck * chunk) < chunk ? (B - ck * chunk) : chunk;
+        fold_all = gemm_fold_shapes_ok((int64_t)2 * Bc * L, D, E, dt);
+    }
+    auto fold_for = [&](const Lane&) -> bool { return fold_all; };
     // Measurement aid (tools/power_probe.py): every launch of ONE kernel class is issued `debug_repeat` times back to back, so a
     // forward becomes seconds of that kernel - the engine's own instantiation, layouts and launch sizes - while the host samples
     // board power and clocks.  Only launches that are idempotent are repeated (in_proj, conv + x_proj, the forward-direction scan,
@@ -562,6 +592,10 @@ static int forward_impl(pcad_handle h, const int32_t* ids, int B, int L, const i
         const int S = 2 * c.Bc;
         const int64_t rows = (int64_t)S * L;
         const bool last_short = walk_len > 0 && li + 1 == e->nl;
+        // strict reference order ("reference_order" 2; never with norm_fold): the reverse direction's gated output goes to its own
+        // tensor (xc[0]: the forward scan, its only reader, has run) and each direction gets its own tied out_proj below
+        const bool strict = e->ref_order == 2 && !c.fold;
+        void* y_rev = strict ? c.w.xc[0] : c.w.y;
         for (int d = 0; d < 2; ++d) {
             const DirWeights& dw = W.dir[d];
             // x_proj -> dt_low [rows, Rp] (model dtype, zero padded) and B_t | C_t [rows, 32] (fp32 side output)
@@ -577,10 +611,35 @@ static int forward_impl(pcad_handle h, const int32_t* ids, int B, int L, const i
             // gate_once: the forward scan stores its ungated output, the reverse scan adds its own and applies SiLU(z)
             // to the sum (one SiLU per element instead of two, z read once; a rounding-order difference from
             // y_f*g + y_r*g, like the out_proj fold below).  PCAD_GATE_EACH=1: each direction gated and rounded.
-            const bool gated = !e->gate_once || d == 1;
+            const bool gated = strict || !e->gate_once || d == 1;
             HIP_TRY(launch_scan(c.w.xc[d], gated ? zp : nullptr, e->xzsplit ? E : 2 * E, nullptr, c.w.dtl[d], Rp, dw.Wdt, Rp,
-                                c.w.bc[d], dw.A2, 1.0f, dw.Dskip, dw.dt_bias, c.w.y, S, L, E, d == 1,
-                                d == 1 ? (e->gate_once ? 2 : 1) : 0, dt, s, e->blocked, e->xzsplit, c.w.seg, last_short ? walk_len : 0));
+                                c.w.bc[d], dw.A2, 1.0f, dw.Dskip, dw.dt_bias, d == 1 ? y_rev : c.w.y, S, L, E, d == 1,
+                                strict ? 0 : (d == 1 ? (e->gate_once ? 2 : 1) : 0), dt, s, e->blocked, e->xzsplit, c.w.seg, last_short ? walk_len : 0));
+        }
+        if (strict) {
+            // out = round(out_proj(y_fwd)) + round(out_proj(y_rev)), rounded: BiMambaWrapper's "add" of two Mamba calls that each end
+            // in their own (tied) out_proj.  Second output: u (dead since in_proj); last-layer shortcut: the gathered rows go
+            // through u, the second small output to xz (dead since the scans).
+            if (last_short) {
+                ProfScope ps(e, PCAD_K_HEAD, s);
+                HIP_TRY(launch_gather_rows(c.w.y, c.w.u, c.Bc, L, E, pos, dt, e->blocked, s));
+                HIP_TRY(launch_gemm_nt(c.w.u, E, W.W_out, E, c.w.h, D, (int64_t)S * P, D, E, dt, dt, false, s, false));
+                HIP_TRY(launch_gather_rows(y_rev, c.w.u, c.Bc, L, E, pos, dt, e->blocked, s));
+                HIP_TRY(launch_gemm_nt(c.w.u, E, W.W_out, E, c.w.xz, D, (int64_t)S * P, D, E, dt, dt, false, s, false));
+                HIP_TRY(launch_add_round(c.w.h, c.w.xz, (int64_t)S * P * D, dt, s));
+                return PCAD_OK;
+            }
+            { ProfScope ps(e, PCAD_K_GEMM_OUT, s);
+            HIP_TRY(launch_gemm_nt(c.w.y, E, W.W_out, E, c.w.h, D, rows, D, E, dt, dt, false, s, e->blocked)); }
+            { ProfScope ps(e, PCAD_K_GEMM_OUT, s);
+            HIP_TRY(launch_gemm_nt(y_rev, E, W.W_out, E, c.w.u, D, rows, D, E, dt, dt, false, s, e->blocked)); }
+            { ProfScope ps(e, PCAD_K_NORM, s);
+            HIP_TRY(launch_add_round(c.w.h, c.w.u, rows * D, dt, s)); }
+            if (all_hidden && li + 1 < e->nl) {
+                char* dst = (char*)all_hidden + ((size_t)(li + 1) * B * L * 2 * D + (size_t)c.b0 * L * 2 * D) * esz;
+                HIP_TRY(launch_assemble_hidden(c.w.h, dst, c.Bc, L, D, dt, s));
+            }
+            return PCAD_OK;
         }
         if (last_short) {       // out_proj on the evaluated rows only: gather (-> u, dead since in_proj) and a small GEMM (-> first rows of h)
             ProfScope ps(e, PCAD_K_HEAD, s);          // counted with the head: not a full-size out_proj launch

@@ -640,6 +640,31 @@ template <int OFF> __device__ __forceinline__ void gload_a128(f32x4& dst, uint32
     asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3 nt" : "=a"(dst) : "v"(vo), "s"(sb), "n"(OFF));
 }
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+// The same wait TIED to the registers it guards: the asm formally rewrites them, so every later reader (the MFMAs that accumulate
+// into an accumulator row, the epilogue's multiplies by the row factors) depends on the wait and cannot be scheduled, copied or
+// spilled across it; tools/isa_census.py --check-res-waits verifies the emitted order after every build.
+template <int N> __device__ __forceinline__ void wait_vmcnt_row(f32x4 (&c)[8]) {
+    asm volatile("s_waitcnt vmcnt(%8)"
+                 : "+a"(c[0]), "+a"(c[1]), "+a"(c[2]), "+a"(c[3]), "+a"(c[4]), "+a"(c[5]), "+a"(c[6]), "+a"(c[7])
+                 : "n"(N)
+                 : "memory");
+}
+template <int N> __device__ __forceinline__ void wait_vmcnt_regs(float (&v)[8]) {
+    asm volatile("s_waitcnt vmcnt(%8)"
+                 : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7])
+                 : "n"(N)
+                 : "memory");
+}
+// EPI_RES's first k-step: the 64 residual loads of a tile are issued in accumulator-row order (8 per row: load_res_group x2) right
+// before it, and every row of the k-step issues exactly ONE LDS-DMA piece (slot kDmaSlot); when row r is about to accumulate into
+// acc[r][*], younger than ITS eight loads are the loads of rows r+1..7 and the DMA pieces of rows 0..r-1 (vector memory
+// operations of one type return in order on gfx950), hence:
+constexpr int kResLoadsPerRow = 8;      // load_res_group(tb, i, 0) + load_res_group(tb, i, 1): 2 x 4 global_load_dwordx4
+constexpr int kDmaPerRow = 1;           // kstep: `if (k == kDmaSlot) dma(r)`
+constexpr int kDmaSlot = 1;
+constexpr int res_row_wait(int r) { return (7 - r) * kResLoadsPerRow + r * kDmaPerRow; }
+static_assert(res_row_wait(0) == 56 && res_row_wait(1) == 49 && res_row_wait(6) == 14 && res_row_wait(7) == 7, "EPI_RES row waits");
+static_assert(res_row_wait(0) < 64, "s_waitcnt vmcnt is a 6-bit field");
 template <int OFF> __device__ __forceinline__ void gload_v32(float& dst, uint32_t vo, const float* sb) {
     asm volatile("global_load_dword %0, %1, %2 offset:%3" : "=v"(dst) : "v"(vo), "s"(sb), "n"(OFF));
 }
@@ -802,9 +827,10 @@ __global__ __launch_bounds__(GEMMQ_THREADS, 1) void gemm256q_kernel(const T* __r
                 // row r multiplies into acc[r][0..7], whose 8 residual loads were issued in row order just before this k-step:
                 // younger than them are the loads of rows r+1..7 (8 each) and this k-step's DMA pieces 0..r-1
                 switch (r) {
-                    case 0: wait_vmcnt<56>(); break; case 1: wait_vmcnt<49>(); break; case 2: wait_vmcnt<42>(); break;
-                    case 3: wait_vmcnt<35>(); break; case 4: wait_vmcnt<28>(); break; case 5: wait_vmcnt<21>(); break;
-                    case 6: wait_vmcnt<14>(); break; default: wait_vmcnt<7>(); break;
+                    case 0: wait_vmcnt_row<res_row_wait(0)>(acc[0]); break; case 1: wait_vmcnt_row<res_row_wait(1)>(acc[1]); break;
+                    case 2: wait_vmcnt_row<res_row_wait(2)>(acc[2]); break; case 3: wait_vmcnt_row<res_row_wait(3)>(acc[3]); break;
+                    case 4: wait_vmcnt_row<res_row_wait(4)>(acc[4]); break; case 5: wait_vmcnt_row<res_row_wait(5)>(acc[5]); break;
+                    case 6: wait_vmcnt_row<res_row_wait(6)>(acc[6]); break; default: wait_vmcnt_row<res_row_wait(7)>(acc[7]); break;
                 }
             }
 #pragma unroll
@@ -816,7 +842,7 @@ __global__ __launch_bounds__(GEMMQ_THREADS, 1) void gemm256q_kernel(const T* __r
                 }
                 // slot k of row r: W' in rows 0-3, A' in rows 4-6, ONE DMA piece per row (4 waves x 1 KiB every 8 MFMAs keeps
                 // the CU's L1 half busy; all eight pieces within rows 0-3 saturated it and stalled the issue: TA stalled-by-TC x7)
-                if (k == 1) dma(r);
+                if (k == kDmaSlot) dma(r);
                 else if (r < 4) {
                     if (k == 0) ldw(2 * r);
                     else if (k == 2) ldw(2 * r + 1);
@@ -865,6 +891,12 @@ __global__ __launch_bounds__(GEMMQ_THREADS, 1) void gemm256q_kernel(const T* __r
         const int64_t mrow = m0 + wm * 128 + li;
         float ss[8];
         float* res_tb = nullptr;
+        if constexpr (EPI == EPI_SCALE) {
+            // the row factors were requested when the tile started, >= one K-tile ago: behind every counted `vmcnt(8)` of the mainloop
+            // they have landed (at most the 16 youngest operations - this K-tile's LDS-DMAs - are in flight here), so this wait never stalls; it exists to
+            // make the multiplies below DEPEND on a wait that covers their operands
+            wait_vmcnt_regs<16>(rs);
+        }
         if constexpr (EPI == EPI_RES) {
 #pragma unroll
             for (int i = 0; i < 8; ++i) ss[i] = 0.f;

@@ -52,6 +52,8 @@ hipError_t launch_final_head(const void* h, const void* res, const float* w, con
 hipError_t launch_assemble_hidden(const void* h, void* out, int B, int L, int D, int dt, hipStream_t s);
 hipError_t launch_embed_only(const int32_t* ids, const void* emb, const int32_t* comp8, void* h, int B, int L,
                              int D, int dt, hipStream_t s);
+// a[i] = round_dt(a[i] + b[i]), n % 8 == 0: the sum of the two directions' out_proj outputs (strict reference order only)
+hipError_t launch_add_round(void* a, const void* b, int64_t n, int dt, hipStream_t s);
 
 // gemm.hip --------------------------------------------------------------------------------------
 // C[M,N] = A[M,K] W[N,K]^T.  K multiple of 128 bytes; lda/ldw multiples of 16 bytes.

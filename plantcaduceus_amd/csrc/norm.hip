@@ -330,6 +330,33 @@ hipError_t launch_final_head(const void* h, const void* res, const float* w, con
 }
 
 // ------------------------------------------------------------------------------------------------
+// a = round(a + b) elementwise in the model dtype: BiMambaWrapper's `out + out_rev` (bidirectional_strategy "add") on the two
+// directions' out_proj outputs, each already stored in the model dtype - only the strict reference-order form
+// (pcad_set_option("reference_order", 2)) materialises them separately.
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void add_round_kernel(T* __restrict__ a, const T* __restrict__ b, int64_t nchunk) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nchunk; i += (int64_t)gridDim.x * blockDim.x) {
+        float x[8], y[8];
+        load8<T>(a + i * 8, x);
+        load8<T>(b + i * 8, y);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) x[k] += y[k];
+        store8<T>(a + i * 8, x);
+    }
+}
+
+hipError_t launch_add_round(void* a, const void* b, int64_t n, int dt, hipStream_t s) {
+    if (n <= 0) return hipSuccess;
+    if (n % 8) return hipErrorInvalidValue;
+    const int64_t nchunk = n / 8;
+    const unsigned grid = (unsigned)((nchunk + 255) / 256 > 16384 ? 16384 : (nchunk + 255) / 256);
+    if (dt == BF16) hipLaunchKernelGGL(add_round_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (bf16_t*)a, (const bf16_t*)b, nchunk);
+    else hipLaunchKernelGGL(add_round_kernel<float>, dim3(grid), dim3(256), 0, s, (float*)a, (const float*)b, nchunk);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
 // hidden_states[i] in the reference's RCPS layout from the 2B-strand tensor:
 // out[b,l,:D] = h[b,l,:] ; out[b,l,D+j] = h[B+b, L-1-l, D-1-j]
 // ------------------------------------------------------------------------------------------------

@@ -433,7 +433,8 @@ static hipError_t launch_scan_t(const void* u, const void* z, int64_t ldz, const
     if constexpr (FUSED) {
         int sb = 0;
         const int G = seg_ws ? scan_segments(S, L, E, &sb) : 1;
-        const bool combo = (!reverse && accumulate == 0) || (reverse && accumulate == 2 && hz) || (reverse && accumulate == 1 && hz);
+        const bool combo = (!reverse && accumulate == 0) || (reverse && accumulate == 2 && hz) || (reverse && accumulate == 1 && hz) ||
+                           (reverse && accumulate == 0 && hz);
         if (G > 1 && combo) {
             dim3 gseg((unsigned)(E / 64), (unsigned)(S * G));
 #define PCAD_SEG(REV, ACC, HZ, SEGM, ZP)                                                                                  \
@@ -442,7 +443,8 @@ static hipError_t launch_scan_t(const void* u, const void* z, int64_t ldz, const
             hipLaunchKernelGGL(scan_carry_kernel, dim3((unsigned)(((int64_t)S * E + 255) / 256)), dim3(256), 0, s, seg_ws, A2, a_scale, S, G, E);
             if (!reverse) { if (hz) PCAD_SEG(false, 0, true, 2, z); else PCAD_SEG(false, 0, false, 2, nullptr); }
             else if (accumulate == 2) PCAD_SEG(true, 2, true, 2, z);
-            else PCAD_SEG(true, 1, true, 2, z);
+            else if (accumulate == 1) PCAD_SEG(true, 1, true, 2, z);
+            else PCAD_SEG(true, 0, true, 2, z);
 #undef PCAD_SEG
             return hipGetLastError();
         }

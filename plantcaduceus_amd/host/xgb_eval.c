@@ -24,6 +24,13 @@ int pcad_xgb_margin(const float* X, int64_t rows, int64_t ldx, int32_t n_feature
     if (rows < 0 || n_trees < 0 || ldx < n_features || (rows > 0 && (!X || !out)) ||
         (n_trees > 0 && (!tree_off || !left || !right || !feat || !cond || !dleft)))
         return -1;
+    /* cheap pre-pass: a split feature outside [0, n_features) of an internal node would read outside the row (the Python loader
+     * validates trees too; this entry point must not trust its caller) */
+    if (n_trees > 0) {
+        const int64_t n_nodes = tree_off[n_trees];
+        for (int64_t k = 0; k < n_nodes; ++k)
+            if (left[k] != -1 && (feat[k] < 0 || feat[k] >= n_features)) return -1;
+    }
 #pragma omp parallel for schedule(dynamic, 1)
     for (int64_t r0 = 0; r0 < rows; r0 += ROW_BLOCK) {
         const int64_t r1 = r0 + ROW_BLOCK < rows ? r0 + ROW_BLOCK : rows;

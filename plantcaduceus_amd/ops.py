@@ -5,6 +5,8 @@ MI355X HIP kernels through the C ABI.  Same names, argument meaning and layouts 
   rms_norm_fn(x, weight, bias, residual, eps, prenorm, residual_in_fp32)   mamba_ssm.ops.triton.layer_norm
   causal_conv1d_fn(x, weight, bias, activation)                            causal_conv1d 1.4.0
   selective_scan_fn(u, delta, A, B, C, D, z, delta_bias, delta_softplus)   mamba_ssm 2.2.2
+  mamba_inner_fn(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, out_proj_weight, out_proj_bias, A, ...)
+                                                                           mamba_ssm 2.2.2 (the call Mamba.forward's fast path makes)
   linear(x, weight)                                                        F.linear (no bias)
 
 Inputs use the reference's channels-first (B, E, L) layout where the originals do; they are transposed
@@ -82,12 +84,8 @@ def from_blocked(xb: torch.Tensor, rows: int) -> torch.Tensor:
     return xb.permute(0, 2, 1, 3).reshape(nb * 8, pieces * per)[:rows].contiguous()
 
 
-def conv_xproj_bidir(x_tm, w_fwd, b_fwd, w_rev, b_rev, x_proj_fwd, x_proj_rev):
-    """The engine's fused head of mamba_inner_fn, both directions from one read of x:
-        xc_d    = causal_conv1d_fn(x, w_d, b_d, "silu")        (d = rev: anti-causal on the same rows)
-        x_dbl_d = F.linear(xc_d, x_proj_d)                     (stored in the model dtype)
-    x_tm [S, L, E]; w_* [E, 4]; b_* [E]; x_proj_* [R + 32, E] with R <= 96.
-    Returns (xc_fwd, xc_rev [S, L, E], x_dbl_fwd, x_dbl_rev [S, L, R + 32]) in x's dtype."""
+def _conv_xproj_raw(x_tm, w_fwd, b_fwd, w_rev, b_rev, x_proj_fwd, x_proj_rev):
+    """pcad_conv_xproj_bidir on a token-major x [S, L, E]: -> (xc [2] blocked, dtl [2] [rows, Rp], bc [2] fp32 [rows, 32], R, Rp)."""
     _require_gpu(x_tm, "x")
     lib = load_library()
     S, L, E = x_tm.shape
@@ -117,6 +115,19 @@ def conv_xproj_bidir(x_tm, w_fwd, b_fwd, w_rev, b_rev, x_proj_fwd, x_proj_rev):
                                          xc[0].data_ptr(), dtl[0].data_ptr(), bc[0].data_ptr(),
                                          xc[1].data_ptr(), dtl[1].data_ptr(), bc[1].data_ptr(),
                                          S, L, E, Rp, _DT[dt], _stream_ptr()), "pcad_conv_xproj_bidir")
+    return xc, dtl, bc, R, Rp
+
+
+def conv_xproj_bidir(x_tm, w_fwd, b_fwd, w_rev, b_rev, x_proj_fwd, x_proj_rev):
+    """The engine's fused head of mamba_inner_fn, both directions from one read of x:
+        xc_d    = causal_conv1d_fn(x, w_d, b_d, "silu")        (d = rev: anti-causal on the same rows)
+        x_dbl_d = F.linear(xc_d, x_proj_d)                     (stored in the model dtype)
+    x_tm [S, L, E]; w_* [E, 4]; b_* [E]; x_proj_* [R + 32, E] with R <= 96.
+    Returns (xc_fwd, xc_rev [S, L, E], x_dbl_fwd, x_dbl_rev [S, L, R + 32]) in x's dtype."""
+    S, L, E = x_tm.shape
+    dt = x_tm.dtype
+    rows = S * L
+    xc, dtl, bc, R, Rp = _conv_xproj_raw(x_tm, w_fwd, b_fwd, w_rev, b_rev, x_proj_fwd, x_proj_rev)
     outs = [from_blocked(c, rows).view(S, L, E) for c in xc]
     dbl = [torch.cat([dtl[d][:, :R], bc[d].to(dt)], dim=1).view(S, L, R + 32) for d in range(2)]
     return outs[0], outs[1], dbl[0], dbl[1]
@@ -200,6 +211,76 @@ def selective_scan_dtproj_fn(u, dt_low, dt_proj_weight, A, B, C, D=None, z=None,
                                               int(bool(reverse)), _acc_mode(accumulate_into, gate_sum), _dt(u_tm),
                                               _stream_ptr()), "pcad_selective_scan_dtproj")
     return y.transpose(1, 2)
+
+
+def mamba_inner_fn(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, out_proj_weight, out_proj_bias,
+                   A, B=None, C=None, D=None, delta_bias=None, B_proj_bias=None, C_proj_bias=None, delta_softplus=True,
+                   reverse=False):
+    """`mamba_ssm.ops.selective_scan_interface.mamba_inner_fn` (mamba-ssm 2.2.2, reference env/requirements.txt:10) - the ONE call
+    `Mamba.forward`'s fast path makes after in_proj - under its own signature, on the engine's kernels:
+
+        x, z    = xz.chunk(2, dim=1)                                        xz (B, 2E, L) channels-first, as upstream
+        xc      = causal_conv1d_fn(x, conv1d_weight, conv1d_bias, "silu")   \  pcad_conv_xproj_bidir (one kernel; dt_rank <= 96),
+        x_dbl   = F.linear(xc^T, x_proj_weight)          (R + 2N columns)   /  else pcad_causal_conv1d_silu + pcad_gemm_nt
+        delta   = delta_proj_weight @ x_dbl[:, :R]^T                        \  pcad_selective_scan_dtproj (dt_proj on MFMA inside
+        y       = selective_scan_fn(xc, delta, A, B_t, C_t, D, z, delta_bias, delta_softplus=True)   /  the scan; delta never stored)
+        return    F.linear(y^T, out_proj_weight)                               pcad_gemm_nt            -> (B, L, D)
+
+    conv1d_weight (E, 1, 4) or (E, 4); x_proj_weight (R + 32, E); delta_proj_weight (E, R); out_proj_weight (D, E);
+    A (E, 16) = -exp(A_log) as upstream passes it; D, delta_bias (E).  B / C must be None (input-dependent, taken from x_dbl - the only
+    form Mamba.forward uses), likewise the projection biases and out_proj_bias (Caduceus builds Mamba with bias=False).
+    reverse=True is the twin BiMambaWrapper needs for `mamba_rev`: the same operator walking right-to-left with the anti-causal
+    conv on the SAME rows, i.e. mamba_inner_fn(xz, ..., reverse=True) == mamba_inner_fn(xz.flip(-1), ...).flip(1) without either
+    flip copy.  Tensors are ROCm tensors in one dtype (fp32 or bf16); parameters are converted as the engine's
+    weight packing does (conv taps, A, D, biases to fp32; projections to xz.dtype)."""
+    _require_gpu(xz, "xz")
+    if B is not None or C is not None:
+        raise NotImplementedError("constant B / C are not on the Caduceus path (Mamba.forward passes None: input-dependent B, C)")
+    if out_proj_bias is not None or B_proj_bias is not None or C_proj_bias is not None:
+        raise NotImplementedError("projection biases are not on the Caduceus path (Mamba(bias=False))")
+    if not delta_softplus:
+        raise NotImplementedError("the Caduceus path always uses delta_softplus=True")
+    lib = load_library()
+    Bsz, E2, L = xz.shape
+    E = E2 // 2
+    dt, dev = xz.dtype, xz.device
+    if A.shape != (E, 16):
+        raise ValueError(f"A must be (d_inner, 16), got {tuple(A.shape)}")
+    R = delta_proj_weight.shape[1]
+    if x_proj_weight.shape != (R + 32, E):
+        raise ValueError(f"x_proj_weight must be (dt_rank + 2 * 16, d_inner) = ({R + 32}, {E}), got {tuple(x_proj_weight.shape)}")
+    w = conv1d_weight.reshape(E, -1)
+    if w.shape[1] != 4:
+        raise NotImplementedError("only conv width 4")
+    bias = conv1d_bias if conv1d_bias is not None else torch.zeros(E, device=dev)
+    x_tm = xz[:, :E].transpose(1, 2).contiguous()                    # the engine is token-major (test plumbing: it never transposes)
+    z_tm = xz[:, E:].transpose(1, 2).contiguous()
+    rows = Bsz * L
+    d = 1 if reverse else 0
+    fused = R <= 96 and (E * xz.element_size()) % 128 == 0 and (rows + 16) * E * xz.element_size() < 2 ** 32
+    if fused:
+        xc_b, dtl, bc, _, Rp = _conv_xproj_raw(x_tm, w, bias, w, bias, x_proj_weight, x_proj_weight)
+        xc = from_blocked(xc_b[d], rows)
+        dl, bcd = dtl[d], bc[d]
+    else:
+        yf, yr = causal_conv1d_bidir(x_tm, w, bias, w, bias)
+        xc = (yr if reverse else yf).reshape(rows, E)
+        x_dbl = linear(xc, x_proj_weight)                            # [rows, R + 32] in xz.dtype (rounded like upstream's F.linear)
+        Rp = 64 if R <= 64 else (R + 31) // 32 * 32
+        dl = torch.zeros((rows, Rp), dtype=dt, device=dev)
+        dl[:, :R] = x_dbl[:, :R]
+        bcd = x_dbl[:, R:].float().contiguous()
+    Wdt = torch.zeros((E, Rp), dtype=dt, device=dev)
+    Wdt[:, :R] = delta_proj_weight.to(dt)
+    A32 = A.float().contiguous()
+    Dv = (D.float() if D is not None else torch.zeros(E, device=dev)).contiguous()
+    db = (delta_bias.float() if delta_bias is not None else torch.zeros(E, device=dev)).contiguous()
+    y = torch.empty((rows, E), dtype=dt, device=dev)
+    with torch.cuda.device(dev):
+        _check(lib.pcad_selective_scan_dtproj(xc.data_ptr(), dl.data_ptr(), Rp, Wdt.data_ptr(), Rp, z_tm.data_ptr(), E,
+                                              bcd.data_ptr(), A32.data_ptr(), Dv.data_ptr(), db.data_ptr(), y.data_ptr(),
+                                              Bsz, L, E, int(bool(reverse)), 0, _dt(xz), _stream_ptr()), "pcad_selective_scan_dtproj")
+    return linear(y.view(Bsz, L, E), out_proj_weight)
 
 
 def linear(x, weight, out_dtype: Optional[torch.dtype] = None):

@@ -55,6 +55,18 @@ def shutdown():
     _OWN_GROUP = False
 
 
+def rank0_decides(flag: bool, device="cpu") -> bool:
+    """A yes / no that selects between a branch WITH collectives and one without (a cache file exists -> load it, else embed =
+    all-gather) must be the same on every rank, whatever each rank's view of the file system: rank 0's value, broadcast (one int).
+    Outside a process group: the caller's own value."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return bool(flag)
+    dev = torch.device(device) if dist.get_backend() == "nccl" else torch.device("cpu")
+    t = torch.tensor([int(bool(flag))], dtype=torch.int32, device=dev)
+    dist.broadcast(t, src=0)
+    return bool(int(t.item()))
+
+
 def shard_bounds(n: int, rank: int, world_size: int) -> Tuple[int, int, int]:
     """-> (start, stop, per_rank): contiguous block of rank `rank`; per_rank = ceil(n / world_size)."""
     per = -(-n // world_size) if n > 0 else 0

@@ -74,8 +74,9 @@ class XGBJsonClassifier:
             l, r = int(t["left"][k]), int(t["right"][k])
             if l == -1:
                 continue
-            if r == -1 or (self.n_features and not 0 <= int(t["feat"][k]) < self.n_features):
-                raise ValueError(f"tree {ti}: node {k} has one child or a split feature outside [0, {self.n_features})")
+            f = int(t["feat"][k])
+            if r == -1 or f < 0 or (self.n_features and f >= self.n_features):
+                raise ValueError(f"tree {ti}: node {k} has one child or a split feature ({f}) outside [0, {self.n_features or 'n_features'})")
             stack += [l, r]
 
     def margin(self, X: np.ndarray) -> np.ndarray:
@@ -160,7 +161,10 @@ def main(argv: Optional[Sequence[str]] = None):
     pending = []
 
     def embeddings_for(seqs, cache):
-        if os.path.exists(cache):
+        # rank 0 looks, every rank follows (the other branch is a collective); only rank 0 needs the values
+        if sharding.rank0_decides(os.path.exists(cache), args.device):
+            if rank != 0:
+                return None
             logging.info(f"Found pre-computed embeddings, loading from file {cache}")
             return np.load(cache)["test"]
         emb = extract_embeddings(model, seqs, args.device, args.tokenIdx, tokenizer, args.batchSize, args.batchExplicit)
@@ -173,10 +177,12 @@ def main(argv: Optional[Sequence[str]] = None):
             preds = []
             for i in range(0, len(test_sequences), args.chunk_size):
                 emb = embeddings_for(test_sequences[i:i + args.chunk_size], os.path.join(args.output, f"{prefix}_chunk_{i}_embeddings.npz"))
-                preds.append(infer_xgboost_model(clf, emb))
+                if rank == 0:                                # the classifier step is host work on rank 0 (the only writer below)
+                    preds.append(infer_xgboost_model(clf, emb))
             predictions = np.concatenate(preds, axis=0) if preds else np.zeros(0, dtype=np.float32)
         else:
-            predictions = infer_xgboost_model(clf, embeddings_for(test_sequences, os.path.join(args.output, prefix + "_embeddings.npz")))
+            emb = embeddings_for(test_sequences, os.path.join(args.output, prefix + "_embeddings.npz"))
+            predictions = infer_xgboost_model(clf, emb) if rank == 0 else None
         # every rank leaves the process group after the last all-gather (rank 0's table writing below is host work; see
         # zero_shot.main)
         sharding.shutdown()

@@ -129,10 +129,17 @@ def main(argv: Optional[Sequence[str]] = None):
         return
     args.device = sharding.init_from_env(args.device)
     os.makedirs(args.output, exist_ok=True)
-    model, tokenizer = load_model_and_tokenizer(args.model, args.device)
-    rank, _ = sharding.world()
     out = lambda name: os.path.join(args.output, name)                                   # noqa: E731
     model_json = out(f"seed_{args.seed}_XGBoost.json")
+    rank, _ = sharding.world()
+    if args.test_only:
+        # the reference fails at xgb_model.load_model before any forward (src/train_XGBoost.py:173): so does every rank here
+        if sharding.rank0_decides(not os.path.exists(model_json), args.device):
+            sharding.shutdown()
+            raise FileNotFoundError(f"{model_json} not found: -test_only evaluates a classifier trained by an earlier run")
+        if rank == 0:
+            XGBJsonClassifier().load_model(model_json)        # a malformed JSON also fails now, not after the embeddings
+    model, tokenizer = load_model_and_tokenizer(args.model, args.device)
 
     def embed(seqs):
         return extract_embeddings(model, seqs, args.device, args.tokenIdx, tokenizer, args.batchSize, args.batchExplicit)
@@ -143,10 +150,13 @@ def main(argv: Optional[Sequence[str]] = None):
         train_sequences, train_labels = load_data(args.train)
         valid_sequences, valid_labels = load_data(args.valid)
         cache = out("train_valid_embeddings.npz")
-        if os.path.exists(cache):
-            logging.info(f"Found pre-computed embeddings, loading from file {cache}")
-            z = np.load(cache)
-            train_emb, valid_emb = z["train"], z["valid"]
+        # rank 0 looks, every rank follows: the else-branch is a collective (all-gather), so all ranks must take the same one even
+        # when they do not see the same output directory (node-local -output, stale attribute caches); only rank 0 reads the file
+        if sharding.rank0_decides(os.path.exists(cache), args.device):
+            if rank == 0:
+                logging.info(f"Found pre-computed embeddings, loading from file {cache}")
+                z = np.load(cache)
+                train_emb, valid_emb = z["train"], z["valid"]
         else:
             train_emb, valid_emb = embed(train_sequences), embed(valid_sequences)
             if rank == 0:
@@ -162,9 +172,10 @@ def main(argv: Optional[Sequence[str]] = None):
         for i, name in spans:
             cache = out(name)
             # -save_memory: a chunk's embeddings live in its cache file only (re-read one at a time at the classifier step below)
-            if os.path.exists(cache):
-                logging.info(f"Found pre-computed embeddings, loading from file {cache}")
-                test_chunks.append(cache if args.save_memory else np.load(cache)["test"])
+            if sharding.rank0_decides(os.path.exists(cache), args.device):
+                if rank == 0:
+                    logging.info(f"Found pre-computed embeddings, loading from file {cache}")
+                    test_chunks.append(cache if args.save_memory else np.load(cache)["test"])
                 continue
             emb = embed(test_sequences[i:i + args.chunk_size] if args.save_memory else test_sequences)
             if rank == 0:

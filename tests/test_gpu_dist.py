@@ -13,9 +13,9 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _torchrun(args, port, timeout=600):
+def _torchrun(args, port, timeout=600, nproc=1):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr", "127.0.0.1",
            "--master-port", str(port)] + args
     return subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
 
@@ -39,6 +39,69 @@ def test_bench_distributed_branch_world1():
     d = json.loads(line)
     assert d["n_gpus"] == 1 and d["distributed_branch_executed"] is True and d["value"] > 0
     assert d["unit"] == "sequences/s" and d["steps"] == 1 and d["scaling"] == "weak"
+    assert d["rccl_ranks_seen"] == [0] and len(d["per_rank_seq_per_s"]) == 1
+
+
+def _visible_gpus():
+    import torch
+    return torch.cuda.device_count()          # counting devices does not initialise the GPU on this image
+
+
+# N > 1 over RCCL: self-verifying the moment a box shows more than one device (the builder's boxes have one GPU: these are
+# collected and skipped there; SURVEY.md §8(e), BASELINE config 4).  Children are torchrun ranks, one per device, exactly as the
+# driver launches bench.py --gpus N.
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_rccl_multi_rank_equals_single_rank(world, tmp_path):
+    """`world` ranks on `world` devices: each runs its block of the 185 example windows through the HIP engine, ONE
+    all_gather_into_tensor over RCCL/xGMI per result; every rank must hold the full [185, 4] / [185, D] result, bit-identical to
+    the one-rank run, and the ranks must report `world` distinct devices on the nccl backend."""
+    if _visible_gpus() < world:
+        pytest.skip(f"needs {world} GPUs, {_visible_gpus()} visible")
+    worker = os.path.join(ROOT, "tests", "_rccl_worker.py")
+    d1, dn = tmp_path / "w1", tmp_path / f"w{world}"
+    d1.mkdir()
+    dn.mkdir()
+    r = _torchrun([worker, str(dn)], _free_port(), nproc=world)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    r1 = _torchrun([worker, str(d1)], _free_port(), nproc=1)
+    assert r1.returncode == 0, r1.stdout[-2000:] + r1.stderr[-4000:]
+    ref = np.load(d1 / "r0.npz")
+    assert ref["p"].shape == (185, 4) and ref["e"].shape == (185, 128)
+    reports = [json.load(open(dn / f"r{k}.json")) for k in range(world)]
+    assert sorted(x["rank"] for x in reports) == list(range(world))
+    assert all(x["world"] == world and x["backend"] == "nccl" for x in reports)
+    assert len({x["device"] for x in reports}) == world, reports            # one device per rank
+    for k in range(world):
+        got = np.load(dn / f"r{k}.npz")
+        np.testing.assert_array_equal(got["p"], ref["p"])
+        np.testing.assert_array_equal(got["e"], ref["e"])
+
+
+def test_rccl_worker_world1(tmp_path):
+    """the same child at one rank on the one GPU at hand, so that the worker the N > 1 tests rely on is itself executed on
+    every box (an N > 1 failure is then about N, not about the worker)."""
+    r = _torchrun([os.path.join(ROOT, "tests", "_rccl_worker.py"), str(tmp_path)], _free_port(), nproc=1)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    rep = json.load(open(tmp_path / "r0.json"))
+    assert rep["rank"] == 0 and rep["world"] == 1 and rep["backend"] == "nccl"
+    got = np.load(tmp_path / "r0.npz")
+    assert got["p"].shape == (185, 4) and got["e"].shape == (185, 128) and np.isfinite(got["p"]).all()
+    np.testing.assert_allclose(got["p"].sum(1), 1.0, rtol=1e-5)
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_bench_rccl_multi_rank(world):
+    """bench.py as the driver launches it for N > 1; the JSON line must name N ranks seen through the RCCL group and carry one
+    per-rank rate each, and the aggregate must be the sum of the work over the slowest rank's time."""
+    if _visible_gpus() < world:
+        pytest.skip(f"needs {world} GPUs, {_visible_gpus()} visible")
+    r = _torchrun([os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "2", "--warmup", "1", "--batch", "64",
+                   "--model", "l20", "--cpu-seqs", "0", "--host-seqs", "0"], _free_port(), nproc=world)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["n_gpus"] == world and d["rccl_ranks_seen"] == list(range(world)) and len(d["per_rank_seq_per_s"]) == world
+    assert d["distributed_branch_executed"] is True and d["scaling"] == "weak"
+    assert d["value"] <= sum(d["per_rank_seq_per_s"]) * 1.001 and d["value"] > 0
 
 
 def test_zero_shot_cli_under_torchrun_world1(golden_dir, tmp_path):

@@ -332,3 +332,66 @@ def test_last_layer_shortcut_bit_identical(dtype, D, nl, B, L, pos):
     m_p = build(cfg, sd, dtype, poison_workspace=1)
     c = m_p(input_ids=ids, output_hidden_states=True, positions=pos)
     assert torch.equal(a.logits, c.logits) and torch.equal(a.hidden_states[-1], c.hidden_states[-1])
+
+
+@pytest.mark.parametrize("L,pos", [(128, None), (77, None), (128, [63]), (45, [44, 0])])
+def test_reference_order_levels_bf16(L, pos):
+    """pcad_set_option("reference_order", 1 / 2) (include/pcad.h) against the torch oracle rounding to bf16 where the reference's
+    bf16 model stores a tensor, in the operation order each level claims:
+      level 2 (strict)  BiMambaWrapper's own order - each direction gated and rounded, its own tied out_proj stored in bf16, then
+                        `out + out_rev` rounded (oracle forward_strands(tie_fold=False));
+      level 1           the same with the two tied out_proj calls folded by linearity (tie_fold=True);
+      level 0           the shipped default.
+    With the rounding points in the same places only fp32 summation order and exp / log implementations differ, so the level's
+    own emulation must be the closest one to it (up to the one-ulp noise two restatements have), and all stay inside the 4-layer
+    bf16 bar of test_forward_bf16_vs_bf16_emulating_oracle.  Covers ragged lengths (reference-order launches only), the
+    last-layer shortcut's strict branch (shared positions) and hidden_states[-1]."""
+    cfg = make_config("x", d_model=256, n_layer=4)
+    sd = synthetic_state_dict(cfg, seed=3)
+    mask = 63 if L > 63 else L - 1
+    ids = rand_ids(4, L, 9, mask=mask)
+    P = O.params_from_state_dict(sd, cfg, dtype=torch.bfloat16)
+    ref_strict = O.forward_strands(ids, P, rnd=O.round_bf16, tie_fold=False)
+    ref_fold = O.forward_strands(ids, P, rnd=O.round_bf16, tie_fold=True)
+    scale = ref_strict["logits"].abs().max()
+    sel = (lambda t: t[:, pos]) if pos is not None else (lambda t: t)
+    err = {}
+    for level in (0, 1, 2):
+        m = build(cfg, sd, torch.bfloat16, reference_order=level)
+        out = m(input_ids=ids.to(DEV), output_hidden_states=True, **({"positions": pos} if pos is not None else {}))
+        lg, hid = out.logits.cpu(), out.hidden_states[-1].float().cpu()
+        for name, ref in (("strict", ref_strict), ("fold", ref_fold)):
+            err[level, name] = ((lg - sel(ref["logits"])).abs().max() / scale).item()
+        hs = sel(ref_strict["hidden"]).float()
+        assert ((hid - hs).abs().max() / hs.abs().max()).item() < 3e-2
+    print(f"L={L} pos={pos}: max logit error / range by (level, emulation order): " + ", ".join(f"{k}: {v:.2e}" for k, v in err.items()))
+    assert all(v < 3e-2 for v in err.values())
+    ulp = 2.0 ** -8                                          # one bf16 ulp of the logit range
+    assert err[2, "strict"] <= err[0, "strict"] + ulp        # the strict level is not further from the reference's order than the default
+    assert err[1, "fold"] <= err[0, "fold"] + ulp
+
+
+@pytest.mark.parametrize("pos", [None, [31, 5]])
+def test_reference_order_strict_fp32(pos):
+    """The strict level on the fp32 model: no rounding anywhere, so it must meet north_star's 1e-4 like the default, on logits,
+    hidden_states[-1] and (all positions) every level of output_hidden_states; and chunking must not change a bit."""
+    cfg = make_config("x", d_model=128, n_layer=3)
+    sd = synthetic_state_dict(cfg, seed=11)
+    ids = rand_ids(5, 64, 4, mask=31)
+    ref = O.forward_literal(ids, O.params_from_state_dict(sd, cfg), output_hidden_states=True)
+    m = build(cfg, sd, torch.float32, reference_order=2)
+    kw = {"positions": pos} if pos is not None else {}
+    out = m(input_ids=ids.to(DEV), output_hidden_states=True, **kw)
+    lg, hid = out.logits.cpu(), out.hidden_states[-1].cpu()
+    rl, rh = (ref["logits"][:, pos], ref["hidden"][:, pos]) if pos is not None else (ref["logits"], ref["hidden"])
+    assert ((lg - rl).abs().max() / ref["logits"].abs().max()).item() < 1e-4
+    assert ((hid - rh).abs().max() / ref["hidden"].abs().max()).item() < 1e-4
+    m2 = build(cfg, sd, torch.float32, reference_order=2, chunk_seqs=2)
+    out2 = m2(input_ids=ids.to(DEV), output_hidden_states=True, **kw)
+    assert torch.equal(out2.logits.cpu(), lg) and torch.equal(out2.hidden_states[-1].cpu(), hid)
+    if pos is None:
+        cfg.materialize_all_hidden_states = True
+        allh = build(cfg, sd, torch.float32, reference_order=2)(input_ids=ids.to(DEV), output_hidden_states=True).hidden_states
+        assert len(allh) == len(ref["all_hidden"]) == cfg.n_layer + 1
+        for i, (a, b) in enumerate(zip(allh, ref["all_hidden"])):
+            assert ((a.cpu().float() - b).abs().max() / b.abs().max().clamp_min(1e-6)).item() < 1e-4, i

@@ -343,3 +343,52 @@ def test_final_head_clamps_and_flags_bad_positions(ops):
     status.zero_(); ids[1, 3] = 9
     ops.final_head(h, res, w, emb, [0, 1, 2, 6, 5, 4, 3, 7], B, L, 1e-5, positions=[1], ids=ids, status=status)
     assert int(status.item()) == 1
+
+
+def _mamba_params(seed, D, E, R, scale=1.0):
+    """One Mamba's parameters with the init ranges of plantcaduceus_amd.checkpoint.synthetic_state_dict (distinct per seed)."""
+    import math
+    g = torch.Generator().manual_seed(seed)
+
+    def U(shape, bound):
+        return (torch.rand(shape, generator=g) * 2 - 1) * bound
+    dt = torch.exp(torch.rand(E, generator=g) * (math.log(0.1) - math.log(1e-3)) + math.log(1e-3)).clamp_min(1e-4)
+    return O.MambaParams(
+        in_proj=U((2 * E, D), D ** -0.5), conv_w=U((E, 4), 0.5), conv_b=U((E,), 0.5), x_proj=U((R + 32, E), E ** -0.5) * scale,
+        dt_proj_w=U((E, R), R ** -0.5), dt_proj_b=dt + torch.log(-torch.expm1(-dt)),
+        A_log=torch.log(torch.arange(1, 17, dtype=torch.float32).repeat(E, 1)) + 0.3 * torch.randn(E, 16, generator=g),
+        D=torch.rand(E, generator=g) + 0.5, out_proj=U((D, E), E ** -0.5))
+
+
+@pytest.mark.parametrize("D,R,Bsz,L", [(384, 24, 2, 512), (1024, 64, 2, 512), (384, 24, 3, 77), (128, 8, 2, 40), (768, 128, 1, 64)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_mamba_inner_fn(ops, D, R, Bsz, L, dtype):
+    """ops.mamba_inner_fn under mamba-ssm 2.2.2's signature (xz channels-first (B, 2E, L) in, (B, L, D) out) against the oracle's
+    restatement of the same function, at the BASELINE widths (D = 384: l20, 1024: l32) and off them (ragged L, dt_rank 128: the
+    unfused conv / x_proj pair); fp32 <= 3e-5 of the output's max, bf16 <= 2^-7 against the oracle rounding to bf16 where
+    upstream stores a bf16 tensor (conv out, x_dbl, delta, scan out, out_proj out).  And the reverse twin BiMambaWrapper needs:
+    reverse=True on the unflipped rows == the plain operator on the flipped sequence, flipped back."""
+    E = 2 * D
+    p = _mamba_params(D + R, D, E, R)
+    g = torch.Generator().manual_seed(L)
+    xz = torch.randn(Bsz, 2 * E, L, generator=g)
+    rnd = O.round_bf16 if dtype == torch.bfloat16 else (lambda t: t)
+    if dtype == torch.bfloat16:                        # from_pretrained(torch_dtype=bf16): parameters and the input are bf16 tensors
+        p = O.MambaParams(**{k: v.bfloat16().float() for k, v in vars(p).items()})
+        xz = xz.bfloat16().float()
+    tol = 2 ** -7 if dtype == torch.bfloat16 else 3e-5
+    A = -torch.exp(p.A_log)
+    args = [t.to(DEV) for t in (p.conv_w.unsqueeze(1), p.conv_b, p.x_proj.to(dtype), p.dt_proj_w.to(dtype), p.out_proj.to(dtype))]
+    kw = dict(D=p.D.to(DEV), delta_bias=p.dt_proj_b.to(DEV), delta_softplus=True)
+    out = ops.mamba_inner_fn(xz.to(dtype).to(DEV), args[0], args[1], args[2], args[3], args[4], None, A.to(DEV), None, None, **kw)
+    ref = O.mamba_inner(xz, p, rnd)
+    assert out.shape == (Bsz, L, D) and out.dtype == dtype
+    e = relerr(out, ref)
+    out_r = ops.mamba_inner_fn(xz.to(dtype).to(DEV), args[0], args[1], args[2], args[3], args[4], None, A.to(DEV), None, None,
+                               reverse=True, **kw)
+    ref_r = O.mamba_inner(xz.flip(-1), p, rnd).flip(1)
+    er = relerr(out_r, ref_r)
+    print(f"mamba_inner_fn D={D} R={R} L={L} {dtype}: rel err {e:.2e} (reverse twin {er:.2e})")
+    assert e < tol and er < tol
+    with pytest.raises(NotImplementedError):
+        ops.mamba_inner_fn(xz.to(dtype).to(DEV), args[0], args[1], args[2], args[3], args[4], torch.zeros(D, device=DEV), A.to(DEV))

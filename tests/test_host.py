@@ -78,6 +78,40 @@ def test_two_handles_share_no_state(lib):
     lib.pcad_destroy(a)
 
 
+def test_fold_copies_are_carved_only_when_the_fold_can_engage(lib):
+    """the norm-folded form's extra weight copies (second in_proj weight per layer, layer-0 table, padded out_proj) cost
+    arena only for handles whose options ask for the fold when the arena is sized: bf16 default yes; bf16 with "norm_fold" 0 or
+    "reference_order" 1 / 2 no; fp32 default no; fp32 with "norm_fold" 1 yes.  And the option values are validated."""
+    def mk(dtype, D=1024, nl=4):
+        c = engine.PcadConfig(d_model=D, n_layer=nl, d_state=16, d_conv=4, expand=2, dt_rank=64, vocab=8, eps=1e-5, dtype=dtype,
+                              residual_in_fp32=1, complement=(C.c_int32 * 8)(0, 1, 2, 6, 5, 4, 3, 7))
+        h = C.c_void_p()
+        assert lib.pcad_create(C.byref(c), C.byref(h)) == 0
+        return h
+    h = mk(1)
+    full = lib.pcad_weight_arena_bytes(h)
+    assert lib.pcad_set_option(h, b"norm_fold", 0) == 0
+    plain = lib.pcad_weight_arena_bytes(h)
+    in_proj_bytes = 4 * (2 * 2048 * 1024 * 2)
+    assert full - plain >= in_proj_bytes and full - plain < in_proj_bytes * 1.05          # the folded in_proj copies + the small table
+    assert lib.pcad_set_option(h, b"norm_fold", -1) == 0 and lib.pcad_weight_arena_bytes(h) == full
+    for level in (1, 2):
+        assert lib.pcad_set_option(h, b"reference_order", level) == 0 and lib.pcad_weight_arena_bytes(h) == plain
+    assert lib.pcad_set_option(h, b"reference_order", 0) == 0 and lib.pcad_weight_arena_bytes(h) == full
+    assert lib.pcad_set_option(h, b"reference_order", 3) == -1 and b"reference_order" in lib.pcad_last_error()
+    lib.pcad_destroy(h)
+    f = mk(0)
+    f_plain = lib.pcad_weight_arena_bytes(f)
+    assert lib.pcad_set_option(f, b"norm_fold", 1) == 0 and lib.pcad_weight_arena_bytes(f) > f_plain
+    lib.pcad_destroy(f)
+    # l20's d_model 384: the folded out_proj is padded to 512 rows - also only when the fold is on
+    g = mk(1, D=384, nl=2)
+    g_full = lib.pcad_weight_arena_bytes(g)
+    lib.pcad_set_option(g, b"norm_fold", 0)
+    assert g_full - lib.pcad_weight_arena_bytes(g) >= 2 * (2 * 768 * 384 * 2 + 512 * 768 * 2)
+    lib.pcad_destroy(g)
+
+
 def test_config_derived_dims_and_support_check():
     for name, (D, nl, R) in {"l20": (384, 20, 24), "l24": (512, 24, 32), "l28": (768, 28, 48), "l32": (1024, 32, 64)}.items():
         c = make_config(name)
@@ -217,6 +251,14 @@ def test_bench_work_formulas_match_survey_8d():
     f, _ = bench.per_sequence_work(cfg, 512, 2)
     assert abs(scan_skip - (1 - 264 / 512)) < 1e-12 and 0.009 < fl_skip / f < 0.013
     assert bench.executed_fraction_last_layer(cfg, 512, 255, False) == (0.0, 0.0)
+    # energy per window = mean sampled board power x wall time / windows (bench.PowerSampler.summary), and the CPU baseline's protocol
+    ps = bench.PowerSampler.__new__(bench.PowerSampler)
+    ps.samples, ps.period, ps.file = [1000.0, 1200.0, 1400.0], 0.05, "x"
+    en = ps.summary(seconds=2.0, windows=2400)
+    assert abs(en["energy_J_per_window"] - 1.0) < 1e-12 and en["max_power_W"] == 1400.0 and en["samples"] == 3
+    ps.samples = []
+    assert ps.summary(1.0, 1) is None
+    assert bench.CPU_REPEATS >= 2
 
 
 def test_effective_batch_keeps_an_explicit_batch_size():
@@ -255,3 +297,17 @@ def test_residual_fragment_layout_formula():
     rng = np.random.default_rng(0)
     for row, col in zip(rng.integers(0, M, 500), rng.integers(0, N, 500)):
         assert frag[off(int(row), int(col))] == res[row, col]
+
+
+def test_gemm_hand_counted_waits_cover_their_consumers():
+    """tools/isa_census.py --check-res-waits on the gfx950 assembly hipcc emits for gemm.hip: no register written by one of the
+    un-waited inline-asm loads of the fused GEMM epilogues (EPI_RES: 64 accumulator quads; EPI_SCALE: 8 row factors) is read
+    before an s_waitcnt whose count proves that load complete."""
+    import shutil
+    import subprocess
+    import sys
+    if shutil.which("hipcc") is None:
+        pytest.skip("hipcc not available")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "isa_census.py"), "--check-res-waits"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "check-res-waits: OK" in r.stdout and r.stdout.count("64 un-waited asm loads, 0 reads") == 2

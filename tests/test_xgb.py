@@ -151,6 +151,19 @@ def test_malformed_trees_are_rejected_at_load(tmp_path):
             xgb_predict.XGBJsonClassifier().load_model(str(path))
     json.dump(_model_json([good], 4), open(tmp_path / "good.json", "w"))
     xgb_predict.XGBJsonClassifier().load_model(str(tmp_path / "good.json"))
+    # a file WITHOUT num_feature (0): the width is derived from the trees, so a negative split index must still be refused at load,
+    # and the native entry point refuses out-of-range features by itself (it must not trust its caller)
+    neg = _model_json([dict(good, split_indices=[-3, 0, 0])], 0)
+    json.dump(neg, open(tmp_path / "neg.json", "w"))
+    with pytest.raises(ValueError):
+        xgb_predict.XGBJsonClassifier().load_model(str(tmp_path / "neg.json"))
+    from plantcaduceus_amd import hostlib
+    X = np.zeros((3, 4), dtype=np.float32)
+    off, L, R, C, Dl = np.array([0, 3]), np.array([1, -1, -1]), np.array([2, -1, -1]), np.array([0.5, 1.0, 2.0]), np.array([0, 0, 0])
+    assert hostlib.xgb_margin(X, 4, off, L, R, np.array([3, 0, 0]), C, Dl, 0.0).shape == (3,)
+    for bad_feat in ([-1, 0, 0], [4, 0, 0]):
+        with pytest.raises(RuntimeError):
+            hostlib.xgb_margin(X, 4, off, L, R, np.array(bad_feat), C, Dl, 0.0)
 
 
 

@@ -12,6 +12,11 @@
               that differ only in summation order already disagree by percent; reported next to that noise floor, no bar.
 
     python tools/argmax_census.py [--n 128] [--n-emul 64] [--model l32] > profiles/r03_argmax_census.txt
+
+Round 5: `--fixture tests/golden/census_<model>.npz` runs the census against the COMMITTED oracle runs (512 l32 / 256 l20 windows,
+oracle/gen_census_golden.py) for the engine's three operation orders (default, "reference_order" 1 and 2) - seconds instead of the
+oracle's minutes; tests/test_gpu_census.py asserts on the same numbers.
+    python tools/argmax_census.py --model l32 --fixture tests/golden/census_l32.npz > profiles/r05_argmax_census_l32.txt
 """
 import argparse
 import os
@@ -53,13 +58,113 @@ def first_layer_delta_fraction(sd, cfg, ids, thr):
     return n / tot
 
 
+def hip_probs(cfg, sd, ids, batch=None, **engine_options):
+    """softmax over a, c, g, t at the masked index for every window, bf16 model on the HIP engine with the given pcad_set_option
+    values; `batch`: windows per forward (BASELINE config 2 runs l20 at 1024 - the census windows are then the head of a batch
+    padded with further seeded windows, so that the engine sees that configuration's launch sizes)."""
+    import numpy as np
+    import torch
+    from plantcaduceus_amd.modeling_caduceus import CaduceusForMaskedLM
+    cfg.engine_options = dict(engine_options)
+    m = CaduceusForMaskedLM(cfg)
+    m.load_state_dict(sd, strict=False)
+    m.tie_weights()
+    m = m.to(torch.bfloat16).to("cuda:0")
+    n = len(ids)
+    batch = batch or n
+    outs = []
+    for b0 in range(0, n, batch):
+        blk = ids[b0:b0 + batch]
+        if len(blk) < batch:
+            pad = np.random.default_rng(99).integers(3, 7, size=(batch - len(blk), ids.shape[1])).astype(np.int32)
+            pad[:, P] = 1
+            blk = np.concatenate([blk, pad], 0)
+        lg = m(input_ids=torch.from_numpy(blk).to("cuda:0"), positions=[P]).logits[:, 0].float().cpu().numpy()
+        outs.append(lg)
+    m.check_status()
+    del m
+    torch.cuda.empty_cache()
+    return softmax4(np.concatenate(outs, 0)[:n, 3:7])
+
+
+def margins(q):
+    import numpy as np
+    top2 = np.sort(q, 1)[:, -2:]
+    return top2[:, 1] - top2[:, 0]
+
+
+def compare(p, q):
+    """-> dict(n, flips: indices where the 4-way calls differ, max_dp, flip_margins: q's top-2 margin at those windows)"""
+    import numpy as np
+    n = min(len(p), len(q))
+    p, q = p[:n], q[:n]
+    flips = np.nonzero(p.argmax(1) != q.argmax(1))[0]
+    return dict(n=n, flips=flips, max_dp=float(np.abs(p - q).max()), flip_margins=margins(q)[flips])
+
+
+MODES = (("default", {}), ("reference_order=1", {"reference_order": 1}), ("reference_order=2", {"reference_order": 2}))
+
+
+def census_from_fixture(model, fixture, batch=None, out=print):
+    """The census against the committed oracle runs (tests/golden/census_<model>.npz, oracle/gen_census_golden.py): the HIP bf16
+    engine in its three operation orders x {fp32 oracle, reference-order bf16 emulation}, next to the floors the CPU restatements
+    have between THEMSELVES (eng vs ref: one reordering; ref_plainc vs ref: same rounding points, other fp32 summation order;
+    ref vs f32: what bf16 storage itself does).  Returns the numbers tests/test_gpu_census.py asserts on."""
+    import hashlib
+    import numpy as np
+    from oracle.gen_census_golden import census_windows
+    from plantcaduceus_amd.checkpoint import make_config, synthetic_state_dict
+    fx = np.load(fixture)
+    n, seed = int(fx["meta"][0]), int(fx["meta"][1])
+    ids = census_windows(n, seed)
+    assert hashlib.sha1(ids.tobytes()).digest() == fx["ids_sha1"].tobytes(), "fixture was generated from other windows"
+    cfg = make_config(model)
+    assert (cfg.d_model, cfg.n_layer) == (int(fx["meta"][4]), int(fx["meta"][5]))
+    sd = synthetic_state_dict(cfg, seed=1234, stress=False)
+    orc = {k: softmax4(fx["logits_" + k][:, 3:7]) for k in ("f32", "ref", "eng", "ref_plainc")}
+    n = min(n, len(orc["f32"]), len(orc["ref"]))                 # a generator run that was cut short holds a common prefix
+    ids = ids[:n]
+    res = {"n": n, "n_eng": len(orc["eng"]), "n_plainc": len(orc["ref_plainc"]), "modes": {}}
+    out(f"== arg-max census, PlantCaduceus_{model} (d_model={cfg.d_model}, n_layer={cfg.n_layer}) bf16, {n} synthetic 512-bp windows, mask index {P}, "
+        f"checkpoint seed 1234" + (f", forwards of {batch} windows" if batch else ""))
+    floors = {"eng_vs_ref": compare(orc["eng"], orc["ref"]), "plainc_vs_ref": compare(orc["ref_plainc"], orc["ref"]),
+              "ref_vs_f32": compare(orc["ref"][:n], orc["f32"][:n]), "eng_vs_f32": compare(orc["eng"], orc["f32"])}
+    res["floors"] = floors
+    out("-- floors between CPU restatements (no GPU involved):")
+    for k, what in (("eng_vs_ref", "bf16 emulation, tied out_proj folded, vs reference order (ONE reordering)"),
+                    ("plainc_vs_ref", "reference order, plain-C GEMM vs host BLAS (same rounding points, other fp32 summation order)"),
+                    ("ref_vs_f32", "reference-order bf16 emulation vs fp32"), ("eng_vs_f32", "folded bf16 emulation vs fp32")):
+        c = floors[k]
+        out(f"   {what}: {len(c['flips'])} of {c['n']} calls differ, max |dp| {c['max_dp']:.3e}"
+            + (f", margins of the differing windows {np.round(c['flip_margins'], 4).tolist()}" if len(c["flips"]) else ""))
+    h, edges = np.histogram(margins(orc["f32"][:n]), bins=[0, 1e-3, 2e-3, 5e-3, 1e-2, 2e-2, 5e-2, 1e-1, 1.0])
+    out("   fp32 oracle's top-2 probability margin, windows per bin: " + ", ".join(f"[{edges[i]:g},{edges[i+1]:g}): {h[i]}" for i in range(len(h))))
+    for name, opts in MODES:
+        p = hip_probs(cfg, sd, ids, batch=batch, **opts)
+        r = {"vs_ref": compare(p, orc["ref"][:n]), "vs_f32": compare(p, orc["f32"][:n]), "vs_eng": compare(p, orc["eng"])}
+        r["vs_ref_on_eng_prefix"] = compare(p[:len(orc["eng"])], orc["ref"][:len(orc["eng"])])
+        res["modes"][name] = r
+        out(f"-- HIP engine, {name}:")
+        for k, what in (("vs_ref", "reference-order bf16 emulation"), ("vs_f32", "fp32 oracle"), ("vs_eng", "folded bf16 emulation")):
+            c = r[k]
+            out(f"   vs {what}: {len(c['flips'])} of {c['n']} calls differ, max |dp| {c['max_dp']:.3e}"
+                + (f"; differing windows {c['flips'].tolist()} with oracle margins {np.round(c['flip_margins'], 4).tolist()}" if len(c["flips"]) else ""))
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--n", type=int, default=128)
     ap.add_argument("--n-emul", type=int, default=64)
     ap.add_argument("--n-stress", type=int, default=8)
     ap.add_argument("--model", default="l32")
+    ap.add_argument("--fixture", default=None, help="tests/golden/census_<model>.npz: census against the committed oracle runs "
+                    "(three engine operation orders; no oracle run) instead of parts 1 and 2")
+    ap.add_argument("--batch", type=int, default=0, help="with --fixture: windows per forward (0: all at once)")
     args = ap.parse_args()
+    if args.fixture:
+        census_from_fixture(args.model, args.fixture, batch=args.batch or None)
+        return
     import numpy as np
     import torch
     from oracle.c_oracle import COracle
