@@ -444,6 +444,12 @@ def main():
         # ---- whole step against the chip peaks, from SURVEY.md §8(d)'s per-sequence counts ----------------------
         fl_seq, by_seq = per_sequence_work(cfg, L, esz)
         opts = dict(kv.split("=", 1) for kv in args.opt)
+        # fp32 model with "f32_gemm_split": in_proj / out_proj (98 % of the flops) run as three bf16 MFMA products per fp32 product
+        split = args.dtype == "f32" and opts.get("f32_gemm_split", "0") != "0"
+        peak_mfma = PEAK["bf16"] / 3.0 if split else PEAK[args.dtype]
+        if split:
+            res["mfma_peak_note"] = ("f32_gemm_split: the projections run on the bf16 matrix pipes at three products per fp32 product; "
+                                     "MFMA fractions are against bf16 peak / 3 = %.0f TFLOP/s of fp32-equivalent work" % peak_mfma)
         shortcut = args.workload != "ism" and opts.get("last_layer_shortcut", "1") != "0"
         fl_skip, scan_skip = executed_fraction_last_layer(cfg, L, p, shortcut)
         # bytes the shortcut skips: the last layer's out_proj term (LE + LD) and scan_skip of its scan term (3LE), both strands
@@ -452,14 +458,14 @@ def main():
         res["whole_step"] = {"flops_per_seq": fl_seq, "hbm_bytes_per_seq": by_seq,
                              "flops_per_seq_executed": fl_exec, "hbm_bytes_per_seq_executed": by_exec,
                              "TFLOP/s": fl_exec * total / dt / 1e12 / world, "GB/s": by_exec * total / dt / 1e9 / world,
-                             "mfma_frac": fl_exec * total / dt / 1e12 / world / PEAK[args.dtype],
+                             "mfma_frac": fl_exec * total / dt / 1e12 / world / peak_mfma,
                              "hbm_frac": by_exec * total / dt / 1e9 / world / PEAK_HBM,
                              "note": "per GPU; SURVEY.md §8(d) algorithmic flops (tie-folded) and bytes (GEMM-boundary fusion) per "
                                      "window MINUS what the last-layer shortcut does not execute (last out_proj except the evaluated "
                                      "rows, the scans beyond the furthest evaluated row: %.2f %% of the flops), x windows / timed wall clock"
                                      % (100.0 * fl_skip / fl_seq)}
         res["box"] = box
-        chunk_max = max(1, ((((1 << 32) - (2 << 20)) // (cfg.d_inner * esz)) & ~7) // (2 * L))   # as api.hip
+        chunk_max = max(1, ((((1 << 32) - (2 << 20)) // (cfg.d_inner * (6 if split else esz))) & ~7) // (2 * L))   # as api.hip chunk_row_limit
         if args.chunk_seqs:
             chunk_max = args.chunk_seqs
         elif os.environ.get("PCAD_DEV") == "1" and os.environ.get("PCAD_CHUNK_SEQS"):
@@ -493,8 +499,8 @@ def main():
             avg_s = kern[dom]["avg_ms"] * 1e-3
             if dom.startswith("gemm"):
                 a = work[dom]["flops"] / avg_s / 1e12
-                res["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": a, "peak": PEAK[args.dtype],
-                                   "unit": "TFLOP/s", "frac": a / PEAK[args.dtype], "traffic": None,
+                res["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": a, "peak": peak_mfma,
+                                   "unit": "TFLOP/s", "frac": a / peak_mfma, "traffic": None,
                                    "algorithmic_flops_per_launch": work[dom]["flops"]}
             else:
                 a = work[dom]["bytes_8d"] / avg_s / 1e9

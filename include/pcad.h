@@ -113,6 +113,14 @@ void   pcad_destroy(pcad_handle h);
  *                 calls (afterwards pcad_forward refuses); turning it off later is always possible;
  *                 0 (default for the fp32 model, whose 1e-4 parity budget would pay for accumulating onto the residual: 2.2e-5 of
  *                 max after 32 layers instead of 1.3e-6): the reference's operation order (one add + RMSNorm launch per block).
+ *   "f32_gemm_split"  1: the fp32 model's two big projections (in_proj, out_proj: 3/4 of its time on the fp32 MFMA instructions) run
+ *                 as split-bf16 GEMMs (pcad_gemm_nt_split below: three bf16 products per fp32 product, fp32 accumulation and
+ *                 result); everything else of the fp32 model is unchanged.  Measured 4e-7 of the logits' range against the fp32
+ *                 oracle after 32 layers (the plain fp32 GEMMs: 1e-6), arg-max exact - inside north_star's 1e-4 - at about twice
+ *                 the fp32 model's speed.  0 (default): fp32 MFMA.  Needs [hi | hi | lo] weight copies (+1.5x the two weights) packed
+ *                 at bind time: set it before pcad_weight_arena_bytes / pcad_bind_weights.  Ignored by the bf16 model and while
+ *                 "norm_fold" 1 is forced.  Chunks are capped at (2^32 - 2 MiB) / (6 d_inner) token-rows (out_proj's 3 d_inner-wide
+ *                 bf16 operand).
  *   "reference_order"  one switch over the options above, for users who want every rounding point where the reference has it
  *                 (BiMambaWrapper "add" of two Mamba calls, rms_norm_fn(prenorm=True, residual_in_fp32=True), mamba_inner_fn):
  *                 0 (default): the engine's defaults ("gate_each" 0, "norm_fold" default, layer 0's in_proj as a table);
@@ -268,6 +276,16 @@ int pcad_selective_scan_dtproj(const void* u, const void* dt_low, int64_t lddt, 
  * lda, ldw multiples of 16 bytes.  out_dtype: PCAD_F32 or `dtype`. */
 int pcad_gemm_nt(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc,
                  int64_t M, int N, int K, int dtype, int out_dtype, pcad_stream stream);
+
+/* F.linear(a, w) of fp32 tensors on the bf16 matrix pipes - the form the fp32 model's in_proj / out_proj take with
+ * pcad_set_option("f32_gemm_split", 1): each operand is carried as two bf16 values (hi = bf16(v), lo = bf16(v - hi): 16 mantissa
+ * bits) and C = A_hi W_hi^T + A_lo W_hi^T + A_hi W_lo^T is ONE bf16 GEMM with K' = 3 K on [hi | lo | hi] x [hi | hi | lo] operands,
+ * fp32 accumulation, fp32 result (3/16 of the fp32-MFMA cost per flop; operand error 2^-17, dropped term 2^-16 relative).
+ *   A [M, K] (lda), W [N, K] (ldw), C [M, N] (ldc) fp32, K % 64 == 0; scratch: device buffer of
+ *   pcad_gemm_nt_split_scratch_bytes(M, N, K) bytes (the split operands; the engine keeps the weights' split copy in its arena). */
+size_t pcad_gemm_nt_split_scratch_bytes(int64_t M, int N, int K);
+int pcad_gemm_nt_split(const float* A, int64_t lda, const float* W, int64_t ldw, float* C, int64_t ldc, int64_t M, int N, int K,
+                       void* scratch, size_t scratch_bytes, pcad_stream stream);
 
 /* out_proj of the "norm_fold" layer form as one operator (MFMA, 256 x 256 tiles only: M % 256 == 0, N % 256 == 0, K * elem a
  * multiple of 128 bytes, every tensor < 4 GiB):

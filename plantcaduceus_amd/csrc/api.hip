@@ -55,6 +55,8 @@ struct LayerWeights {
     void* W_in_f;    // [2E, D] = W_in . diag(norm_w), rounded once from the source precision: in_proj of the norm-folded form
     void* W_out;     // [D, E]
     void* W_out_p;   // [Dp, E]: W_out with zero rows up to Dp = round_up(D, 256) for the folded out_proj (== W_out when D % 256 == 0)
+    void* W_in_s;    // [2E, 3D] bf16 = [hi | hi | lo] of W_in: split-bf16 in_proj of the fp32 model ("f32_gemm_split"), else nullptr
+    void* W_out_s;   // [D, 3E] bf16 = [hi | hi | lo] of W_out
     DirWeights dir[2];
 };
 
@@ -78,6 +80,8 @@ struct pcad_engine {
     int rep_class = -1, rep_count = 1;   // pcad_set_option("debug_repeat_class" / "debug_repeat"): measurement aid, see forward_impl
     bool poison = false;   // pcad_set_option("poison_workspace", 1): debug — fill the workspace with 0xFF (NaN patterns) before every forward
     bool bound = false;
+    bool f32_split = false;     // pcad_set_option("f32_gemm_split", 1): the fp32 model's in_proj / out_proj as split-bf16 GEMMs (split_wanted)
+    bool split_packed = false;  // ... and their [hi | hi | lo] weight copies exist in the arena (decided like fold_packed)
     bool fold_packed = false;   // the norm-folded form's extra weight copies (W_in_f, xz_tab0, padded W_out) exist in the arena: decided
                                 // from the options in force when pcad_weight_arena_bytes / pcad_bind_weights run (fold_wanted)
     int32_t* status = nullptr;   // caller-owned device word for asynchronous input-validation flags (pcad_set_status_buffer)
@@ -117,11 +121,24 @@ bool fold_wanted(const pcad_engine* e) {
     return want && e->rdt == F32 && e->xzsplit && e->blocked;
 }
 
+// "f32_gemm_split": fp32 model only, and never together with the norm-folded form (whose GEMM epilogues are fp32-in / fp32-out)
+bool split_wanted(const pcad_engine* e) {
+    return e->f32_split && e->cfg.dtype == PCAD_F32 && !fold_wanted(e) && e->xzsplit && e->blocked && e->D % 64 == 0 && e->E % 64 == 0;
+}
+
+// token-rows per pass through the layer stack: the kernels address their tensors with unsigned 32-bit byte offsets; the widest
+// per-row tensor is E * esz bytes (x, z, xc, y) - or, with the split-bf16 GEMMs, the 3 E bf16 columns of out_proj's operand
+int64_t chunk_row_limit(const pcad_engine* e) {
+    const int64_t per_row = split_wanted(e) ? (int64_t)e->E * 6 : (int64_t)e->E * e->esz;
+    return ((((int64_t)1 << 32) - ((int64_t)2 << 20)) / per_row) & ~(int64_t)7;
+}
+
 void carve_weights(pcad_engine* e, Carver& c) {
     const size_t D = e->D, E = e->E, N = e->N, V = e->V, esz = e->esz;
     // the folded form's copies (a second in_proj weight per layer, the layer-0 table, out_proj padded to 256 rows) are carved only
     // when the fold can engage: +37 % of the arena at l32 that an fp32 model or "norm_fold" 0 / "reference_order" never reads
     const bool pf = fold_wanted(e);
+    const bool ps = split_wanted(e);
     e->emb = c.take(V * D * esz);
     e->emb_f32 = (float*)c.take(V * D * 4);
     e->normf_w = (float*)c.take(D * 4);
@@ -135,6 +152,8 @@ void carve_weights(pcad_engine* e, Carver& c) {
         L.W_in_f = pf ? c.take(2 * E * D * esz) : nullptr;
         L.W_out = c.take(D * E * esz);
         L.W_out_p = pf && (size_t)fold_padded_width((int)D) != D ? c.take((size_t)fold_padded_width((int)D) * E * esz) : L.W_out;
+        L.W_in_s = ps ? c.take(2 * E * 3 * D * 2) : nullptr;
+        L.W_out_s = ps ? c.take(D * 3 * E * 2) : nullptr;
         for (int d = 0; d < 2; ++d) {
             DirWeights& w = L.dir[d];
             w.conv_w = (float*)c.take(E * 4 * 4);
@@ -150,6 +169,7 @@ void carve_weights(pcad_engine* e, Carver& c) {
 
 struct Workspace {
     void *res, *u, *h, *xz, *zb, *xc[2], *dtl[2], *y;
+    void* ys;        // "f32_gemm_split": out_proj's operand, bf16 [rows8, 3E] blocked = [hi | lo | hi] of y; else nullptr
     float* bc[2];
     float *rstd, *ssq;   // norm-folded form: rstd [rows]; partial sums of squares [rows, D / 128]
     float* seg;      // segmented-scan scratch (long sequences with few strands), or nullptr
@@ -163,7 +183,8 @@ Workspace carve_workspace(const pcad_engine* e, void* base, int Bc, int L) {
     Workspace w;
     const size_t Dp = fold_padded_width((int)D);       // the folded form keeps res / u Dp = round_up(D, 256) columns wide
     w.res = c.take(rows * Dp * (e->rdt == F32 ? 4 : esz));
-    w.u = c.take(rows * Dp * esz);
+    const bool sp = split_wanted(e);
+    w.u = c.take(sp && rows * 3 * D * 2 > rows * Dp * esz ? rows * 3 * D * 2 : rows * Dp * esz);   // split: bf16 [rows, 3D] = [hi | lo | hi]
     w.h = c.take(rows * D * esz);
     const size_t rows8z = (rows + 7) / 8 * 8;
     // in_proj output: plain xz [rows, 2E]; or (xzsplit) x [rows8, E] in `xz` and z [rows8, E] in `zb`, both blocked
@@ -177,6 +198,7 @@ Workspace carve_workspace(const pcad_engine* e, void* base, int Bc, int L) {
     w.bc[0] = (float*)c.take(rows * 2 * e->N * 4);   // B_t | C_t rows, fp32 (values rounded to the model dtype)
     w.bc[1] = (float*)c.take(rows * 2 * e->N * 4);
     w.y = c.take(rows8 * E * esz);
+    w.ys = sp ? c.take(rows8 * 3 * E * 2) : nullptr;
     w.rstd = (float*)c.take(rows * 4);
     w.ssq = (float*)c.take(rows * (Dp / 128) * 4);
     const size_t segb = e->segments ? scan_segment_bytes(2 * Bc, L, (int)E) : 0;
@@ -264,7 +286,7 @@ int pcad_create(const pcad_config* cfg, pcad_handle* out) {
     // of the scan should fill the chip's 4096 wave slots (2 strands x E/64 waves per window).
     e->chunk = ck ? atoi(ck) : 0;
     if (e->chunk < 0) e->chunk = 0;
-    e->chunk_rows = ((((int64_t)1 << 32) - ((int64_t)2 << 20)) / ((int64_t)e->E * e->esz)) & ~(int64_t)7;
+    e->chunk_rows = 0;        // derived per call from the options in force: chunk_row_limit()
     // developer A/B switches (honoured only with PCAD_DEV=1): plain layouts / unfused conv
     e->blocked = dev_env("PCAD_PLAIN_LAYOUT") == nullptr && (e->E * e->esz) % 128 == 0;
     e->xzsplit = e->blocked && dev_env("PCAD_PLAIN_XZ") == nullptr && e->E % 16 == 0;
@@ -292,6 +314,8 @@ int pcad_set_option(pcad_handle h, const char* key, int64_t value) {
         h->gate_once = value == 0;
     } else if (k == "norm_fold") {
         h->norm_fold = value < 0 ? -1 : (value != 0 ? 1 : 0);
+    } else if (k == "f32_gemm_split") {
+        h->f32_split = value != 0;
     } else if (k == "reference_order") {
         // one switch for "every rounding point where the reference has it" (BiMambaWrapper + rms_norm_fn + mamba_inner_fn):
         //   1  = gate_each 1 + norm_fold 0 (which also means no layer-0 in_proj table): only the tied out_proj fold remains
@@ -389,6 +413,8 @@ int pcad_bind_weights(pcad_handle h, const pcad_tensor* tensors, int n, void* ar
         NEED(t_out, mf + "out_proj.weight", (int64_t)D * E);
         HIP_TRY(launch_pack2d(t_out->data, t_out->dtype, E, L.W_out, dt, E, D, E, D, E, s));
         if (L.W_out_p != L.W_out) HIP_TRY(launch_pack2d(t_out->data, t_out->dtype, E, L.W_out_p, dt, E, D, E, fold_padded_width(D), E, s));
+        if (L.W_in_s) HIP_TRY(launch_pack_split3_w(t_in->data, t_in->dtype, D, L.W_in_s, 2 * E, D, s));
+        if (L.W_out_s) HIP_TRY(launch_pack_split3_w(t_out->data, t_out->dtype, E, L.W_out_s, D, E, s));
         for (int d = 0; d < 2; ++d) {
             DirWeights& w = L.dir[d];
             const std::string mp = lp + "mixer.submodule.mamba_" + (d == 0 ? "fwd." : "rev.");
@@ -418,6 +444,7 @@ int pcad_bind_weights(pcad_handle h, const pcad_tensor* tensors, int n, void* ar
     // layer 0's in_proj (norm-folded form) as a table over the V token ids: emb and layer 0's folded in_proj weight are packed above
     if (e->xz_tab0) HIP_TRY(launch_embed_inproj_table(e->emb, e->layers[0].W_in_f, e->xz_tab0, V, D, 2 * E, e->cfg.eps, dt, s));
     e->fold_packed = fold_wanted(e);
+    e->split_packed = split_wanted(e);
     e->bound = true;
     return PCAD_OK;
 }
@@ -425,7 +452,8 @@ int pcad_bind_weights(pcad_handle h, const pcad_tensor* tensors, int n, void* ar
 // windows per chunk for a batch of B windows of L positions: the fewest chunks within the row limit, evenly sized (no small
 // tail chunk)
 static int chunk_for(const pcad_engine* e, int B, int L) {
-    int64_t cap = e->chunk > 0 ? e->chunk : e->chunk_rows / (2 * (int64_t)L);
+    int64_t cap = chunk_row_limit(e) / (2 * (int64_t)L);
+    if (e->chunk > 0 && e->chunk < cap) cap = e->chunk;
     if (cap < 1) cap = 1;
     const int64_t n = (B + cap - 1) / cap;
     return (int)((B + n - 1) / n);
@@ -505,6 +533,13 @@ static int forward_impl(pcad_handle h, const int32_t* ids, int B, int L, const i
             return fail(PCAD_ERR_INVALID, "pcad_forward: \"norm_fold\" 1 was set after pcad_bind_weights; the folded form's weight copies are "
                                           "packed at bind time - set the option before pcad_weight_arena_bytes / pcad_bind_weights");
     }
+    if (split_wanted(e) && !e->split_packed)
+        return fail(PCAD_ERR_INVALID, "pcad_forward: \"f32_gemm_split\" 1 was set after pcad_bind_weights; the split weight copies are packed at "
+                                      "bind time - set the option before pcad_weight_arena_bytes / pcad_bind_weights");
+    // Split-bf16 GEMMs of the fp32 model ("f32_gemm_split"; pack.hip): in_proj and out_proj - 3/4 of the fp32 model's time on the
+    // fp32 MFMA instructions - run as bf16 GEMMs with K' = 3 K on [hi | lo | hi] x [hi | hi | lo] operands and an fp32 result:
+    // operand error 2^-17, measured 4e-7 of the logits' range after 32 layers (fp32 MFMA: 1e-6 from summation order alone).
+    const bool sp = split_wanted(e) && e->split_packed;
     bool fold_all = fold_wanted(e) && e->fold_packed && !all_hidden;
     for (int ck = 0; ck < nchunks && fold_all; ++ck) {
         const int Bc = (B - ck * chunk) < chunk ? (B - ck * chunk) : chunk;
@@ -536,10 +571,10 @@ static int forward_impl(pcad_handle h, const int32_t* ids, int B, int L, const i
                 HIP_TRY(launch_assemble_hidden(c.w.h, (char*)all_hidden + ((size_t)c.b0 * L * 2 * D) * esz, c.Bc, L, D, dt, s));
             }
             ProfScope ps(e, PCAD_K_NORM, s);
-            HIP_TRY(launch_embed_rmsnorm(ids_c, e->emb, e->comp, W.norm_w, c.w.u, c.w.res, c.Bc, L, D, eps, dt, rdt, s));
+            HIP_TRY(launch_embed_rmsnorm(ids_c, e->emb, e->comp, W.norm_w, c.w.u, c.w.res, c.Bc, L, D, eps, dt, rdt, s, nullptr, 0, sp));
         } else {
             ProfScope ps(e, PCAD_K_NORM, s);
-            HIP_TRY(launch_add_rmsnorm(c.w.h, c.w.res, W.norm_w, c.w.u, c.w.res, rows, D, eps, dt, rdt, s));
+            HIP_TRY(launch_add_rmsnorm(c.w.h, c.w.res, W.norm_w, c.w.u, c.w.res, rows, D, eps, dt, rdt, s, sp));
         }
         return PCAD_OK;
     };
@@ -558,6 +593,7 @@ static int forward_impl(pcad_handle h, const int32_t* ids, int B, int L, const i
         for (int rep = 0; rep < reps(PCAD_K_GEMM_IN); ++rep)
         { ProfScope ps(e, PCAD_K_GEMM_IN, s);
         if (c.fold) HIP_TRY(launch_gemm_nt_two(c.w.u, Dp, W.W_in_f, D, c.w.xz, c.w.zb, E, true, rows, 2 * E, D, dt, s, c.w.rstd));
+        else if (sp) HIP_TRY(launch_gemm_nt_two(c.w.u, 3 * D, W.W_in_s, 3 * D, c.w.xz, c.w.zb, E, true, rows, 2 * E, 3 * D, BF16, s, nullptr, F32));
         else if (e->xzsplit) HIP_TRY(launch_gemm_nt_two(c.w.u, D, W.W_in, D, c.w.xz, c.w.zb, E, true, rows, 2 * E, D, dt, s));
         else HIP_TRY(launch_gemm_nt(c.w.u, D, W.W_in, D, c.w.xz, 2 * E, rows, 2 * E, D, dt, dt, false, s)); }
         // conv1d + SiLU, causal and anti-causal from one read of x (fused with x_proj of both directions when possible)
@@ -594,6 +630,15 @@ static int forward_impl(pcad_handle h, const int32_t* ids, int B, int L, const i
         const bool last_short = walk_len > 0 && li + 1 == e->nl;
         // strict reference order ("reference_order" 2; never with norm_fold): the reverse direction's gated output goes to its own
         // tensor (xc[0]: the forward scan, its only reader, has run) and each direction gets its own tied out_proj below
+        // the full-size tied out_proj of one [rows, E] tensor (y, or in the strict order each direction's own): fp32 / bf16 GEMM, or the
+        // split-bf16 form (operand conversion + bf16 GEMM with K' = 3E, fp32 result)
+        auto out_proj_full = [&](const void* ysrc, void* dst) -> hipError_t {
+            if (sp) {
+                if (hipError_t er = launch_split3_rows((const float*)ysrc, E, c.w.ys, rows, E, e->blocked, e->blocked, s)) return er;
+                return launch_gemm_nt(c.w.ys, 3 * E, W.W_out_s, 3 * E, dst, D, rows, D, 3 * E, BF16, F32, false, s, e->blocked);
+            }
+            return launch_gemm_nt(ysrc, E, W.W_out, E, dst, D, rows, D, E, dt, dt, false, s, e->blocked);
+        };
         const bool strict = e->ref_order == 2 && !c.fold;
         void* y_rev = strict ? c.w.xc[0] : c.w.y;
         for (int d = 0; d < 2; ++d) {
@@ -630,9 +675,9 @@ static int forward_impl(pcad_handle h, const int32_t* ids, int B, int L, const i
                 return PCAD_OK;
             }
             { ProfScope ps(e, PCAD_K_GEMM_OUT, s);
-            HIP_TRY(launch_gemm_nt(c.w.y, E, W.W_out, E, c.w.h, D, rows, D, E, dt, dt, false, s, e->blocked)); }
+            HIP_TRY(out_proj_full(c.w.y, c.w.h)); }
             { ProfScope ps(e, PCAD_K_GEMM_OUT, s);
-            HIP_TRY(launch_gemm_nt(y_rev, E, W.W_out, E, c.w.u, D, rows, D, E, dt, dt, false, s, e->blocked)); }
+            HIP_TRY(out_proj_full(y_rev, c.w.u)); }
             { ProfScope ps(e, PCAD_K_NORM, s);
             HIP_TRY(launch_add_round(c.w.h, c.w.u, rows * D, dt, s)); }
             if (all_hidden && li + 1 < e->nl) {
@@ -657,7 +702,7 @@ static int forward_impl(pcad_handle h, const int32_t* ids, int B, int L, const i
         // out_proj on (y_fwd + y_rev): the two tied out_proj calls folded by linearity
         for (int rep = 0; rep < reps(PCAD_K_GEMM_OUT); ++rep)
         { ProfScope ps(e, PCAD_K_GEMM_OUT, s);
-        HIP_TRY(launch_gemm_nt(c.w.y, E, W.W_out, E, c.w.h, D, rows, D, E, dt, dt, false, s, e->blocked)); }
+        HIP_TRY(out_proj_full(c.w.y, c.w.h)); }
         if (all_hidden && li + 1 < e->nl) {
             char* dst = (char*)all_hidden + ((size_t)(li + 1) * B * L * 2 * D + (size_t)c.b0 * L * 2 * D) * esz;
             HIP_TRY(launch_assemble_hidden(c.w.h, dst, c.Bc, L, D, dt, s));
@@ -834,6 +879,29 @@ int pcad_gemm_nt(const void* A, int64_t lda, const void* W, int64_t ldw, void* C
     if (err == hipErrorInvalidValue)
         return fail(PCAD_ERR_INVALID, "pcad_gemm_nt: K*elem must be a multiple of 128 bytes; A/W 16-byte aligned rows");
     if (err != hipSuccess) return fail(PCAD_ERR_HIP, "pcad_gemm_nt: %s", hipGetErrorString(err));
+    return PCAD_OK;
+}
+
+size_t pcad_gemm_nt_split_scratch_bytes(int64_t M, int N, int K) {
+    if (M <= 0 || N <= 0 || K <= 0) return 0;
+    return align_up((size_t)M * 3 * K * 2) + align_up((size_t)N * 3 * K * 2);
+}
+
+int pcad_gemm_nt_split(const float* A, int64_t lda, const float* W, int64_t ldw, float* C, int64_t ldc, int64_t M, int N, int K,
+                       void* scratch, size_t scratch_bytes, pcad_stream stream) {
+    if (!A || !W || !C || !scratch) return fail(PCAD_ERR_INVALID, "pcad_gemm_nt_split: null argument");
+    if (M < 0 || N <= 0 || K <= 0 || K % 64 || lda < K || ldw < K || ldc < N)
+        return fail(PCAD_ERR_INVALID, "pcad_gemm_nt_split: K must be a multiple of 64; lda, ldw >= K; ldc >= N");
+    if (((uintptr_t)scratch) % 256 || scratch_bytes < pcad_gemm_nt_split_scratch_bytes(M, N, K))
+        return fail(PCAD_ERR_WORKSPACE, "pcad_gemm_nt_split: scratch must be 256-byte aligned and pcad_gemm_nt_split_scratch_bytes large");
+    if (M == 0) return PCAD_OK;
+    hipStream_t s = (hipStream_t)stream;
+    void* As = scratch;
+    void* Ws = (char*)scratch + align_up((size_t)M * 3 * K * 2);
+    HIP_TRY(launch_split3_rows(A, lda, As, M, K, false, false, s));               // [hi | lo | hi]
+    HIP_TRY(launch_pack_split3_w(W, PCAD_F32, ldw, Ws, N, K, s));                 // [hi | hi | lo]
+    hipError_t err = launch_gemm_nt(As, 3 * (int64_t)K, Ws, 3 * (int64_t)K, C, ldc, M, N, 3 * K, BF16, F32, false, s, false);
+    if (err != hipSuccess) return fail(PCAD_ERR_HIP, "pcad_gemm_nt_split: %s", hipGetErrorString(err));
     return PCAD_OK;
 }
 

@@ -1100,7 +1100,9 @@ static bool quad_ok(int64_t lda, int64_t ldw, int64_t M, int N, bool two, int ns
            (int64_t)N * ldw * esz_ < ((int64_t)1 << 32) - 65536;
 }
 
-template <typename T>
+// OutT != T only as <bf16_t, float>: bf16 operands, fp32 result stored as fp32 (the split-bf16 GEMMs of the fp32 model, api.hip
+// "f32_gemm_split"); the fused epilogues exist for OutT == T only.
+template <typename T, typename OutT = T>
 static hipError_t launch_gemm256_t(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc, int64_t M,
                                    int N, int K, hipStream_t s, bool a_blocked, void* C2 = nullptr, int nsplit = 0,
                                    bool out_blocked = false, int epi_kind = EPI_NONE, GemmEpi epi = GemmEpi{nullptr, nullptr, nullptr}) {
@@ -1112,36 +1114,46 @@ static hipError_t launch_gemm256_t(const void* A, int64_t lda, const void* W, in
     if (epi_kind != EPI_NONE && !qok) return hipErrorInvalidValue;             // the fused epilogues exist on the 4-wave kernel only
 #define PCAD_LAUNCH_Q(EPIK)                                                                                                     \
     do {                                                                                                                        \
-        auto kq = gemm256q_kernel<T, T, EPIK>;                                                                                  \
+        auto kq = gemm256q_kernel<T, OutT, EPIK>;                                                                               \
         if (hipError_t ae = ensure_dynamic_lds((const void*)kq, GEMM3_LDS)) return ae;                                          \
-        hipLaunchKernelGGL(kq, grid, dim3(GEMMQ_THREADS), GEMM3_LDS, s, (const T*)A, lda, (const T*)W, ldw, (T*)C, ldc, M, N, K, \
-                           tiles_m, tiles_n, (int)a_blocked, (T*)C2, nsplit, (int)out_blocked, (int)epi_swap, epi);            \
+        hipLaunchKernelGGL(kq, grid, dim3(GEMMQ_THREADS), GEMM3_LDS, s, (const T*)A, lda, (const T*)W, ldw, (OutT*)C, ldc, M, N, K, \
+                           tiles_m, tiles_n, (int)a_blocked, (OutT*)C2, nsplit, (int)out_blocked, (int)epi_swap, epi);         \
                                                                                              \
         return hipGetLastError();                                                                                               \
     } while (0)
-    if (epi_kind == EPI_SCALE) PCAD_LAUNCH_Q(EPI_SCALE);
-    if (epi_kind == EPI_RES) PCAD_LAUNCH_Q(EPI_RES);
+    if constexpr (std::is_same<T, OutT>::value) {
+        if (epi_kind == EPI_SCALE) PCAD_LAUNCH_Q(EPI_SCALE);
+        if (epi_kind == EPI_RES) PCAD_LAUNCH_Q(EPI_RES);
+    } else if (epi_kind != EPI_NONE) {
+        return hipErrorInvalidValue;
+    }
     if (quad && qok) PCAD_LAUNCH_Q(EPI_NONE);
 #undef PCAD_LAUNCH_Q
-    auto kr = gemm256r_kernel<T, T>;
+    auto kr = gemm256r_kernel<T, OutT>;
     if (hipError_t ae = ensure_dynamic_lds((const void*)kr, GEMM3_LDS)) return ae;
-    hipLaunchKernelGGL(kr, grid, block, GEMM3_LDS, s, (const T*)A, lda, (const T*)W, ldw, (T*)C, ldc, M, N, K, tiles_m,
-                       tiles_n, (int)a_blocked, (T*)C2, nsplit, (int)out_blocked);
+    hipLaunchKernelGGL(kr, grid, block, GEMM3_LDS, s, (const T*)A, lda, (const T*)W, ldw, (OutT*)C, ldc, M, N, K, tiles_m,
+                       tiles_n, (int)a_blocked, (OutT*)C2, nsplit, (int)out_blocked);
     return hipGetLastError();
 }
 
 // in_proj form on the 256x256 kernel: columns [0, nsplit) -> C1, [nsplit, N) -> C2: two separate tensors of nsplit and
 // N - nsplit columns, plain (contiguous rows) or both in the blocked layout.
 hipError_t launch_gemm_nt_two(const void* A, int64_t lda, const void* W, int64_t ldw, void* C1, void* C2, int nsplit,
-                              bool out_blocked, int64_t M, int N, int K, int dt, hipStream_t s, const float* rscale) {
+                              bool out_blocked, int64_t M, int N, int K, int dt, hipStream_t s, const float* rscale, int out_dt) {
     if (M <= 0 || N <= 0) return hipSuccess;
     const int esz = dt == BF16 ? 2 : 4;
+    if (out_dt < 0) out_dt = dt;
+    const int osz = out_dt == BF16 ? 2 : 4;
     if (K <= 0 || (K * esz) % ROWB || nsplit % 16 || N % 16 || nsplit <= 0 || nsplit >= N) return hipErrorInvalidValue;
     if ((lda * esz) % 16 || (ldw * esz) % 16 || ((uintptr_t)A) % 16 || ((uintptr_t)W) % 16) return hipErrorInvalidValue;
     if (((uintptr_t)C1) % 16 || ((uintptr_t)C2) % 16) return hipErrorInvalidValue;
-    if (out_blocked && ((nsplit * esz) % 128 || ((N - nsplit) * esz) % 128)) return hipErrorInvalidValue;
+    if (out_blocked && ((nsplit * osz) % 128 || ((N - nsplit) * osz) % 128)) return hipErrorInvalidValue;
     const int ek = rscale ? EPI_SCALE : EPI_NONE;
     const GemmEpi epi{rscale, nullptr, nullptr};
+    if (out_dt != dt) {                    // bf16 operands -> fp32 outputs (split-bf16 in_proj of the fp32 model)
+        if (dt != BF16 || out_dt != F32 || rscale) return hipErrorInvalidValue;
+        return launch_gemm256_t<bf16_t, float>(A, lda, W, ldw, C1, nsplit, M, N, K, s, false, C2, nsplit, out_blocked, EPI_NONE, epi);
+    }
     if (dt == BF16) return launch_gemm256_t<bf16_t>(A, lda, W, ldw, C1, nsplit, M, N, K, s, false, C2, nsplit, out_blocked, ek, epi);
     return launch_gemm256_t<float>(A, lda, W, ldw, C1, nsplit, M, N, K, s, false, C2, nsplit, out_blocked, ek, epi);
 }
@@ -1183,9 +1195,11 @@ hipError_t launch_gemm_nt(const void* A, int64_t lda, const void* W, int64_t ldw
         return hipErrorInvalidValue;
     if (a_blocked && (lda * esz) % 128) return hipErrorInvalidValue;
     static const bool no256 = dev_env("PCAD_GEMM_NO256") != nullptr;      // PCAD_DEV=1 only: force the 256x128 kernel
-    const bool big = !no256 && M >= 2048 && N >= 512 && N % 16 == 0 && out_dt == dt &&
-                     (ldc * esz) % 16 == 0 && ((uintptr_t)C) % 16 == 0;
+    const int osz = out_dt == BF16 ? 2 : 4;
+    const bool big = !no256 && M >= 2048 && N >= 512 && N % 16 == 0 && (out_dt == dt || (dt == BF16 && out_dt == F32 && !round_bf16)) &&
+                     (ldc * osz) % 16 == 0 && ((uintptr_t)C) % 16 == 0;
     if (big) {
+        if (dt == BF16 && out_dt == F32) return launch_gemm256_t<bf16_t, float>(A, lda, W, ldw, C, ldc, M, N, K, s, a_blocked);
         if (dt == BF16) return launch_gemm256_t<bf16_t>(A, lda, W, ldw, C, ldc, M, N, K, s, a_blocked);
         return launch_gemm256_t<float>(A, lda, W, ldw, C, ldc, M, N, K, s, a_blocked);
     }

@@ -28,15 +28,17 @@ struct Positions {            // by-value kernel argument: the positions evaluat
 
 // norm.hip --------------------------------------------------------------------------------------
 // fused residual add + RMSNorm (rms_norm_fn prenorm=True).  x/y dtype `dt`; residuals `rdt`.
+// split_y (dt == F32 only): y is written as a bf16 tensor [rows, 3 D] = [hi | lo | hi] (pack.hip launch_split3_rows' format).
 hipError_t launch_add_rmsnorm(const void* x, const void* res_in, const float* w, void* y, void* res_out,
-                              int64_t rows, int D, float eps, int dt, int rdt, hipStream_t s);
+                              int64_t rows, int D, float eps, int dt, int rdt, hipStream_t s, bool split_y = false);
 // layer-0 variant: x = Emb[strand token] gathered on the fly (RCPS strands by index arithmetic).
 // rstd_out != nullptr: the norm-folded form - y (may be nullptr) = the un-normalised embedding row, rstd_out[row] = its rstd, and
 // res_out (fp32) is written in the 4-wave GEMM's fragment layout (common.hpp res_frag_off; 2 B L % 256 == 0) as a tensor of
 // Dp = round_up(D, 256) columns whose padding columns are zeroed; y rows are Dp elements apart.
 hipError_t launch_embed_rmsnorm(const int32_t* ids, const void* emb, const int32_t* comp8, const float* w,
                                 void* y, void* res_out, int B, int L, int D, float eps, int dt, int rdt,
-                                hipStream_t s, float* rstd_out = nullptr, int Dp = 0);    // Dp: padded width of res / y rows (0: D)
+                                hipStream_t s, float* rstd_out = nullptr, int Dp = 0,     // Dp: padded width of res / y rows (0: D)
+                                bool split_y = false);
 // rstd[row] = rsqrt(sum of the np partial sums of squares of the row / D + eps)
 hipError_t launch_rstd(const float* ssq, float* rstd, int64_t rows, int np, int D, float eps, hipStream_t s);
 // final add + norm_f + RC re-assembly + tied RCPS LM head, only at the requested positions (a shared list `pos`,
@@ -71,8 +73,10 @@ hipError_t launch_gemm_nt_split(const void* A, int64_t lda, const void* W, int64
 // in_proj form on the 256x256 kernel: columns [0, nsplit) -> C1, [nsplit, N) -> C2 (separate tensors of nsplit and
 // N - nsplit columns; both plain or both blocked).
 // rscale (or nullptr): per-row factor [M] applied to the result before it is rounded (the norm-folded in_proj: rstd of the row).
+// out_dt: -1 = dt; F32 with dt == BF16: bf16 operands, fp32 outputs (no rscale) - the split-bf16 in_proj of the fp32 model.
 hipError_t launch_gemm_nt_two(const void* A, int64_t lda, const void* W, int64_t ldw, void* C1, void* C2, int nsplit,
-                              bool out_blocked, int64_t M, int N, int K, int dt, hipStream_t s, const float* rscale = nullptr);
+                              bool out_blocked, int64_t M, int N, int K, int dt, hipStream_t s, const float* rscale = nullptr,
+                              int out_dt = -1);
 
 // out_proj of the norm-folded layer form, on the 4-wave kernel only (gemm_fold_shapes_ok):
 //   res [M, N] fp32 (FRAGMENT layout, common.hpp res_frag_off) += A . W^T (in place);  C [M, N] (plain rows, dtype dt; unused for
@@ -164,6 +168,13 @@ hipError_t launch_pack_scale_cols(const void* src, int src_dt, int64_t src_ld, c
 hipError_t launch_embed_inproj_table(const void* emb, const void* Wf, void* tab, int V, int D, int N2, float eps, int dt, hipStream_t s);
 hipError_t launch_embed_xz_gather(const int32_t* ids, const int32_t* comp8, const void* tab, void* x, void* z, int B, int L, int E, int dt,
                                   hipStream_t s);
+// split-bf16 operands of the fp32 model's big GEMMs ("f32_gemm_split"): v = hi + lo, hi = bf16(v), lo = bf16(v - hi);
+//   weights     [rows, cols] (fp32 / bf16 source) -> bf16 [rows, 3 cols] = [hi | hi | lo]               (bind time)
+//   activations fp32 [rows, K] (plain or blocked) -> bf16 [rows, 3 K]    = [hi | lo | hi] (plain or blocked), K % 64 == 0
+// so that a_hi w_hi + a_lo w_hi + a_hi w_lo is ONE bf16 GEMM with K' = 3 K and an fp32 result.
+hipError_t launch_pack_split3_w(const void* src, int src_dt, int64_t src_ld, void* dst, int rows, int cols, hipStream_t s);
+hipError_t launch_split3_rows(const float* src, int64_t src_ld, void* dst, int64_t rows, int K, bool src_blocked, bool dst_blocked,
+                              hipStream_t s);      // src_ld: elements between plain source rows (ignored for a blocked source)
 // A2[e, n] = -exp(A_log[e, n]) * log2(e)   (A_log read through its storage dtype)
 hipError_t launch_pack_A(const void* A_log, int src_dt, float* A2, int64_t n, float scale, hipStream_t s);
 

@@ -7,6 +7,8 @@
 // (RCPSEmbedding: rc strand = complement of the reversed ids, by index arithmetic), and the final variant
 // fuses norm_f, the RC re-assembly of hidden_states[-1] and the tied RCPS LM head at the requested
 // positions only.
+#include <type_traits>
+
 #include "common.hpp"
 #include "kernels.hpp"
 
@@ -16,7 +18,9 @@ constexpr int PCAD_STATUS_BAD_TOKEN_BIT = 1, PCAD_STATUS_BAD_POSITION_BIT = 2;  
 
 // FOLD (norm-folded layer form, api.hip): y = the UN-normalised sum rounded to the model dtype and rstd_out[row] = its rstd; the
 // norm weight lives in the in_proj weight (folded at bind time) and rstd is applied by in_proj's epilogue.
-template <typename T, typename RT, int MAXC, bool EMBED, bool FOLD = false>
+// SPLIT (T == float only; api.hip "f32_gemm_split"): y is a bf16 tensor [rows, 3 D] = [hi | lo | hi] of the normalised row
+// (hi = bf16(v), lo = bf16(v - hi)): the A operand of the split-bf16 in_proj (pack.hip), written here instead of the fp32 row.
+template <typename T, typename RT, int MAXC, bool EMBED, bool FOLD = false, bool SPLIT = false>
 __global__ __launch_bounds__(256) void add_rmsnorm_kernel(const T* __restrict__ x, const RT* __restrict__ res_in,
                                                           const float* __restrict__ w, T* __restrict__ y,
                                                           RT* __restrict__ res_out, int64_t rows, int D, float eps,
@@ -90,7 +94,17 @@ __global__ __launch_bounds__(256) void add_rmsnorm_kernel(const T* __restrict__ 
             load8<float>(w + c * 8, wv);
 #pragma unroll
             for (int i = 0; i < 8; ++i) o[i] = v[j][i] * rstd * wv[i];
-            store8<T>(y + row * D + c * 8, o);
+            if constexpr (SPLIT) {
+                bf16_t* ys = reinterpret_cast<bf16_t*>(y) + row * 3 * D + c * 8;
+                float lo[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) lo[i] = o[i] - round_to_bf16(o[i]);
+                store8<bf16_t>(ys, o);
+                store8<bf16_t>(ys + D, lo);
+                store8<bf16_t>(ys + 2 * D, o);
+            } else {
+                store8<T>(y + row * D + c * 8, o);
+            }
         }
     }
 }
@@ -124,9 +138,21 @@ hipError_t launch_rstd(const float* ssq, float* rstd, int64_t rows, int np, int 
 template <typename T, typename RT, bool EMBED>
 static hipError_t launch_norm_t(const T* x, const RT* res_in, const float* w, T* y, RT* res_out, int64_t rows, int D,
                                 float eps, const int32_t* ids, const int32_t* comp8, int B, int L, hipStream_t s,
-                                float* rstd_out = nullptr, int Dp = 0) {
+                                float* rstd_out = nullptr, int Dp = 0, bool split = false) {
     if (rows <= 0) return hipSuccess;
     dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+    if constexpr (std::is_same<T, float>::value && std::is_same<RT, float>::value) {
+        if (split) {                          // fp32 model, split-bf16 in_proj operand
+            if (D <= 512)
+                hipLaunchKernelGGL((add_rmsnorm_kernel<T, RT, 1, EMBED, false, true>), grid, block, 0, s, x, res_in, w, y, res_out, rows, D, eps, ids, comp8, B, L, nullptr, 0);
+            else if (D <= 1024)
+                hipLaunchKernelGGL((add_rmsnorm_kernel<T, RT, 2, EMBED, false, true>), grid, block, 0, s, x, res_in, w, y, res_out, rows, D, eps, ids, comp8, B, L, nullptr, 0);
+            else
+                hipLaunchKernelGGL((add_rmsnorm_kernel<T, RT, 4, EMBED, false, true>), grid, block, 0, s, x, res_in, w, y, res_out, rows, D, eps, ids, comp8, B, L, nullptr, 0);
+            return hipGetLastError();
+        }
+    }
+    if (split) return hipErrorInvalidValue;
     if constexpr (EMBED) {
         if (rstd_out != nullptr) {            // layer 0 of the norm-folded form
             if (D <= 512)
@@ -153,8 +179,9 @@ static hipError_t launch_norm_t(const T* x, const RT* res_in, const float* w, T*
 template <bool EMBED>
 static hipError_t dispatch_norm(const void* x, const void* res_in, const float* w, void* y, void* res_out,
                                 int64_t rows, int D, float eps, int dt, int rdt, const int32_t* ids,
-                                const int32_t* comp8, int B, int L, hipStream_t s, float* rstd_out = nullptr, int Dp = 0) {
+                                const int32_t* comp8, int B, int L, hipStream_t s, float* rstd_out = nullptr, int Dp = 0, bool split = false) {
     if (D % 8 || D > 2048) return hipErrorInvalidValue;
+    if (split && !(dt == F32 && rdt == F32 && rstd_out == nullptr)) return hipErrorInvalidValue;
     if (Dp == 0) Dp = D;
     if (dt == BF16 && rdt == F32)
         return launch_norm_t<bf16_t, float, EMBED>((const bf16_t*)x, (const float*)res_in, w, (bf16_t*)y,
@@ -164,18 +191,19 @@ static hipError_t dispatch_norm(const void* x, const void* res_in, const float* 
                                                      (bf16_t*)res_out, rows, D, eps, ids, comp8, B, L, s, rstd_out, Dp);
     if (dt == F32 && rdt == F32)
         return launch_norm_t<float, float, EMBED>((const float*)x, (const float*)res_in, w, (float*)y,
-                                                   (float*)res_out, rows, D, eps, ids, comp8, B, L, s, rstd_out, Dp);
+                                                   (float*)res_out, rows, D, eps, ids, comp8, B, L, s, rstd_out, Dp, split);
     return hipErrorInvalidValue;
 }
 
 hipError_t launch_add_rmsnorm(const void* x, const void* res_in, const float* w, void* y, void* res_out, int64_t rows,
-                              int D, float eps, int dt, int rdt, hipStream_t s) {
-    return dispatch_norm<false>(x, res_in, w, y, res_out, rows, D, eps, dt, rdt, nullptr, nullptr, 0, 1, s);
+                              int D, float eps, int dt, int rdt, hipStream_t s, bool split_y) {
+    return dispatch_norm<false>(x, res_in, w, y, res_out, rows, D, eps, dt, rdt, nullptr, nullptr, 0, 1, s, nullptr, 0, split_y);
 }
 
 hipError_t launch_embed_rmsnorm(const int32_t* ids, const void* emb, const int32_t* comp8, const float* w, void* y,
-                                void* res_out, int B, int L, int D, float eps, int dt, int rdt, hipStream_t s, float* rstd_out, int Dp) {
-    return dispatch_norm<true>(emb, nullptr, w, y, res_out, (int64_t)2 * B * L, D, eps, dt, rdt, ids, comp8, B, L, s, rstd_out, Dp);
+                                void* res_out, int B, int L, int D, float eps, int dt, int rdt, hipStream_t s, float* rstd_out, int Dp,
+                                bool split_y) {
+    return dispatch_norm<true>(emb, nullptr, w, y, res_out, (int64_t)2 * B * L, D, eps, dt, rdt, ids, comp8, B, L, s, rstd_out, Dp, split_y);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -490,6 +490,11 @@ hipError_t launch_scan(const void* u, const void* z, int64_t ldz, const void* de
         if (fused) return launch_scan_t<bf16_t, true>(u, z, ldz, dt_low, lddt, Wdt, Rp, bc, A2, a_scale, Dskip, dbias, y, S, L, E, reverse, accumulate, s, uyb, zblk, seg_ws, walk_len);
         return launch_scan_t<bf16_t, false>(u, z, ldz, delta, E, nullptr, 0, bc, A2, a_scale, Dskip, dbias, y, S, L, E, reverse, accumulate, s, uyb, zblk, seg_ws, walk_len);
     }
+    // the fp32 engine's case (blocked u / y / z, L % 8 == 0): layouts known at compile time like the bf16 instantiation above (one
+    // scalar block offset per 4-step chunk, per-step offsets in the immediates); dt_proj stays on v_mfma_f32_32x32x2_f32, unprefetched
+    static const bool f32_generic = dev_env("PCAD_SCAN_F32_GENERIC") != nullptr;       // PCAD_DEV=1 A/B: the run-time-layout instantiation
+    if (!f32_generic && fused && uyb && L % 8 == 0 && zblk)
+        return launch_scan_t<float, true, 0, true, true>(u, z, ldz, dt_low, lddt, Wdt, Rp, bc, A2, a_scale, Dskip, dbias, y, S, L, E, reverse, accumulate, s, uyb, zblk, seg_ws, walk_len);
     if (fused) return launch_scan_t<float, true>(u, z, ldz, dt_low, lddt, Wdt, Rp, bc, A2, a_scale, Dskip, dbias, y, S, L, E, reverse, accumulate, s, uyb, zblk, seg_ws, walk_len);
     return launch_scan_t<float, false>(u, z, ldz, delta, E, nullptr, 0, bc, A2, a_scale, Dskip, dbias, y, S, L, E, reverse, accumulate, s, uyb, zblk, seg_ws, walk_len);
 }

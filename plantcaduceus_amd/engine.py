@@ -73,6 +73,9 @@ SIGNATURES = {
                                C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "pcad_gemm_nt_residual": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
                                         C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "pcad_gemm_nt_split_scratch_bytes": (C.c_size_t, [C.c_int64, C.c_int, C.c_int]),
+    "pcad_gemm_nt_split": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int,
+                                     C.c_void_p, C.c_size_t, C.c_void_p]),
     "pcad_gather_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int32), C.c_int, C.c_int,
                                    C.c_void_p]),
     "pcad_final_head": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
@@ -304,8 +307,10 @@ class Engine:
 
     def set_option(self, key: str, value: int):
         """`pcad_set_option` (include/pcad.h): "chunk_seqs" (windows per pass through the stack), "gate_each" (reference-order
-        SiLU gate), "norm_fold" (add + RMSNorm folded into out_proj's epilogue / in_proj), "scan_segments" (segmented scan of long
-        strands), "last_layer_shortcut", "poison_workspace" (debug)."""
+        SiLU gate), "norm_fold" (add + RMSNorm folded into out_proj's epilogue / in_proj), "reference_order" (0 / 1 / 2: one switch for
+        the reference's rounding points), "f32_gemm_split" (fp32 model: split-bf16 in_proj / out_proj), "scan_segments" (segmented
+        scan of long strands), "last_layer_shortcut", "poison_workspace" (debug).  "norm_fold" 1 on an fp32 model and
+        "f32_gemm_split" need weight copies packed at bind time: pass them as `config.engine_options` (applied before binding)."""
         _check(self.lib.pcad_set_option(self._h, key.encode(), int(value)), "pcad_set_option")
         self._ws = None
 

@@ -299,6 +299,27 @@ def linear(x, weight, out_dtype: Optional[torch.dtype] = None):
     return out.view(*x.shape[:-1], N)
 
 
+def linear_split(x, weight):
+    """F.linear(x, weight) of fp32 tensors as ONE split-bf16 GEMM on the bf16 matrix pipes (include/pcad.h pcad_gemm_nt_split):
+    x [..., K], weight [N, K], K % 64 == 0 -> fp32 [..., N]."""
+    _require_gpu(x, "x")
+    lib = load_library()
+    if x.dtype != torch.float32:
+        raise ValueError("linear_split takes fp32 tensors")
+    K = x.shape[-1]
+    N = weight.shape[0]
+    xf = x.contiguous().view(-1, K)
+    wf = weight.float().contiguous()
+    M = xf.shape[0]
+    out = torch.empty((M, N), dtype=torch.float32, device=x.device)
+    nb = lib.pcad_gemm_nt_split_scratch_bytes(M, N, K)
+    scratch = torch.empty(nb + 256, dtype=torch.uint8, device=x.device)
+    with torch.cuda.device(x.device):
+        _check(lib.pcad_gemm_nt_split(xf.data_ptr(), K, wf.data_ptr(), K, out.data_ptr(), N, M, N, K,
+                                      (scratch.data_ptr() + 255) // 256 * 256, nb, _stream_ptr()), "pcad_gemm_nt_split")
+    return out.view(*x.shape[:-1], N)
+
+
 def to_res_fragment(res: torch.Tensor) -> torch.Tensor:
     """[M, N] (M, N multiples of 256) -> the same values in the 4-wave GEMM's fragment layout (include/pcad.h
     pcad_gemm_nt_residual), as a flat [M * N] tensor."""

@@ -134,6 +134,33 @@ def test_full_depth_bf16_engine_options_against_reference_order():
     assert d["norm_fold"] <= 2 * max(d["default"], floor) + 1e-3
 
 
+@pytest.mark.parametrize("size,n", [("l20", 16), ("l32", 16)])
+def test_full_depth_fp32_split_gemm(size, n):
+    """north_star's 1e-4 (and exact arg-max) on the fp32 model at full depth with pcad_set_option("f32_gemm_split", 1): in_proj and
+    out_proj as split-bf16 GEMMs on the bf16 matrix pipes (three bf16 products per fp32 product, fp32 accumulation) - the
+    parity configuration at about twice the fp32-MFMA model's speed.  Same checkpoint, windows and oracle run as
+    test_full_depth_fp32 (memoised)."""
+    cfg = make_config(size)
+    sd = synthetic_state_dict(cfg, seed=21, stress=True)
+    ids = windows(n, 5)
+    lg_ref, hid_ref = oracle_forward((size, 21, True), sd, cfg, ids, want_hidden=True)
+    m = hip_model(cfg, sd, torch.float32, f32_gemm_split=1)
+    out = m(input_ids=torch.from_numpy(ids).to(DEV), output_hidden_states=True)
+    lg, hid = out.logits.cpu().numpy(), out.hidden_states[-1].cpu().numpy()
+    e_l = np.abs(lg - lg_ref).max() / np.abs(lg_ref).max()
+    e_h = np.abs(hid - hid_ref).max() / np.abs(hid_ref).max()
+    print(f"{size} fp32 full depth, f32_gemm_split=1: logits rel err {e_l:.2e}, hidden rel err {e_h:.2e}")
+    assert e_l < 1e-4 and e_h < 1e-4
+    assert (lg[:, P, 3:7].argmax(-1) == lg_ref[:, P, 3:7].argmax(-1)).all()
+    z = np.sort(lg_ref[..., 3:7], -1)
+    sure = (z[..., -1] - z[..., -2]) > 1e-4 * np.abs(lg_ref).max()
+    assert (lg[..., 3:7].argmax(-1)[sure] == lg_ref[..., 3:7].argmax(-1)[sure]).all()
+    # the positions fast path (last-layer shortcut: gathered rows through the plain fp32 GEMM) agrees with slicing the full output
+    # to fp32 rounding of the last out_proj (split vs fp32 MFMA on the evaluated rows)
+    lgp = m(input_ids=torch.from_numpy(ids).to(DEV), positions=[P]).logits[:, 0].cpu().numpy()
+    assert np.abs(lgp - lg[:, P]).max() / np.abs(lg_ref).max() < 2e-5
+
+
 def test_full_depth_fp32_norm_fold():
     """north_star's 1e-4 on the fp32 model, all 32 layers, with the folded add + norm forced on (norm_fold=1; the fp32 model's
     default is the reference-order launch, which test_full_depth_fp32 runs: accumulating the GEMM onto the residual value costs

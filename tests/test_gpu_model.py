@@ -395,3 +395,30 @@ def test_reference_order_strict_fp32(pos):
         assert len(allh) == len(ref["all_hidden"]) == cfg.n_layer + 1
         for i, (a, b) in enumerate(zip(allh, ref["all_hidden"])):
             assert ((a.cpu().float() - b).abs().max() / b.abs().max().clamp_min(1e-6)).item() < 1e-4, i
+
+
+@pytest.mark.parametrize("D,nl,B,L", [(128, 2, 5, 64), (384, 2, 3, 203), (256, 3, 4, 128), (1024, 1, 2, 512)])
+def test_f32_gemm_split_matches_oracle(D, nl, B, L):
+    """"f32_gemm_split" 1 on the fp32 model (include/pcad.h): north_star's 1e-4 on logits and hidden states, exact arg-max, on
+    shapes that take the 4-wave GEMM (whole 256-row tiles), the 8-wave one (ragged rows) and the 256 x 128 one (d_model 384);
+    chunked and un-chunked runs bit-identical; the strict reference order composes with it; the bf16 model ignores the option."""
+    cfg = make_config("x", d_model=D, n_layer=nl)
+    sd = synthetic_state_dict(cfg, seed=D + nl)
+    ids = rand_ids(B, L, 5, mask=L // 2 - 1)
+    ref = O.forward_strands(ids, O.params_from_state_dict(sd, cfg))
+    m = build(cfg, sd, torch.float32, f32_gemm_split=1)
+    out = m(input_ids=ids.to(DEV), output_hidden_states=True)
+    lg, hid = out.logits.cpu(), out.hidden_states[-1].cpu()
+    e_l = ((lg - ref["logits"]).abs().max() / ref["logits"].abs().max()).item()
+    e_h = ((hid - ref["hidden"]).abs().max() / ref["hidden"].abs().max()).item()
+    print(f"f32_gemm_split D={D} L={L}: logits rel err {e_l:.2e}, hidden {e_h:.2e}")
+    assert e_l < 1e-4 and e_h < 1e-4
+    p = L // 2 - 1
+    assert torch.equal(lg[:, p, 3:7].argmax(-1), ref["logits"][:, p, 3:7].argmax(-1))
+    m2 = build(cfg, sd, torch.float32, f32_gemm_split=1, chunk_seqs=2)
+    assert torch.equal(m2(input_ids=ids.to(DEV)).logits.cpu(), lg)
+    m3 = build(cfg, sd, torch.float32, f32_gemm_split=1, reference_order=2)
+    assert ((m3(input_ids=ids.to(DEV)).logits.cpu() - ref["logits"]).abs().max() / ref["logits"].abs().max()).item() < 1e-4
+    mb = build(cfg, sd, torch.bfloat16, f32_gemm_split=1)
+    mb0 = build(cfg, sd, torch.bfloat16)
+    assert torch.equal(mb(input_ids=ids.to(DEV)).logits.cpu(), mb0(input_ids=ids.to(DEV)).logits.cpu())

@@ -392,3 +392,25 @@ def test_mamba_inner_fn(ops, D, R, Bsz, L, dtype):
     assert e < tol and er < tol
     with pytest.raises(NotImplementedError):
         ops.mamba_inner_fn(xz.to(dtype).to(DEV), args[0], args[1], args[2], args[3], args[4], torch.zeros(D, device=DEV), A.to(DEV))
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 256, 64), (2048, 4096, 1024), (4096, 1024, 2048), (300, 96, 768), (1000, 384, 768), (513, 1536, 384)])
+def test_linear_split(ops, M, N, K):
+    """pcad_gemm_nt_split (the fp32 model's in_proj / out_proj under "f32_gemm_split"): fp32 operands carried as two bf16 values,
+    three bf16 MFMA products per fp32 product, fp32 accumulation.  Against a float64 product of the same fp32 inputs: <= 2e-5 of
+    the result's max (operand error 2^-17 per element; measured ~2e-6), and at least 50x closer than the plain bf16 GEMM of the
+    rounded operands; shapes on and off the 256 x 256 tiles (in_proj / out_proj of l32 and l20)."""
+    g = torch.Generator().manual_seed(M + N + K)
+    x = torch.randn(M, K, generator=g)
+    w = torch.randn(N, K, generator=g) * K ** -0.5
+    ref = (x.double() @ w.double().t())
+    out = ops.linear_split(x.to(DEV), w.to(DEV))
+    assert out.dtype == torch.float32 and out.shape == (M, N)
+    e = ((out.double().cpu() - ref).abs().max() / ref.abs().max()).item()
+    e32 = ((ops.linear(x.to(DEV), w.to(DEV)).double().cpu() - ref).abs().max() / ref.abs().max()).item()
+    if K % 64 == 0 and (K * 2) % 128 == 0:
+        ebf = ((ops.linear(x.bfloat16().to(DEV), w.bfloat16().to(DEV), out_dtype=torch.float32).double().cpu() - ref).abs().max() / ref.abs().max()).item()
+    else:
+        ebf = 1.0
+    print(f"linear_split {M}x{N}x{K}: rel err {e:.2e} (fp32 MFMA GEMM {e32:.2e}, bf16 GEMM {ebf:.2e})")
+    assert e < 2e-5 and e * 50 < ebf
