@@ -265,6 +265,37 @@ def test_plantcad2_task_table_sources(tmp_path, monkeypatch):
     assert list(got["label"]) == [1, 0] and list(got.index) == [0, 1]
 
 
+def test_plantcad2_load_task_through_the_real_datasets_library(tmp_path, monkeypatch):
+    """`load_task(repo_id, task, split)` = the reference's `load_dataset(repo_id, task)[split].to_pandas()`
+    (src/zero-shot-eval.py:344, :394, :444, :498) executed by the REAL `datasets` package - not a monkey-patch - on a local
+    directory laid out as a hub dataset repository is (README.md `configs:` front matter naming one config per task with
+    per-split parquet files).  No network: HF_HUB_OFFLINE / HF_DATASETS_OFFLINE; a hub id goes through the same call with the
+    user's cache.  Then one driver end to end from that source."""
+    datasets = pytest.importorskip("datasets")
+    from plantcaduceus_amd import plantcad2_eval as pe
+    monkeypatch.setenv("HF_HUB_OFFLINE", "1")
+    monkeypatch.setenv("HF_DATASETS_OFFLINE", "1")
+    monkeypatch.setenv("HF_DATASETS_CACHE", str(tmp_path / "cache"))
+    repo = tmp_path / "PlantCAD2_zero_shot_tasks"
+    (repo / "conservation").mkdir(parents=True)
+    rng = np.random.default_rng(5)
+    seqs = ["".join(rng.choice(list("ACGT"), size=40)) for _ in range(10)]
+    df = pd.DataFrame({"sequence": seqs, "label": rng.integers(0, 2, size=10)})
+    df.to_parquet(repo / "conservation" / "valid.parquet")
+    df.iloc[:4].to_parquet(repo / "conservation" / "test.parquet")
+    (repo / "README.md").write_text("---\nconfigs:\n- config_name: conservation\n  data_files:\n  - split: valid\n"
+                                    "    path: conservation/valid.parquet\n  - split: test\n    path: conservation/test.parquet\n---\n")
+    got = pe.load_task(str(repo), "conservation", "valid")
+    assert list(got.columns) == ["sequence", "label"] and got["sequence"].tolist() == seqs
+    assert len(pe._frame((str(repo), "conservation", "test"))) == 4
+    cfg = make_config("x", d_model=32, n_layer=1)
+    model = O.OracleForMaskedLM(O.params_from_state_dict(synthetic_state_dict(cfg, seed=2), cfg))
+    tok = CaduceusTokenizer()
+    a = pe.evo_cons((str(repo), "conservation", "valid"), model, tok, "cpu", token_idx=19, batch_size=4)
+    b = pe.evo_cons(df, model, tok, "cpu", token_idx=19, batch_size=4)
+    assert a == b and set(a) == {"AUROC", "AUPRC"}
+
+
 def test_plantcad2_command_line(tmp_path, monkeypatch, capsys):
     """`python -m plantcaduceus_amd.plantcad2_eval <sub-command> ...` with the reference's flag names (docs/zero-shot-eval.md):
     same numbers as calling the drivers; `--logits_path` skips the model; the oracle stand-in as the loaded model otherwise."""
