@@ -92,6 +92,10 @@ void   pcad_destroy(pcad_handle h);
  *                 chunkings of a bf16 batch can differ by bf16 rounding; the
  *                 workspace does: ~30 MB per window at l32 bf16, i.e. up to ~30 GB for one 1 023-window chunk (a batch of
  *                 1 024 runs as two chunks of 512 in a 15.3 GB workspace) - always size it with pcad_workspace_bytes.
+ *   "workspace_limit_mb"  N > 0: chunks are sized so that pcad_workspace_bytes stays at or below N MiB whatever the batch (a server
+ *                 holding several models on one GPU bounds each one's slab; the default chunking takes up to ~30 GB for a
+ *                 1 023-window chunk at l32 bf16); smaller chunks cost throughput (1 024 windows as 16 chunks instead of 2: -7 %),
+ *                 never results.  One window always runs, even if its workspace exceeds the limit.  0 (default): no limit.
  *   "last_layer_shortcut"  1 (default): when pcad_forward is given a list of positions, the LAST layer's scans stop at the
  *                 furthest evaluated row and its out_proj runs on the evaluated rows only (bit-identical outputs);  0: full layer.
  *   "gate_each"   1: SiLU(z) applied to each direction's scan output, each rounded, then summed — the reference's order

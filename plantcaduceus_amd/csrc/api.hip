@@ -80,6 +80,7 @@ struct pcad_engine {
     int rep_class = -1, rep_count = 1;   // pcad_set_option("debug_repeat_class" / "debug_repeat"): measurement aid, see forward_impl
     bool poison = false;   // pcad_set_option("poison_workspace", 1): debug — fill the workspace with 0xFF (NaN patterns) before every forward
     bool bound = false;
+    int64_t ws_limit = 0;       // pcad_set_option("workspace_limit_mb"): chunks are sized so that the workspace stays below it (0: no limit)
     bool f32_split = false;     // pcad_set_option("f32_gemm_split", 1): the fp32 model's in_proj / out_proj as split-bf16 GEMMs (split_wanted)
     bool split_packed = false;  // ... and their [hi | hi | lo] weight copies exist in the arena (decided like fold_packed)
     bool fold_packed = false;   // the norm-folded form's extra weight copies (W_in_f, xz_tab0, padded W_out) exist in the arena: decided
@@ -314,6 +315,9 @@ int pcad_set_option(pcad_handle h, const char* key, int64_t value) {
         h->gate_once = value == 0;
     } else if (k == "norm_fold") {
         h->norm_fold = value < 0 ? -1 : (value != 0 ? 1 : 0);
+    } else if (k == "workspace_limit_mb") {
+        if (value < 0 || value > ((int64_t)1 << 30)) return fail(PCAD_ERR_INVALID, "workspace_limit_mb=%lld out of range", (long long)value);
+        h->ws_limit = value << 20;
     } else if (k == "f32_gemm_split") {
         h->f32_split = value != 0;
     } else if (k == "reference_order") {
@@ -455,6 +459,15 @@ static int chunk_for(const pcad_engine* e, int B, int L) {
     int64_t cap = chunk_row_limit(e) / (2 * (int64_t)L);
     if (e->chunk > 0 && e->chunk < cap) cap = e->chunk;
     if (cap < 1) cap = 1;
+    if (cap > B) cap = B;
+    if (e->ws_limit > 0 && carve_workspace(e, nullptr, (int)cap, L).bytes > (size_t)e->ws_limit) {
+        int64_t lo = 1, hi = cap;                     // largest chunk whose workspace fits (the size is monotone in the chunk)
+        while (lo < hi) {
+            const int64_t mid = (lo + hi + 1) / 2;
+            if (carve_workspace(e, nullptr, (int)mid, L).bytes <= (size_t)e->ws_limit) lo = mid; else hi = mid - 1;
+        }
+        cap = lo;                                     // one window always runs, whatever the limit
+    }
     const int64_t n = (B + cap - 1) / cap;
     return (int)((B + n - 1) / n);
 }

@@ -314,6 +314,11 @@ class Engine:
         _check(self.lib.pcad_set_option(self._h, key.encode(), int(value)), "pcad_set_option")
         self._ws = None
 
+    def release_workspace(self):
+        """Free the workspace slab (it is re-allocated by the next forward): for a process that keeps several models resident
+        and runs them in turn.  `set_option("workspace_limit_mb", N)` bounds what a forward allocates in the first place."""
+        self._ws = None
+
     def profile(self, on):
         """False/0: off; True/1: HIP events around every launch; N > 1: around every N-th launch of each kernel class."""
         _check(self.lib.pcad_profile_enable(self._h, int(on)), "pcad_profile_enable")

@@ -112,6 +112,26 @@ def test_fold_copies_are_carved_only_when_the_fold_can_engage(lib):
     lib.pcad_destroy(g)
 
 
+def test_workspace_limit_option_bounds_the_slab(lib):
+    """pcad_set_option("workspace_limit_mb"): the chunk shrinks until the workspace fits, for any batch; one window always runs."""
+    c = engine.PcadConfig(d_model=1024, n_layer=2, d_state=16, d_conv=4, expand=2, dt_rank=64, vocab=8, eps=1e-5, dtype=1,
+                          residual_in_fp32=1, complement=(C.c_int32 * 8)(0, 1, 2, 6, 5, 4, 3, 7))
+    h = C.c_void_p()
+    assert lib.pcad_create(C.byref(c), C.byref(h)) == 0
+    full = lib.pcad_workspace_bytes(h, 1024, 512)
+    assert full > 10 << 30                                            # two chunks of 512 windows: ~15 GB
+    assert lib.pcad_set_option(h, b"workspace_limit_mb", 2048) == 0
+    for B in (64, 1024, 5000):
+        assert lib.pcad_workspace_bytes(h, B, 512) <= 2048 << 20
+    assert lib.pcad_workspace_bytes(h, 1024, 512) > 1024 << 20          # and not needlessly small
+    one = lib.pcad_workspace_bytes(h, 1, 512)
+    assert lib.pcad_set_option(h, b"workspace_limit_mb", 1) == 0
+    assert lib.pcad_workspace_bytes(h, 1024, 512) == one                # below one window's need: one window per chunk
+    assert lib.pcad_set_option(h, b"workspace_limit_mb", 0) == 0 and lib.pcad_workspace_bytes(h, 1024, 512) == full
+    assert lib.pcad_set_option(h, b"workspace_limit_mb", -1) == -1
+    lib.pcad_destroy(h)
+
+
 def test_config_derived_dims_and_support_check():
     for name, (D, nl, R) in {"l20": (384, 20, 24), "l24": (512, 24, 32), "l28": (768, 28, 48), "l32": (1024, 32, 64)}.items():
         c = make_config(name)
