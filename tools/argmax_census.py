@@ -94,12 +94,14 @@ def margins(q):
 
 
 def compare(p, q):
-    """-> dict(n, flips: indices where the 4-way calls differ, max_dp, flip_margins: q's top-2 margin at those windows)"""
+    """-> dict(n, flips: indices where the 4-way calls differ, max_dp, flip_margins: q's top-2 margin at those windows,
+    margins_all: q's top-2 margin of every window)"""
     import numpy as np
     n = min(len(p), len(q))
     p, q = p[:n], q[:n]
     flips = np.nonzero(p.argmax(1) != q.argmax(1))[0]
-    return dict(n=n, flips=flips, max_dp=float(np.abs(p - q).max()), flip_margins=margins(q)[flips])
+    m = margins(q)
+    return dict(n=n, flips=flips, max_dp=float(np.abs(p - q).max()), flip_margins=m[flips], margins_all=m)
 
 
 MODES = (("default", {}), ("reference_order=1", {"reference_order": 1}), ("reference_order=2", {"reference_order": 2}))
@@ -136,7 +138,7 @@ def census_from_fixture(model, fixture, batch=None, out=print):
                     ("ref_vs_f32", "reference-order bf16 emulation vs fp32"), ("eng_vs_f32", "folded bf16 emulation vs fp32")):
         c = floors[k]
         out(f"   {what}: {len(c['flips'])} of {c['n']} calls differ, max |dp| {c['max_dp']:.3e}"
-            + (f", margins of the differing windows {np.round(c['flip_margins'], 4).tolist()}" if len(c["flips"]) else ""))
+            + (f", margins of the differing windows {[float(f'{m:.2e}') for m in c['flip_margins']]}" if len(c["flips"]) else ""))
     h, edges = np.histogram(margins(orc["f32"][:n]), bins=[0, 1e-3, 2e-3, 5e-3, 1e-2, 2e-2, 5e-2, 1e-1, 1.0])
     out("   fp32 oracle's top-2 probability margin, windows per bin: " + ", ".join(f"[{edges[i]:g},{edges[i+1]:g}): {h[i]}" for i in range(len(h))))
     for name, opts in MODES:
@@ -148,7 +150,13 @@ def census_from_fixture(model, fixture, batch=None, out=print):
         for k, what in (("vs_ref", "reference-order bf16 emulation"), ("vs_f32", "fp32 oracle"), ("vs_eng", "folded bf16 emulation")):
             c = r[k]
             out(f"   vs {what}: {len(c['flips'])} of {c['n']} calls differ, max |dp| {c['max_dp']:.3e}"
-                + (f"; differing windows {c['flips'].tolist()} with oracle margins {np.round(c['flip_margins'], 4).tolist()}" if len(c["flips"]) else ""))
+                + (f"; differing windows {c['flips'].tolist()} with oracle margins {[float(f'{m:.2e}') for m in c['flip_margins']]}" if len(c["flips"]) else ""))
+    d_sum = floors["plainc_vs_ref"]["max_dp"]
+    out(f"-- resolved calls (oracle margin >= {d_sum:.2e} = what another fp32 summation order alone does to the reference-order emulation): "
+        + "; ".join(f"{name}: {int((r['vs_ref']['flip_margins'] >= d_sum).sum())} vs reference order, {int((r['vs_f32']['flip_margins'] >= d_sum).sum())} vs fp32"
+                    for name, r in res["modes"].items())
+        + f"; CPU emulations among themselves {int((floors['eng_vs_ref']['flip_margins'] >= d_sum).sum())}, reference-order emulation vs fp32 "
+          f"{int((floors['ref_vs_f32']['flip_margins'] >= d_sum).sum())}")
     return res
 
 
