@@ -44,7 +44,9 @@ inline int round_up(int v, int a) { return (v + a - 1) / a * a; }
 struct DirWeights {
     float *conv_w, *conv_b;   // [E,4], [E]
     void* Wx;                 // [XP, E] dtype
+    void* Wx_s;               // [XP, 2E] bf16, per 32-channel K-tile [hi | lo] ("f32_gemm_split": x_proj inside the fused conv kernel), else nullptr
     void* Wdt;                // [E, Rp] dtype
+    void* Wdt_s;              // [E, 3 Rp] bf16 = [hi | hi | lo] of Wdt ("f32_gemm_split": the fp32 model's dt_proj on the bf16 pipes), else nullptr
     float *dt_bias, *A2, *Dskip;
 };
 
@@ -160,7 +162,9 @@ void carve_weights(pcad_engine* e, Carver& c) {
             w.conv_w = (float*)c.take(E * 4 * 4);
             w.conv_b = (float*)c.take(E * 4);
             w.Wx = c.take((size_t)e->XP * E * esz);
+            w.Wx_s = ps && e->convx ? c.take((size_t)e->XP * 2 * E * 2) : nullptr;
             w.Wdt = c.take(E * (size_t)e->Rp * esz);
+            w.Wdt_s = ps && e->convx ? c.take(E * (size_t)e->Rp * 3 * 2) : nullptr;
             w.dt_bias = (float*)c.take(E * 4);
             w.A2 = (float*)c.take(E * N * 4);
             w.Dskip = (float*)c.take(E * 4);
@@ -194,8 +198,10 @@ Workspace carve_workspace(const pcad_engine* e, void* base, int Bc, int L) {
     const size_t rows8 = (rows + 7) / 8 * 8;   // xc and y use the blocked layout: whole 8-row blocks
     w.xc[0] = c.take(rows8 * E * esz);
     w.xc[1] = c.take(rows8 * E * esz);
-    w.dtl[0] = c.take(rows * e->Rp * esz);     // dt_low (x_proj columns [0, Rp), zero padded past R)
-    w.dtl[1] = c.take(rows * e->Rp * esz);
+    // dt_low (x_proj columns [0, Rp), zero padded past R); split: bf16 [rows, 3 Rp] = [hi | lo | hi]
+    const size_t dtl_bytes = sp && e->convx ? rows * e->Rp * 3 * 2 : rows * e->Rp * esz;
+    w.dtl[0] = c.take(dtl_bytes);
+    w.dtl[1] = c.take(dtl_bytes);
     w.bc[0] = (float*)c.take(rows * 2 * e->N * 4);   // B_t | C_t rows, fp32 (values rounded to the model dtype)
     w.bc[1] = (float*)c.take(rows * 2 * e->N * 4);
     w.y = c.take(rows8 * E * esz);
@@ -432,8 +438,10 @@ int pcad_bind_weights(pcad_handle h, const pcad_tensor* tensors, int n, void* ar
             HIP_TRY(launch_pack2d(t_x->data, t_x->dtype, E, w.Wx, dt, E, R, E, Rp, E, s));
             HIP_TRY(launch_pack2d((const char*)t_x->data + (size_t)R * E * esz_src, t_x->dtype, E,
                                   (char*)w.Wx + (size_t)Rp * E * e->esz, dt, E, 2 * N, E, 2 * N, E, s));
+            if (w.Wx_s) HIP_TRY(launch_pack_convx_wsplit((const float*)w.Wx, E, w.Wx_s, e->XP, E, s));     // from the padded fp32 copy
             NEED(t_dw, mp + "dt_proj.weight", (int64_t)E * R);
             HIP_TRY(launch_pack2d(t_dw->data, t_dw->dtype, R, w.Wdt, dt, Rp, E, R, E, Rp, s));
+            if (w.Wdt_s) HIP_TRY(launch_pack_split3_w(w.Wdt, dt, Rp, w.Wdt_s, E, Rp, s));        // from the zero-padded fp32 copy
             NEED(t_db, mp + "dt_proj.bias", (int64_t)E);
             HIP_TRY(launch_pack2d(t_db->data, t_db->dtype, E, w.dt_bias, F32, E, 1, E, 1, E, s));
             NEED(t_A, mp + "A_log", (int64_t)E * N);
@@ -613,8 +621,8 @@ static int forward_impl(pcad_handle h, const int32_t* ids, int B, int L, const i
         const bool convx = e->convx && ((int64_t)rows + 16) * E * esz < ((int64_t)1 << 32);      // the fused kernel's 32-bit offsets
         if (convx) for (int rep = 0; rep < reps(PCAD_K_CONV); ++rep) {
             ProfScope ps(e, PCAD_K_CONV, s);
-            HIP_TRY(launch_convx(c.w.xz, W.convw, W.dir[0].Wx, c.w.xc[0], c.w.dtl[0], c.w.bc[0], W.dir[1].Wx, c.w.xc[1],
-                                 c.w.dtl[1], c.w.bc[1], S, L, E, dt, s, Rp));
+            HIP_TRY(launch_convx(c.w.xz, W.convw, sp ? W.dir[0].Wx_s : W.dir[0].Wx, c.w.xc[0], c.w.dtl[0], c.w.bc[0], sp ? W.dir[1].Wx_s : W.dir[1].Wx, c.w.xc[1],
+                                 c.w.dtl[1], c.w.bc[1], S, L, E, dt, s, Rp, sp, sp));      // sp: dt_low as bf16 [hi | lo | hi] for the scan's split dt_proj
         } else {
             ProfScope ps(e, PCAD_K_CONV, s);
             HIP_TRY(launch_conv_bidir(c.w.xz, e->xzsplit ? E : 2 * E, W.dir[0].conv_w, W.dir[0].conv_b, W.dir[1].conv_w,
@@ -641,12 +649,19 @@ static int forward_impl(pcad_handle h, const int32_t* ids, int B, int L, const i
         const int S = 2 * c.Bc;
         const int64_t rows = (int64_t)S * L;
         const bool last_short = walk_len > 0 && li + 1 == e->nl;
+        // split-bf16 dt_proj inside the scan ("f32_gemm_split"): the fused conv + x_proj kernel wrote dt_low as bf16 [rows, 3 Rp]
+        const bool dts = sp && e->convx && ((int64_t)rows + 16) * E * esz < ((int64_t)1 << 32);
         // strict reference order ("reference_order" 2; never with norm_fold): the reverse direction's gated output goes to its own
         // tensor (xc[0]: the forward scan, its only reader, has run) and each direction gets its own tied out_proj below
         // the full-size tied out_proj of one [rows, E] tensor (y, or in the strict order each direction's own): fp32 / bf16 GEMM, or the
         // split-bf16 form (operand conversion + bf16 GEMM with K' = 3E, fp32 result)
+        // ... whose [hi | lo | hi] operand the gating (reverse) scan writes itself where it can (whole walk, unsegmented, L % 8 == 0),
+        // instead of fp32 y + a conversion pass
+        const bool ys_from_scan = sp && !(e->ref_order == 2 && !c.fold) && !last_short && L % 8 == 0 && e->blocked && e->xzsplit &&
+                                  !(c.w.seg && scan_segments(S, L, E, nullptr) > 1);
         auto out_proj_full = [&](const void* ysrc, void* dst) -> hipError_t {
             if (sp) {
+                if (!(ys_from_scan && ysrc == c.w.y))
                 if (hipError_t er = launch_split3_rows((const float*)ysrc, E, c.w.ys, rows, E, e->blocked, e->blocked, s)) return er;
                 return launch_gemm_nt(c.w.ys, 3 * E, W.W_out_s, 3 * E, dst, D, rows, D, 3 * E, BF16, F32, false, s, e->blocked);
             }
@@ -662,17 +677,18 @@ static int forward_impl(pcad_handle h, const int32_t* ids, int B, int L, const i
                                          e->blocked)); }
             // dt_proj (on MFMA inside the scan) + bias + softplus + recurrence + D skip + SiLU(z) gate
             for (int rep = 1; rep < (d == 0 ? reps(PCAD_K_SCAN) : 1); ++rep)         // measurement aid: the forward-direction launch is idempotent
-                HIP_TRY(launch_scan(c.w.xc[d], nullptr, e->xzsplit ? E : 2 * E, nullptr, c.w.dtl[d], Rp, dw.Wdt, Rp, c.w.bc[d], dw.A2, 1.0f,
-                                    dw.Dskip, dw.dt_bias, c.w.y, S, L, E, false, 0, dt, s, e->blocked, e->xzsplit, c.w.seg, 0));
+                HIP_TRY(launch_scan(c.w.xc[d], nullptr, e->xzsplit ? E : 2 * E, nullptr, c.w.dtl[d], dts ? 3 * Rp : Rp, dts ? dw.Wdt_s : dw.Wdt, dts ? 3 * Rp : Rp, c.w.bc[d], dw.A2, 1.0f,
+                                    dw.Dskip, dw.dt_bias, c.w.y, S, L, E, false, 0, dt, s, e->blocked, e->xzsplit, c.w.seg, 0, nullptr, dts));
             ProfScope ps(e, PCAD_K_SCAN, s);
             const void* zp = e->xzsplit ? c.w.zb : (const void*)((const char*)c.w.xz + (size_t)E * esz);
             // gate_once: the forward scan stores its ungated output, the reverse scan adds its own and applies SiLU(z)
             // to the sum (one SiLU per element instead of two, z read once; a rounding-order difference from
             // y_f*g + y_r*g, like the out_proj fold below).  PCAD_GATE_EACH=1: each direction gated and rounded.
             const bool gated = strict || !e->gate_once || d == 1;
-            HIP_TRY(launch_scan(c.w.xc[d], gated ? zp : nullptr, e->xzsplit ? E : 2 * E, nullptr, c.w.dtl[d], Rp, dw.Wdt, Rp,
+            HIP_TRY(launch_scan(c.w.xc[d], gated ? zp : nullptr, e->xzsplit ? E : 2 * E, nullptr, c.w.dtl[d], dts ? 3 * Rp : Rp, dts ? dw.Wdt_s : dw.Wdt, dts ? 3 * Rp : Rp,
                                 c.w.bc[d], dw.A2, 1.0f, dw.Dskip, dw.dt_bias, d == 1 ? y_rev : c.w.y, S, L, E, d == 1,
-                                strict ? 0 : (d == 1 ? (e->gate_once ? 2 : 1) : 0), dt, s, e->blocked, e->xzsplit, c.w.seg, last_short ? walk_len : 0));
+                                strict ? 0 : (d == 1 ? (e->gate_once ? 2 : 1) : 0), dt, s, e->blocked, e->xzsplit, c.w.seg, last_short ? walk_len : 0,
+                                d == 1 && ys_from_scan ? c.w.ys : nullptr, dts));
         }
         if (strict) {
             // out = round(out_proj(y_fwd)) + round(out_proj(y_rev)), rounded: BiMambaWrapper's "add" of two Mamba calls that each end

@@ -124,13 +124,19 @@ struct ConvxDir {
     void* xc;            // [rows8, E] blocked
     void* dtl;           // [rows, Rp]
     float* bc;           // [rows, 32]
+    int dtl_split;       // T == float only: dtl is a bf16 tensor [rows, 3 Rp] = [hi | lo | hi] (the scan's split-bf16 dt_proj operand)
 };
 
 // convw: per K-tile CX_CW_BYTES of fp32 [dir][tap 0..3, bias][KC]  (packed at bind time by launch_pack_convw)
 // ZFILL (L % 8 == 0: a strand is a contiguous byte range of the blocked tensor): the raw tile is fetched through a
 // descriptor that covers exactly the strand, so the halo rows outside [0, L) are out of range and arrive as zeros (a
 // negative strand-relative offset wraps to a huge unsigned one) - the conv pass then needs no per-element masking.
-template <typename T, bool ZFILL, int NJ = 6>
+// XS (T == float only; api.hip "f32_gemm_split"): x_proj on the bf16 matrix pipes as three bf16 products per fp32 product.  Wx arrives
+// as bf16 [XP, 2E] whose K-tile kt (32 channels) is the 128-byte piece [hi (32) | lo (32)] (launch_pack_convx_wsplit: same row pitch, same
+// LDS slab and staging as the fp32 weight); the conv stage stays fp32 (it is also what the xc copy-out reads) and the A fragment - 8
+// consecutive channels per lane - is split into hi / lo when it is loaded: 36 v_mfma_f32_16x16x32_bf16 per K-tile and wave instead of
+// 96 v_mfma_f32_16x16x4_f32 at a quarter of the rate (the fp32 kernel is MFMA-bound: 3 072 of its cycles per K-tile and wave).
+template <typename T, bool ZFILL, int NJ = 6, bool XS = false>
 __global__ __launch_bounds__(CX_THREADS, 2) void convx_kernel(const T* __restrict__ x, const float* __restrict__ convw,
                                                               ConvxDir d0, ConvxDir d1, int S, int L, int E) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -231,9 +237,43 @@ __global__ __launch_bounds__(CX_THREADS, 2) void convx_kernel(const T* __restric
     // and the MFMAs + xc copy-out of K-tile it-1 (matrix pipe + LDS, reads conv stage (it-1)&1) in the same barrier
     // interval, so the two pipes overlap instead of alternating.  DMAs issued at the start of iteration it: Wx(it),
     // taps(it+1), raw(it+1), each into the slot whose last reader finished in iteration it-1.
+    // XS: A fragment of the bf16 MFMA = channels 8 lg .. 8 lg + 7 of row li = fp32 chunks 2 lg and 2 lg + 1 of the (swizzled) conv stage row
+    int frag_xs[2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) frag_xs[c] = li * CX_ROWB + (((2 * lg + c) ^ cx_key(li)) << 4);
     auto mfma_half = [&](int mpar, int kk) __attribute__((always_inline)) {          // mpar: parity of the K-tile being multiplied
         const char* at = smem + CX_OFF_C + mpar * 2 * CX_TILE_BYTES + cdir * CX_TILE_BYTES;
         const char* wb = smem + CX_OFF_W + (W1 ? 0 : mpar) * 2 * CX_W_BYTES + cdir * CX_W_BYTES;
+        if constexpr (XS) {
+            if (kk != 0) return;                              // the whole K-tile (K = 32) in the kk == 0 call
+            u32x4 ahi[2], alo[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const char* rowp = at + (mq * 32 + i * 16) * CX_ROWB;
+                const f32x4 v0 = *reinterpret_cast<const f32x4*>(rowp + frag_xs[0]);
+                const f32x4 v1 = *reinterpret_cast<const f32x4*>(rowp + frag_xs[1]);
+                const float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const uint32_t h = pack_bf16x2(v[2 * q], v[2 * q + 1]);
+                    ahi[i][q] = h;
+                    alo[i][q] = pack_bf16x2(v[2 * q] - bf16lo_to_f32(h), v[2 * q + 1] - bf16hi_to_f32(h));
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const u32x4 whi = *reinterpret_cast<const u32x4*>(wb + j * 16 * CX_ROWB + frag_lo[0]);      // chunk lg of [hi | lo]
+                const u32x4 wlo = *reinterpret_cast<const u32x4*>(wb + j * 16 * CX_ROWB + frag_lo[1]);      // chunk 4 + lg
+                // three products per accumulator, the two row blocks alternating (no back-to-back dependent MFMAs)
+                acc[0][j] = CxMma<bf16_t>::run(whi, ahi[0], acc[0][j]);
+                acc[1][j] = CxMma<bf16_t>::run(whi, ahi[1], acc[1][j]);
+                acc[0][j] = CxMma<bf16_t>::run(whi, alo[0], acc[0][j]);
+                acc[1][j] = CxMma<bf16_t>::run(whi, alo[1], acc[1][j]);
+                acc[0][j] = CxMma<bf16_t>::run(wlo, ahi[0], acc[0][j]);
+                acc[1][j] = CxMma<bf16_t>::run(wlo, ahi[1], acc[1][j]);
+            }
+            return;
+        }
         u32x4 af[2], wfr[NJ];
 #pragma unroll
         for (int i = 0; i < 2; ++i) af[i] = *reinterpret_cast<const u32x4*>(at + (mq * 32 + i * 16) * CX_ROWB + frag_lo[kk]);
@@ -405,6 +445,15 @@ __global__ __launch_bounds__(CX_THREADS, 2) void convx_kernel(const T* __restric
             if constexpr (sizeof(T) == 2) {
                 u32x2 v = {pack_bf16x2(acc[i][j][0], acc[i][j][1]), pack_bf16x2(acc[i][j][2], acc[i][j][3])};
                 *reinterpret_cast<u32x2*>(dl + j * 16 + lg * 4) = v;
+            } else if (dd.dtl_split) {
+                constexpr int RPW = 16 * (NJ - 2);
+                bf16_t* ds = (bf16_t*)dd.dtl + row * (3 * RPW) + j * 16 + lg * 4;
+                const u32x2 hi = {pack_bf16x2(acc[i][j][0], acc[i][j][1]), pack_bf16x2(acc[i][j][2], acc[i][j][3])};
+                const u32x2 lo = {pack_bf16x2(acc[i][j][0] - bf16lo_to_f32(hi[0]), acc[i][j][1] - bf16hi_to_f32(hi[0])),
+                                  pack_bf16x2(acc[i][j][2] - bf16lo_to_f32(hi[1]), acc[i][j][3] - bf16hi_to_f32(hi[1]))};
+                *reinterpret_cast<u32x2*>(ds) = hi;
+                *reinterpret_cast<u32x2*>(ds + RPW) = lo;
+                *reinterpret_cast<u32x2*>(ds + 2 * RPW) = hi;
             } else {
                 *reinterpret_cast<f32x4*>(dl + j * 16 + lg * 4) = acc[i][j];
             }
@@ -437,6 +486,27 @@ __global__ __launch_bounds__(256) void pack_convw_kernel(const float* __restrict
     }
 }
 
+// x_proj weight for the XS form: src fp32 [rows, E] (ld) -> dst bf16 [rows, 2E]: K-tile kt (channels 32 kt .. 32 kt + 31) becomes the
+// 64 bf16 [hi (32) | lo (32)], hi = bf16(w), lo = bf16(w - hi)
+__global__ __launch_bounds__(256) void pack_convx_wsplit_kernel(const float* __restrict__ src, int64_t ld, bf16_t* __restrict__ dst, int rows, int E) {
+    const int64_t total = (int64_t)rows * E;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int r = (int)(i / E), c = (int)(i - (int64_t)r * E);
+        const float v = src[(int64_t)r * ld + c];
+        const bf16_t hi = f32_to_bf16(v);
+        bf16_t* d = dst + (int64_t)r * 2 * E + (c >> 5) * 64 + (c & 31);
+        d[0] = hi;
+        d[32] = f32_to_bf16(v - bf16_to_f32(hi));
+    }
+}
+
+hipError_t launch_pack_convx_wsplit(const float* src, int64_t ld, void* dst, int rows, int E, hipStream_t s) {
+    if (rows <= 0) return hipSuccess;
+    if (E % 32) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(pack_convx_wsplit_kernel, dim3(256), dim3(256), 0, s, src, ld, (bf16_t*)dst, rows, E);
+    return hipGetLastError();
+}
+
 size_t convx_packed_bytes(int E, int dt) {
     const int KC = CX_ROWB / (dt == BF16 ? 2 : 4);
     return (size_t)(E / KC) * CX_CW_BYTES;
@@ -451,17 +521,20 @@ hipError_t launch_pack_convw(const float* wf, const float* bf, const float* wr, 
 }
 
 hipError_t launch_convx(const void* x, const float* convw, const void* Wx0, void* xc0, void* dtl0, float* bc0,
-                        const void* Wx1, void* xc1, void* dtl1, float* bc1, int S, int L, int E, int dt, hipStream_t s, int Rp) {
+                        const void* Wx1, void* xc1, void* dtl1, float* bc1, int S, int L, int E, int dt, hipStream_t s, int Rp, bool dtl_split,
+                        bool w_split) {
     if (S <= 0 || L <= 0) return hipSuccess;
+    if ((dtl_split || w_split) && dt != F32) return hipErrorInvalidValue;
     const int esz = dt == BF16 ? 2 : 4;
     if ((E * esz) % CX_ROWB || (Rp != 64 && Rp != 96)) return hipErrorInvalidValue;
     if (((int64_t)S * L + 16) * E * esz >= ((int64_t)1 << 32)) return hipErrorInvalidValue;    // unsigned 32-bit in-tensor offsets
-    ConvxDir d0{Wx0, xc0, dtl0, bc0}, d1{Wx1, xc1, dtl1, bc1};
+    ConvxDir d0{Wx0, xc0, dtl0, bc0, dtl_split ? 1 : 0}, d1{Wx1, xc1, dtl1, bc1, dtl_split ? 1 : 0};
     const int tiles = S * ((L + CX_ROWS - 1) / CX_ROWS);
     const bool zfill = L % 8 == 0;
 #define PCAD_CONVX(T, Z, NJ_)                                                                                         \
     do {                                                                                                                \
         auto k = convx_kernel<T, Z, NJ_>;                                                                               \
+        if constexpr (std::is_same<T, float>::value) { if (w_split) k = convx_kernel<T, Z, NJ_, true>; }                \
         if (hipError_t ae = ensure_dynamic_lds((const void*)k, CxGeom<NJ_>::LDS)) return ae;                            \
         hipLaunchKernelGGL(k, dim3((unsigned)tiles), dim3(CX_THREADS), CxGeom<NJ_>::LDS, s, (const T*)x, convw, d0, d1, S, L, E); \
     } while (0)

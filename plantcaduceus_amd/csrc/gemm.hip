@@ -704,7 +704,7 @@ __global__ __launch_bounds__(GEMMQ_THREADS, 1) void gemm256q_kernel(const T* __r
     const int my_tiles = (nblk - (int)blockIdx.x + gstride - 1) / gstride;
     const int G = my_tiles * nkt;                                 // K-tiles this block walks
 
-    auto tile_coords = [&](int tile, int64_t& m0, int& n0) {
+    auto tile_coords = [&](int tile, int64_t& m0, int& n0) __attribute__((always_inline)) {
         const int xcd = tile & 7, idx = tile >> 3;
         const int q = nblk >> 3, r = nblk & 7;
         const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
@@ -738,29 +738,29 @@ __global__ __launch_bounds__(GEMMQ_THREADS, 1) void gemm256q_kernel(const T* __r
         w_lo[i] = (uint32_t)((int64_t)row * ldw * (int64_t)sizeof(T) + (((lane & 7) ^ key_w(row)) << 4));
     }
     uint32_t a_base, w_base;                          // wave-uniform byte offset of the cursor's tile
-    auto set_pa = [&](int64_t m0) {
+    auto set_pa = [&](int64_t m0) __attribute__((always_inline)) {
         a_base = (uint32_t)(a_blocked ? ((m0 >> 3) * a_pieces << 10) : m0 * lda * (int64_t)sizeof(T));
     };
-    auto set_pw = [&](int n0) { w_base = (uint32_t)((int64_t)n0 * ldw * (int64_t)sizeof(T)); };
+    auto set_pw = [&](int n0) __attribute__((always_inline)) { w_base = (uint32_t)((int64_t)n0 * ldw * (int64_t)sizeof(T)); };
     int a_tile = blockIdx.x, a_kt = 0, a_g = 0;
     int w_tile = blockIdx.x, w_kt = 0, w_g = 0;
-    auto a_piece = [&](int sa, int p) {               // piece p of A(a_g) -> A stage sa
+    auto a_piece = [&](int sa, int p) __attribute__((always_inline)) {               // piece p of A(a_g) -> A stage sa
         const uint32_t soff = a_base + (uint32_t)a_kt * (a_blocked ? 1024u : (uint32_t)ROWB);
         blds16(A, a_lo[p], soff, smem + sa * A2_BYTES + (wave * 64 + p * 8) * ROWB);
     };
-    auto a_issue = [&](int sa) {
+    auto a_issue = [&](int sa) __attribute__((always_inline)) {
 #pragma unroll
         for (int p = 0; p < 8; ++p) a_piece(sa, p);
     };
-    auto w_piece = [&](int sw, int p) {
+    auto w_piece = [&](int sw, int p) __attribute__((always_inline)) {
         const uint32_t soff = w_base + (uint32_t)w_kt * (uint32_t)ROWB;
         blds16(W, w_lo[p], soff, smem + GEMM3_OFF_W + sw * W2_BYTES + (wave * 64 + p * 8) * ROWB);
     };
-    auto w_issue = [&](int sw) {
+    auto w_issue = [&](int sw) __attribute__((always_inline)) {
 #pragma unroll
         for (int p = 0; p < 8; ++p) w_piece(sw, p);
     };
-    auto a_advance = [&]() {
+    auto a_advance = [&]() __attribute__((always_inline)) {
         if (a_g + 1 < G) {
             ++a_g;
             if (++a_kt == nkt) {
@@ -772,7 +772,7 @@ __global__ __launch_bounds__(GEMMQ_THREADS, 1) void gemm256q_kernel(const T* __r
             }
         }
     };
-    auto w_advance = [&]() {
+    auto w_advance = [&]() __attribute__((always_inline)) {
         if (w_g + 1 < G) {
             ++w_g;
             if (++w_kt == nkt) {
@@ -798,7 +798,7 @@ __global__ __launch_bounds__(GEMMQ_THREADS, 1) void gemm256q_kernel(const T* __r
         const int rw = wn * 128 + (j >> 2) * 64 + (li >> 2) * 16 + (j & 3) * 4 + (li & 3);
         w_fo[j] = GEMM3_OFF_W + rw * ROWB + ((lg ^ key_w(rw)) << 4);
     }
-    auto load_frags = [&](int sa, int sw, int kk, u32x4 (&a)[8], u32x4 (&w)[8]) {
+    auto load_frags = [&](int sa, int sw, int kk, u32x4 (&a)[8], u32x4 (&w)[8]) __attribute__((always_inline)) {
         const int ab = sa * A2_BYTES, wb = sw * W2_BYTES, kx = kk << 6;
 #pragma unroll
         for (int j = 0; j < 8; ++j) w[j] = *reinterpret_cast<const u32x4*>(smem + ((wb + w_fo[j]) ^ kx));
@@ -813,14 +813,19 @@ __global__ __launch_bounds__(GEMMQ_THREADS, 1) void gemm256q_kernel(const T* __r
     //   rows 0-3: next W fragments (a second register set); rows 4-6: next A fragments 6, 7 (spare registers) and 0..5 into
     //   the registers of rows that are already done; every row: one DMA piece; row 7: no reads, so every read was
     //   issued at least 8 MFMAs before the k-step ends.
+    // slot_tag (PCAD_GEMM_STAGGER): the slot of a row in which THIS wave issues its LDS-DMA piece.  The four waves of the block run in
+    // lockstep behind the per-K-tile barrier, so with one common slot all four hand a 1 KiB request to the CU's single address unit in
+    // the same cycle and three of them wait at issue (16 cycles of address processing each) with nothing else to issue; with slot =
+    // wave index each wave meets a free unit.  The fragment read that owned the slot moves to slot kDmaSlot.
     auto kstep = [&](const u32x4 (&ac)[8], const u32x4 (&wc)[8], u32x4 (&an)[8], u32x4 (&wn)[8], int nsa, int nsw, int nkk,
-                     bool dma_a, int dma_stage, auto first_tag) {
+                     bool dma_a, int dma_stage, auto first_tag, auto slot_tag) __attribute__((always_inline)) {
         constexpr int MODE = (int)decltype(first_tag)::value;       // 1: first k-step of an output tile: acc = product;
         constexpr bool FIRST = MODE == 1;                           // 2 (EPI_RES): the accumulators are arriving from memory (row waits)
+        constexpr int SLOT = (int)decltype(slot_tag)::value;
         const int abn = nsa * A2_BYTES, wbn = nsw * W2_BYTES, kx = nkk << 6;
-        auto lda = [&](int f) { an[f] = *reinterpret_cast<const u32x4*>(smem + ((abn + a_fo[f]) ^ kx)); };
-        auto ldw = [&](int f) { wn[f] = *reinterpret_cast<const u32x4*>(smem + ((wbn + w_fo[f]) ^ kx)); };
-        auto dma = [&](int p) { if (dma_a) a_piece(dma_stage, p); else w_piece(dma_stage, p); };
+        auto lda = [&](int f) __attribute__((always_inline)) { an[f] = *reinterpret_cast<const u32x4*>(smem + ((abn + a_fo[f]) ^ kx)); };
+        auto ldw = [&](int f) __attribute__((always_inline)) { wn[f] = *reinterpret_cast<const u32x4*>(smem + ((wbn + w_fo[f]) ^ kx)); };
+        auto dma = [&](int p) __attribute__((always_inline)) { if (dma_a) a_piece(dma_stage, p); else w_piece(dma_stage, p); };
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
             if constexpr (MODE == 2) {
@@ -834,12 +839,13 @@ __global__ __launch_bounds__(GEMMQ_THREADS, 1) void gemm256q_kernel(const T* __r
                 }
             }
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
+            for (int ks = 0; ks < 4; ++ks) {
 #pragma unroll
-                for (int j = 2 * k; j < 2 * k + 2; ++j) {
+                for (int j = 2 * ks; j < 2 * ks + 2; ++j) {
                     if (FIRST) MmaAcc<T>::run0(wc[j], ac[r], acc[r][j]);
                     else MmaAcc<T>::run(wc[j], ac[r], acc[r][j]);
                 }
+                const int k = ks == SLOT ? kDmaSlot : (ks == kDmaSlot ? SLOT : ks);      // logical slot: the DMA's and the wave's own slot swapped
                 // slot k of row r: W' in rows 0-3, A' in rows 4-6, ONE DMA piece per row (4 waves x 1 KiB every 8 MFMAs keeps
                 // the CU's L1 half busy; all eight pieces within rows 0-3 saturated it and stalled the issue: TA stalled-by-TC x7)
                 if (k == kDmaSlot) dma(r);
@@ -865,7 +871,7 @@ __global__ __launch_bounds__(GEMMQ_THREADS, 1) void gemm256q_kernel(const T* __r
     const int swap_fix = (((lg & 1) * 16 + (lg >> 1) * 8) - lg * 16) * 2;
     // ---- fused-epilogue state -------------------------------------------------------------------------------------------
     float rs[8];                                            // EPI_SCALE: row factors of the current tile (rows mrow + 16 i)
-    auto load_rscale = [&](int64_t m0) {
+    auto load_rscale = [&](int64_t m0) __attribute__((always_inline)) {
         if constexpr (EPI == EPI_SCALE) {
             // asm loads: the values are consumed a whole tile later, behind >= 1 counted "s_waitcnt vmcnt(8)" with 8 younger
             // DMAs in flight, so they have landed by construction and no wait is ever issued for them
@@ -879,15 +885,15 @@ __global__ __launch_bounds__(GEMMQ_THREADS, 1) void gemm256q_kernel(const T* __r
     // The residual tensor is in the fragment layout (common.hpp res_frag_off): the wave's 128 x 128 part of a tile is 64 KiB
     // contiguous, group (i, jg) quad k = 1 KiB = lane-linear 16-byte pieces, so every access instruction moves whole lines.
     const uint32_t res_vo = (uint32_t)lane * 16u;
-    auto res_tile_base = [&](int64_t m0, int n0) -> float* {
+    auto res_tile_base = [&](int64_t m0, int n0) __attribute__((always_inline)) -> float* {
         return epi.res + ((((m0 >> 8) * (int64_t)(N >> 8) + (n0 >> 8)) * 4 + wave) << 14);
     };
-    auto load_res_group = [&](const float* tb, int i, int jg) {
+    auto load_res_group = [&](const float* tb, int i, int jg) __attribute__((always_inline)) {
         const float* sb = tb + (i * 2 + jg) * 1024;
         gload_a128<0>(acc[i][jg * 4 + 0], res_vo, sb);    gload_a128<1024>(acc[i][jg * 4 + 1], res_vo, sb);
         gload_a128<2048>(acc[i][jg * 4 + 2], res_vo, sb); gload_a128<3072>(acc[i][jg * 4 + 3], res_vo, sb);
     };
-    auto epilogue = [&](int64_t m0, int n0) {
+    auto epilogue = [&](int64_t m0, int n0) __attribute__((always_inline)) {
         const int64_t mrow = m0 + wm * 128 + li;
         float ss[8];
         float* res_tb = nullptr;
@@ -999,6 +1005,7 @@ __global__ __launch_bounds__(GEMMQ_THREADS, 1) void gemm256q_kernel(const T* __r
     u32x4 fa0[8], fw0[8], fa1[8], fw1[8];
     load_frags(0, 0, 0, fa0, fw0);
     int sa = 0, sw = 0, kt = 0;
+    auto mainloop = [&](auto slot) __attribute__((always_inline)) {
     while (true) {
         const int sa_n = sa == 2 ? 0 : sa + 1;
         const int sa_f = sa == 0 ? 2 : sa - 1;          // stage of K-tile g-1 == stage of K-tile g+2
@@ -1010,20 +1017,20 @@ __global__ __launch_bounds__(GEMMQ_THREADS, 1) void gemm256q_kernel(const T* __r
                 const float* tb = res_tile_base(m0, n0);
 #pragma unroll
                 for (int i = 0; i < 8; ++i) { load_res_group(tb, i, 0); load_res_group(tb, i, 1); }
-                kstep(fa0, fw0, fa1, fw1, sa, sw, 1, true, sa_f, std::integral_constant<int, 2>{});
+                kstep(fa0, fw0, fa1, fw1, sa, sw, 1, true, sa_f, std::integral_constant<int, 2>{}, slot);
             } else {
-                kstep(fa0, fw0, fa1, fw1, sa, sw, 1, true, sa_f, std::integral_constant<int, 0>{});
+                kstep(fa0, fw0, fa1, fw1, sa, sw, 1, true, sa_f, std::integral_constant<int, 0>{}, slot);
             }
         } else {
-            if (kt == 0) kstep(fa0, fw0, fa1, fw1, sa, sw, 1, true, sa_f, std::integral_constant<int, 1>{});
-            else kstep(fa0, fw0, fa1, fw1, sa, sw, 1, true, sa_f, std::integral_constant<int, 0>{});
+            if (kt == 0) kstep(fa0, fw0, fa1, fw1, sa, sw, 1, true, sa_f, std::integral_constant<int, 1>{}, slot);
+            else kstep(fa0, fw0, fa1, fw1, sa, sw, 1, true, sa_f, std::integral_constant<int, 0>{}, slot);
         }
         a_advance();
         asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         // k-step 1: MFMAs on (g, k-step 1); reads (g+1, k-step 0); DMAs W(g+2) into the W stage just freed
-        kstep(fa1, fw1, fa0, fw0, sa_n, sw ^ 1, 0, false, sw, std::integral_constant<int, 0>{});
+        kstep(fa1, fw1, fa0, fw0, sa_n, sw ^ 1, 0, false, sw, std::integral_constant<int, 0>{}, slot);
         w_advance();
         sa = sa_n;
         sw ^= 1;
@@ -1038,6 +1045,16 @@ __global__ __launch_bounds__(GEMMQ_THREADS, 1) void gemm256q_kernel(const T* __r
             kt = 0;
         }
     }
+    };
+#ifdef PCAD_GEMM_STAGGER
+    // one copy of the loop per wave, differing only in the DMA slot (wave-uniform branch, taken once)
+    if (wave == 0) mainloop(std::integral_constant<int, 0>{});
+    else if (wave == 1) mainloop(std::integral_constant<int, 1>{});
+    else if (wave == 2) mainloop(std::integral_constant<int, 2>{});
+    else mainloop(std::integral_constant<int, 3>{});
+#else
+    mainloop(std::integral_constant<int, kDmaSlot>{});
+#endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // trailing (unused) DMAs must not outlive the block's LDS
 }
 

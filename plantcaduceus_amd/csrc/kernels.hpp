@@ -102,7 +102,11 @@ size_t convx_packed_bytes(int E, int dt);
 hipError_t launch_pack_convw(const float* wf, const float* bf, const float* wr, const float* br, float* out, int E, int dt,
                              hipStream_t s);
 hipError_t launch_convx(const void* x, const float* convw, const void* Wx0, void* xc0, void* dtl0, float* bc0,
-                        const void* Wx1, void* xc1, void* dtl1, float* bc1, int S, int L, int E, int dt, hipStream_t s, int Rp = 64);
+                        const void* Wx1, void* xc1, void* dtl1, float* bc1, int S, int L, int E, int dt, hipStream_t s, int Rp = 64,
+                        bool dtl_split = false,       // dtl_split (dt == F32): dtl_d is written as bf16 [S*L, 3 Rp] = [hi | lo | hi]
+                        bool w_split = false);        // w_split (dt == F32): Wx_d is the bf16 [Rp + 32, 2E] copy of launch_pack_convx_wsplit and
+                                                      // x_proj runs as three bf16 MFMA products per fp32 product
+hipError_t launch_pack_convx_wsplit(const float* src, int64_t ld, void* dst, int rows, int E, hipStream_t s);
 // dt_rank padded to the K granule of the fused kernels: 64 up to dt_rank 64 (every PlantCaduceus size), else the next multiple of 32
 // (PlantCAD2 Large: dt_rank 96 -> 96)
 inline int padded_dt_rank(int R) { return R <= 64 ? 64 : (R + 31) / 32 * 32; }
@@ -121,7 +125,12 @@ inline int padded_dt_rank(int R) { return R <= 64 ? 64 : (R + 31) / 32 * 32; }
 hipError_t launch_scan(const void* u, const void* z, int64_t ldz, const void* delta, const void* dt_low, int64_t lddt,
                        const void* Wdt, int Rp, const float* bc, const float* A2, float a_scale, const float* Dskip,
                        const float* dbias, void* y, int S, int L, int E, bool reverse, int accumulate, int dt,
-                       hipStream_t s, bool uy_blocked = false, bool z_blocked = false, float* seg_ws = nullptr, int walk_len = 0);
+                       hipStream_t s, bool uy_blocked = false, bool z_blocked = false, float* seg_ws = nullptr, int walk_len = 0,
+                       void* ysplit = nullptr, bool dt_split = false);
+// dt_split (dt == F32, fused dt_proj): dt_low is bf16 [rows, lddt >= Rp] = [hi | lo | hi] and Wdt bf16 [E, Rp] = [hi | hi | lo] with Rp = 3 x
+// the padded dt_rank: the fp32 model's dt_proj as three bf16 MFMA products per fp32 product ("f32_gemm_split").
+// ysplit (fp32 engine layouts only: dt == F32, fused dt_proj, blocked u / y / z, L % 8 == 0; reverse gating launch, unsegmented, whole
+// walk): the output is written NOT to y but as out_proj's split-bf16 operand, bf16 [rows8, 3E] blocked = [hi | lo | hi] (pack.hip).
 
 // Segments per strand for the scan of S strands of L steps over E channels.  Pass A + pass B cost ~1.8x the arithmetic of one
 // walk, and a single wave per SIMD already keeps the VALU ~65 % busy, so cutting only pays when most SIMDs would otherwise idle

@@ -24,6 +24,7 @@
 // VALU/transcendental bound (measured on gfx950: v_exp_f32 8.5, v_fma_f32 3.7, v_pk_fma_f32 5.2 cycles per
 // wave-instruction at 4 waves/SIMD, not overlapping): ~19 cycles per (t, channel, state).
 #include <cstdlib>
+#include <type_traits>
 
 #include "common.hpp"
 #include "kernels.hpp"
@@ -157,7 +158,10 @@ template <> struct DeltaTile<float> {
 // run as separate workgroups.  SEG = 1, pass A: from a ZERO state, no output - stores the segment's end state and its sum of delta
 // (the product of its decays is exp2(A2 * sum delta));  SEG = 2, pass B: the normal walk of the segment from the true initial state
 // that scan_carry_kernel derived from pass A.  SEG = 0: the whole strand in one workgroup (G = 1).
-template <typename T, bool REV, int ACC, bool HASZ, bool FUSED, int PRE, bool BLK8, int SEG = 0, bool ZB = false>
+// SPLITY (fp32 engine with "f32_gemm_split", BLK8 only): the output is ALSO NOT written as fp32 rows but as out_proj's split-bf16
+// operand - ysplit, bf16 [rows8, 3E] blocked = [hi | lo | hi] with hi = bf16(y), lo = bf16(y - hi) (pack.hip launch_split3_rows'
+// format) - which saves the separate conversion pass over y (read 4E + write 6E bytes per row).
+template <typename T, bool REV, int ACC, bool HASZ, bool FUSED, int PRE, bool BLK8, int SEG = 0, bool ZB = false, bool SPLITY = false>
 __global__ __launch_bounds__(64, 4) void scan_kernel(const T* __restrict__ u, const T* __restrict__ z, int64_t ldz,
                                                   const T* __restrict__ dsrc, int64_t ldd,
                                                   const T* __restrict__ Wdt, int Rp,
@@ -165,7 +169,7 @@ __global__ __launch_bounds__(64, 4) void scan_kernel(const T* __restrict__ u, co
                                                   const float* __restrict__ A2, float a_scale,
                                                   const float* __restrict__ Dskip, const float* __restrict__ dbias,
                                                   const T* yin, T* y, int L, int E, int uyb, int zblk, int G, int seg_blocks,
-                                                  float* __restrict__ seg_state, int Lw) {
+                                                  float* __restrict__ seg_state, int Lw, bf16_t* __restrict__ ysplit, int dts) {
     // delta slab: rows 1..TB hold the block's TB steps; rows 0 and TB + 1 are never-consumed landing rows for the one-step-ahead
     // read at the block's ends, so that read needs no wrap (its address is a per-chunk base + a compile-time offset)
     __shared__ float dvs[TB + 2][64];
@@ -248,6 +252,15 @@ __global__ __launch_bounds__(64, 4) void scan_kernel(const T* __restrict__ u, co
         }
     };
     auto uy_voff = [&](int i) -> int { return BLK8 ? voff_uy + 128 * (REV ? CH - 1 - i : i) : voff_uy; };
+    // SPLITY: rows of 3E bf16 in the blocked layout; the wave's 64 channels are exactly one 128-byte piece of each third
+    const uint32_t pieces3 = (3u * (uint32_t)E * 2u) >> 7, third = ((uint32_t)E >> 6) << 10;
+    const auto ys_r = make_rsrc(SPLITY ? (const void*)ysplit : (const void*)u, SPLITY ? tot_rows * 3u * (uint32_t)E * 2u : 4u);
+    auto ys_soff = [&](int s0) -> uint32_t {            // scalar offset of the chunk's lowest row (BLK8: a chunk never crosses an 8-row block)
+        const int slo = min(REV ? s0 + CH - 1 : s0, L - 1);
+        const uint32_t r = (uint32_t)row0 + (uint32_t)(REV ? (L - 1 - slo) : slo);
+        return (((r >> 3) * pieces3 + ((uint32_t)c0 >> 6)) << 10) + ((r & 7u) << 7);
+    };
+    auto ys_voff = [&](int i) -> int { return lane * 2 + 128 * (REV ? CH - 1 - i : i); };
 
     T ub[CH], zb[CH], yb[CH], dr[CH];      // RAW prefetched values: converted at use, so no early vmcnt wait
     auto tclamp = [&](int s) { const int sc = min(s, L - 1); return REV ? (L - 1 - sc) : sc; };
@@ -334,6 +347,12 @@ __global__ __launch_bounds__(64, 4) void scan_kernel(const T* __restrict__ u, co
                 delta_run_pre<PRE>(pre, (const bf16_t*)Wdt, c0, lane, acc0, acc1);
                 // next block's operand: in flight during this block's 32-step walk (rows clamp at the sequence ends)
                 pre = delta_prefetch<PRE>((const bf16_t*)dsrc, ldd, row0, REV ? (L - (b + 2) * TB) : (b + 1) * TB, L, lane);
+            } else if constexpr (std::is_same<T, float>::value) {
+                // dts (fp32 engine with "f32_gemm_split"): dt_low arrives as bf16 [rows, 3 R'] = [hi | lo | hi] (convx epilogue) and Wdt as
+                // bf16 [E, 3 R'] = [hi | hi | lo] (bind time), Rp = 3 R': dt_low . Wdt^T as three bf16 products per fp32 product on
+                // v_mfma_f32_32x32x16_bf16 - 24 instead of 64 (4x slower) MFMAs per 32-step tile (wave-uniform branch, once per tile)
+                if (dts) DeltaTile<bf16_t>::run(reinterpret_cast<const bf16_t*>(dsrc), ldd, row0, tb0, L, reinterpret_cast<const bf16_t*>(Wdt), c0, Rp, lane, acc0, acc1);
+                else DeltaTile<T>::run(dsrc, ldd, row0, tb0, L, Wdt, c0, Rp, lane, acc0, acc1);
             } else {
                 DeltaTile<T>::run(dsrc, ldd, row0, tb0, L, Wdt, c0, Rp, lane, acc0, acc1);
             }
@@ -353,15 +372,23 @@ __global__ __launch_bounds__(64, 4) void scan_kernel(const T* __restrict__ u, co
         const int s_end = min(Lw, s_begin + TB);                         // one past the last
         if constexpr (FUSED) dv_cur = dvs[REV ? TB : 1][lane];          // block row of the first walk step: 0 forward, TB - 1 reverse
         auto dv_base = [&](int s0) -> const float* { return &dvs[REV ? TB - CH - (s0 - s_begin) : (s0 - s_begin)][lane]; };
-        auto run_step = [&](int s, int i, const float* dvp, uint32_t oy, int vy, T uraw, T zraw, T yraw, T draw) {
+        auto run_step = [&](int s, int i, const float* dvp, uint32_t oy, int vy, T uraw, T zraw, T yraw, T draw, uint32_t oys) {
             const float yv = step(s, i, dvp, Elem<T>::to_f32(uraw), HASZ ? Elem<T>::to_f32(zraw) : 0.f,
                                   ACC != 0 ? Elem<T>::to_f32(yraw) : 0.f, draw);
-            if constexpr (SEG != 1) BufIO<T>::store(Elem<T>::from_f32(yv), y_r, vy, oy);
+            if constexpr (SPLITY && SEG != 1) {
+                const uint32_t pk = pack_bf16x2(yv, 0.f);                                  // hi = bf16(y)
+                const bf16_t hi = (bf16_t)(pk & 0xffffu);
+                const bf16_t lo = f32_to_bf16(yv - bf16lo_to_f32(pk));                       // lo = bf16(y - hi)
+                BufIO<bf16_t>::store(hi, ys_r, ys_voff(i), oys);
+                BufIO<bf16_t>::store(lo, ys_r, ys_voff(i), oys + third);
+                BufIO<bf16_t>::store(hi, ys_r, ys_voff(i), oys + 2u * third);
+            } else if constexpr (SEG != 1) BufIO<T>::store(Elem<T>::from_f32(yv), y_r, vy, oy);
         };
         auto run_chunk = [&](int s0, T (&uu)[CH], T (&zz)[CH], T (&yy)[CH], T (&dd)[CH]) {
             const float* dvp = dv_base(s0);
+            const uint32_t oys = SPLITY ? ys_soff(s0) : 0u;
 #pragma unroll
-            for (int i = 0; i < CH; ++i) run_step(s0 + i, i, dvp, uy_soff(s0, i), uy_voff(i), uu[i], zz[i], yy[i], dd[i]);
+            for (int i = 0; i < CH; ++i) run_step(s0 + i, i, dvp, uy_soff(s0, i), uy_voff(i), uu[i], zz[i], yy[i], dd[i], oys);
         };
         int s0 = s_begin;
         // two chunks per iteration on alternating register sets: no copies between the sets, and each set is waited for at
@@ -384,7 +411,7 @@ __global__ __launch_bounds__(64, 4) void scan_kernel(const T* __restrict__ u, co
             const float* dvp = dv_base(s0);
 #pragma unroll
             for (int i = 0; i < CH - 1; ++i)
-                if (s0 + i < s_end) run_step(s0 + i, i, dvp, uy_soff(s0, i), uy_voff(i), ub[i], zb[i], yb[i], dr[i]);
+                if (s0 + i < s_end) run_step(s0 + i, i, dvp, uy_soff(s0, i), uy_voff(i), ub[i], zb[i], yb[i], dr[i], SPLITY ? ys_soff(s0) : 0u);
         }
     }
     if constexpr (SEG == 1) {
@@ -423,9 +450,27 @@ template <typename T, bool FUSED, int PRE = 0, bool BLK8 = false, bool ZB = fals
 static hipError_t launch_scan_t(const void* u, const void* z, int64_t ldz, const void* dsrc, int64_t ldd,
                                 const void* Wdt, int Rp, const float* bc, const float* A2, float a_scale,
                                 const float* Dskip, const float* dbias, void* y, int S, int L, int E, bool reverse,
-                                int accumulate, hipStream_t s, bool uyb, bool zblk = false, float* seg_ws = nullptr, int walk_len = 0) {
+                                int accumulate, hipStream_t s, bool uyb, bool zblk = false, float* seg_ws = nullptr, int walk_len = 0,
+                                void* ysplit = nullptr, bool dt_split = false) {
+    const int dts = dt_split ? 1 : 0;
     dim3 grid((unsigned)(E / 64), (unsigned)S), block(64);
     const bool hz = z != nullptr;
+    if (ysplit != nullptr) {
+        // out_proj's split-bf16 operand written by the walk itself: the fp32 engine's reverse (gating) launch only
+        if constexpr (std::is_same<T, float>::value && FUSED && BLK8 && ZB) {
+            const bool seg = seg_ws && scan_segments(S, L, E, nullptr) > 1;
+            if (!reverse || !hz || (accumulate != 1 && accumulate != 2) || seg || (walk_len > 0 && walk_len < L)) return hipErrorInvalidValue;
+#define PCAD_SCAN_SPLITY(ACCM)                                                                                                       \
+            hipLaunchKernelGGL((scan_kernel<T, true, ACCM, true, FUSED, PRE, BLK8, 0, true, true>), grid, block, 0, s, (const T*)u, (const T*)z, ldz, \
+                               (const T*)dsrc, ldd, (const T*)Wdt, Rp, bc, A2, a_scale, Dskip, dbias, (const T*)y, (T*)y, L, E, (int)uyb, (int)zblk, \
+                               1, 0, (float*)nullptr, L, (bf16_t*)ysplit, dts)
+            if (accumulate == 2) PCAD_SCAN_SPLITY(2); else PCAD_SCAN_SPLITY(1);
+#undef PCAD_SCAN_SPLITY
+            return hipGetLastError();
+        } else {
+            return hipErrorInvalidValue;
+        }
+    }
 #define PCAD_SCAN_ARGS(ZP) (const T*)u, (const T*)(ZP), ldz, (const T*)dsrc, ldd, (const T*)Wdt, Rp, bc, A2, a_scale, Dskip, dbias, \
                            (const T*)y, (T*)y, L, E, (int)uyb, (int)zblk
 #define PCAD_WALK (walk_len > 0 && walk_len < L ? walk_len : L)
@@ -438,7 +483,7 @@ static hipError_t launch_scan_t(const void* u, const void* z, int64_t ldz, const
         if (G > 1 && combo) {
             dim3 gseg((unsigned)(E / 64), (unsigned)(S * G));
 #define PCAD_SEG(REV, ACC, HZ, SEGM, ZP)                                                                                  \
-            hipLaunchKernelGGL((scan_kernel<T, REV, ACC, HZ, FUSED, PRE, BLK8, SEGM, ZB && HZ>), gseg, block, 0, s, PCAD_SCAN_ARGS(ZP), G, sb, seg_ws, L)
+            hipLaunchKernelGGL((scan_kernel<T, REV, ACC, HZ, FUSED, PRE, BLK8, SEGM, ZB && HZ>), gseg, block, 0, s, PCAD_SCAN_ARGS(ZP), G, sb, seg_ws, L, (bf16_t*)nullptr, dts)
             if (reverse) PCAD_SEG(true, 0, false, 1, nullptr); else PCAD_SEG(false, 0, false, 1, nullptr);
             hipLaunchKernelGGL(scan_carry_kernel, dim3((unsigned)(((int64_t)S * E + 255) / 256)), dim3(256), 0, s, seg_ws, A2, a_scale, S, G, E);
             if (!reverse) { if (hz) PCAD_SEG(false, 0, true, 2, z); else PCAD_SEG(false, 0, false, 2, nullptr); }
@@ -450,7 +495,7 @@ static hipError_t launch_scan_t(const void* u, const void* z, int64_t ldz, const
         }
     }
 #define PCAD_SCAN(REV, ACC, HZ)                                                                                    \
-    hipLaunchKernelGGL((scan_kernel<T, REV, ACC, HZ, FUSED, PRE, BLK8, 0, ZB && HZ>), grid, block, 0, s, PCAD_SCAN_ARGS(z), 1, 0, (float*)nullptr, PCAD_WALK)
+    hipLaunchKernelGGL((scan_kernel<T, REV, ACC, HZ, FUSED, PRE, BLK8, 0, ZB && HZ>), grid, block, 0, s, PCAD_SCAN_ARGS(z), 1, 0, (float*)nullptr, PCAD_WALK, (bf16_t*)nullptr, dts)
     if (accumulate == 2) {                    // (y_prev + y) * silu(z): the bi-directional sum gated once
         if (!hz) return hipErrorInvalidValue;
         if (reverse) PCAD_SCAN(true, 2, true); else PCAD_SCAN(false, 2, true);
@@ -468,8 +513,11 @@ static hipError_t launch_scan_t(const void* u, const void* z, int64_t ldz, const
 hipError_t launch_scan(const void* u, const void* z, int64_t ldz, const void* delta, const void* dt_low, int64_t lddt,
                        const void* Wdt, int Rp, const float* bc, const float* A2, float a_scale, const float* Dskip,
                        const float* dbias, void* y, int S, int L, int E, bool reverse, int accumulate, int dt,
-                       hipStream_t s, bool uyb, bool zblk, float* seg_ws, int walk_len) {
+                       hipStream_t s, bool uyb, bool zblk, float* seg_ws, int walk_len, void* ysplit, bool dt_split) {
     if (zblk && !uyb) return hipErrorInvalidValue;
+    if (dt_split && !(dt == F32 && delta == nullptr && Rp % 16 == 0 && lddt % 8 == 0)) return hipErrorInvalidValue;   // bf16 [hi | lo | hi] x [hi | hi | lo]
+    if (ysplit && !(dt == F32 && delta == nullptr && uyb && zblk && L % 8 == 0 && ((int64_t)S * L + 7) / 8 * 8 * 3 * E * 2 < ((int64_t)1 << 32)))
+        return hipErrorInvalidValue;        // the split output exists in the fp32 engine's compile-time-layout instantiation only
     if (S <= 0 || L <= 0) return hipSuccess;
     if (E % 64) return hipErrorInvalidValue;
     if ((int64_t)L * (ldz > E ? ldz : E) * 4 >= ((int64_t)1 << 31)) return hipErrorInvalidValue;   // 32-bit in-strand offsets
@@ -494,8 +542,9 @@ hipError_t launch_scan(const void* u, const void* z, int64_t ldz, const void* de
     // scalar block offset per 4-step chunk, per-step offsets in the immediates); dt_proj stays on v_mfma_f32_32x32x2_f32, unprefetched
     static const bool f32_generic = dev_env("PCAD_SCAN_F32_GENERIC") != nullptr;       // PCAD_DEV=1 A/B: the run-time-layout instantiation
     if (!f32_generic && fused && uyb && L % 8 == 0 && zblk)
-        return launch_scan_t<float, true, 0, true, true>(u, z, ldz, dt_low, lddt, Wdt, Rp, bc, A2, a_scale, Dskip, dbias, y, S, L, E, reverse, accumulate, s, uyb, zblk, seg_ws, walk_len);
-    if (fused) return launch_scan_t<float, true>(u, z, ldz, dt_low, lddt, Wdt, Rp, bc, A2, a_scale, Dskip, dbias, y, S, L, E, reverse, accumulate, s, uyb, zblk, seg_ws, walk_len);
+        return launch_scan_t<float, true, 0, true, true>(u, z, ldz, dt_low, lddt, Wdt, Rp, bc, A2, a_scale, Dskip, dbias, y, S, L, E, reverse, accumulate, s, uyb, zblk, seg_ws, walk_len, ysplit, dt_split);
+    if (ysplit) return hipErrorInvalidValue;
+    if (fused) return launch_scan_t<float, true>(u, z, ldz, dt_low, lddt, Wdt, Rp, bc, A2, a_scale, Dskip, dbias, y, S, L, E, reverse, accumulate, s, uyb, zblk, seg_ws, walk_len, nullptr, dt_split);
     return launch_scan_t<float, false>(u, z, ldz, delta, E, nullptr, 0, bc, A2, a_scale, Dskip, dbias, y, S, L, E, reverse, accumulate, s, uyb, zblk, seg_ws, walk_len);
 }
 
