@@ -429,3 +429,26 @@ def test_f32_gemm_split_matches_oracle(D, nl, B, L):
     mb = build(cfg, sd, torch.bfloat16, f32_gemm_split=1)
     mb0 = build(cfg, sd, torch.bfloat16)
     assert torch.equal(mb(input_ids=ids.to(DEV)).logits.cpu(), mb0(input_ids=ids.to(DEV)).logits.cpu())
+
+
+def test_options_that_need_bind_time_copies_are_refused_afterwards():
+    """"f32_gemm_split" 1 and "norm_fold" 1 on an fp32 model need weight copies that are packed when the weights are bound
+    (include/pcad.h): set through config.engine_options they work; set on a bound engine the next forward fails loudly instead of
+    silently running another form; turning them OFF afterwards is always possible."""
+    cfg = make_config("x", d_model=256, n_layer=2)
+    sd = synthetic_state_dict(cfg, seed=4)
+    ids = rand_ids(2, 64, 3).to(DEV)
+    m = build(cfg, sd, torch.float32)
+    ref = m(input_ids=ids).logits.cpu()
+    eng = m._engine()
+    for opt in ("f32_gemm_split", "norm_fold"):
+        eng.set_option(opt, 1)
+        with pytest.raises(RuntimeError, match="pcad_bind_weights"):
+            m(input_ids=ids)
+        eng.set_option(opt, 0)
+        assert torch.equal(m(input_ids=ids).logits.cpu(), ref)
+    m2 = build(cfg, sd, torch.float32, f32_gemm_split=1)
+    a = m2(input_ids=ids).logits.cpu()
+    m2._engine().set_option("f32_gemm_split", 0)                 # off again: the plain fp32 GEMMs, bit-identical to a plain engine
+    assert torch.equal(m2(input_ids=ids).logits.cpu(), ref)
+    assert ((a - ref).abs().max() / ref.abs().max()).item() < 1e-5

@@ -62,6 +62,27 @@ def _worker(rank, ws, port, n, outdir):
         dist.destroy_process_group()
 
 
+def _decide_worker(rank, ws, port, outdir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=ws)
+    try:
+        # each rank "sees" something else (a cache file visible on some ranks only): everyone must follow rank 0
+        got = [sharding.rank0_decides(rank == 0), sharding.rank0_decides(rank != 0), sharding.rank0_decides(rank % 2 == 1)]
+        with open(os.path.join(outdir, f"d{rank}.txt"), "w") as f:
+            f.write(repr(got))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rank0_decides_is_uniform_across_ranks(tmp_path):
+    """a yes / no that selects between a branch with collectives and one without (cache file exists?) is rank 0's
+    value on every rank, whatever each rank sees; outside a process group it is the caller's own value."""
+    assert sharding.rank0_decides(True) is True and sharding.rank0_decides(False) is False
+    mp.spawn(_decide_worker, args=(3, _free_port(), str(tmp_path)), nprocs=3, join=True)
+    for r in range(3):
+        assert open(tmp_path / f"d{r}.txt").read() == repr([True, False, False])
+
+
 @pytest.mark.parametrize("ws,n", [(2, 5), (2, 0), (4, 185), (4, 1), (8, 185), (8, 1), (8, 0)])
 def test_multi_rank_gather_equals_single_rank(tmp_path, ws, n):
     """world 2 / 4 / 8 over gloo; N = 185 (the example table: not divisible by 4 or 8, tail padded), N = 1 (fewer rows than
