@@ -87,6 +87,7 @@ void   pcad_destroy(pcad_handle h);
  *   "chunk_seqs"  windows per pass through the layer stack (0 = default: as many as the kernels' unsigned 32-bit in-tensor
  *                 offsets allow, (2^32 - 2 MiB) / (d_inner * elem) token-rows = 1 023 windows of 512 bp at l32 bf16, the batch
  *                 split evenly into the fewest such chunks).  Results do not depend on it (rows are independent) - bit for bit
+ *                 (up to the small-launch forms of "scan_segments", whose fp32 summation order follows the launch size)
  *                 whenever every chunking runs the same layer form, which holds for window lengths that are multiples of 128
  *                 (every shipped use); for other lengths "norm_fold" engages per chunk (whole 256-row tiles only), so two
  *                 chunkings of a bf16 batch can differ by bf16 rounding; the
@@ -137,9 +138,12 @@ void   pcad_destroy(pcad_handle h);
  *                 Cost at l32 bf16 (same box, profiles/r05_*): see INTEGRATION.md "Operation order".  Setting "gate_each" /
  *                 "norm_fold" afterwards overrides the respective part; level 2 is ignored while "norm_fold" is forced to 1.
  *   "scan_segments"  1 (default): when a launch has few scan waves (at most 768 for L >= 2 048: PlantCAD2's 8 192-bp windows in small
- *                 batches; at most 512 for shorter windows: up to 8 windows of 512 bp at l32) the scan of every strand is cut into up to 8 segments that run as
+ *                 batches; at most 512 for shorter windows: up to 8 windows of 512 bp at l32) the scan of every strand is cut into up to 8 (short windows: 16, of at least 32 steps) segments that run as
  *                 separate workgroups (zero-state pass, carry, real pass: ~1.8x the arithmetic for up to 8x the parallelism;
  *                 results equal up to fp32 rounding of the carried decay product);  0: one workgroup walks the whole strand.
+ *                 The same switch governs the K-split of the fused conv + x_proj kernel for launches of at most 64 row tiles (up to 8
+ *                 windows of 512 bp): several blocks per row tile each walk a share of the channels and a second tiny kernel adds
+ *                 their partial x_proj sums in a fixed order (deterministic; another fp32 summation order than the unsplit walk).
  *                 Never used by the benchmark batch (1 024 windows: 65 536 waves).
  *   "debug_repeat_class" / "debug_repeat"  measurement aid (tools/power_probe.py): every idempotent launch of ONE pcad_kernel_class
  *                 (in_proj, conv + x_proj, the forward-direction scan, the reference-order out_proj) is issued `debug_repeat` times

@@ -178,6 +178,7 @@ struct Workspace {
     float* bc[2];
     float *rstd, *ssq;   // norm-folded form: rstd [rows]; partial sums of squares [rows, D / 128]
     float* seg;      // segmented-scan scratch (long sequences with few strands), or nullptr
+    float* cxp;      // K-split scratch of the fused conv + x_proj kernel (small launches), or nullptr
     size_t bytes;
 };
 
@@ -210,6 +211,10 @@ Workspace carve_workspace(const pcad_engine* e, void* base, int Bc, int L) {
     w.ssq = (float*)c.take(rows * (Dp / 128) * 4);
     const size_t segb = e->segments ? scan_segment_bytes(2 * Bc, L, (int)E) : 0;
     w.seg = segb ? (float*)c.take(segb) : nullptr;
+    // small launches: the conv + x_proj kernel splits its channel walk over several blocks per row tile ("scan_segments" 0 turns this
+    // off together with the segmented scan: both trade a different fp32 summation order for parallelism on an otherwise empty chip)
+    const size_t cxb = e->segments && e->convx ? convx_split_bytes(2 * Bc, L, (int)E, e->cfg.dtype, e->Rp) : 0;
+    w.cxp = cxb ? (float*)c.take(cxb) : nullptr;
     w.bytes = c.off;
     return w;
 }
@@ -622,7 +627,7 @@ static int forward_impl(pcad_handle h, const int32_t* ids, int B, int L, const i
         if (convx) for (int rep = 0; rep < reps(PCAD_K_CONV); ++rep) {
             ProfScope ps(e, PCAD_K_CONV, s);
             HIP_TRY(launch_convx(c.w.xz, W.convw, sp ? W.dir[0].Wx_s : W.dir[0].Wx, c.w.xc[0], c.w.dtl[0], c.w.bc[0], sp ? W.dir[1].Wx_s : W.dir[1].Wx, c.w.xc[1],
-                                 c.w.dtl[1], c.w.bc[1], S, L, E, dt, s, Rp, sp, sp));      // sp: dt_low as bf16 [hi | lo | hi] for the scan's split dt_proj
+                                 c.w.dtl[1], c.w.bc[1], S, L, E, dt, s, Rp, sp, sp, c.w.cxp));      // sp: dt_low as bf16 [hi | lo | hi] for the scan's split dt_proj
         } else {
             ProfScope ps(e, PCAD_K_CONV, s);
             HIP_TRY(launch_conv_bidir(c.w.xz, e->xzsplit ? E : 2 * E, W.dir[0].conv_w, W.dir[0].conv_b, W.dir[1].conv_w,

@@ -136,9 +136,12 @@ struct ConvxDir {
 // LDS slab and staging as the fp32 weight); the conv stage stays fp32 (it is also what the xc copy-out reads) and the A fragment - 8
 // consecutive channels per lane - is split into hi / lo when it is loaded: 36 v_mfma_f32_16x16x32_bf16 per K-tile and wave instead of
 // 96 v_mfma_f32_16x16x4_f32 at a quarter of the rate (the fp32 kernel is MFMA-bound: 3 072 of its cycles per K-tile and wave).
+// K-split (small launches, launch_convx): gridDim.y = KS blocks share a row tile, block ks convolves / copies out / multiplies the K-tiles
+// [ks * nkt / KS, (ks + 1) * nkt / KS) only and writes its raw fp32 x_proj accumulators to `part` ([KS][2 dirs][rows][16 NJ]);
+// convx_reduce_kernel adds the KS partials in index order (deterministic) and writes dt_low / B|C in the formats of the epilogue below.
 template <typename T, bool ZFILL, int NJ = 6, bool XS = false>
 __global__ __launch_bounds__(CX_THREADS, 2) void convx_kernel(const T* __restrict__ x, const float* __restrict__ convw,
-                                                              ConvxDir d0, ConvxDir d1, int S, int L, int E) {
+                                                              ConvxDir d0, ConvxDir d1, int S, int L, int E, float* __restrict__ part) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using G = CxGeom<NJ>;
     constexpr int CX_W_BYTES = G::W_BYTES, CX_OFF_CW = G::OFF_CW;
@@ -153,8 +156,9 @@ __global__ __launch_bounds__(CX_THREADS, 2) void convx_kernel(const T* __restric
     const int strand = blockIdx.x / tiles_per_strand;
     const int t0 = (blockIdx.x - strand * tiles_per_strand) * CX_ROWS;
     const int64_t row0 = (int64_t)strand * L;                     // whole-tensor row of t = 0
-    const int nkt = E / KC;
-    const int64_t pieces = nkt;                                   // 128-byte pieces per row of x / xc
+    const int64_t pieces = E / KC;                                // 128-byte pieces per row of x / xc
+    const int nkt = (E / KC) / (int)gridDim.y;                    // K-tiles THIS block walks (K-split: a gridDim.y-th of them)
+    const int kt0 = (int)blockIdx.y * nkt;                        // ... starting at this one
 
     // ---- staging (every wave issues exactly 7 LDS-DMAs per K-tile: 3 raw + 3 Wx + 1 taps) -------------------------
     // raw: 17 groups of 8 rows; wave w stages groups w, w + 8 and (all waves, redundantly) group 16
@@ -386,9 +390,9 @@ __global__ __launch_bounds__(CX_THREADS, 2) void convx_kernel(const T* __restric
         if (with_mfma && !REVC) { __builtin_amdgcn_sched_barrier(0); mfma_half(1 - par, 0); mfma_half(1 - par, 1); copy_out(kt - 1, 1 - par); }
     };
 
-    // prologue: taps(0), raw(0)
-    stage_taps(0, 0);
-    stage_raw(0, 0);
+    // prologue: taps and raw tile of the block's first K-tile
+    stage_taps(kt0, 0);
+    stage_raw(kt0, 0);
     // the loop is unrolled by two so that every LDS stage offset is a compile-time constant (addresses = a lane register
     // + an immediate instead of per-access SALU/VALU address arithmetic; the kernel is instruction-issue bound)
     auto iteration = [&](int it, auto par_tag) __attribute__((always_inline)) {
@@ -402,28 +406,28 @@ __global__ __launch_bounds__(CX_THREADS, 2) void convx_kernel(const T* __restric
         if constexpr (W1) {
             // single Wx slab: taps / raw tile of K-tile it+1 first, then ALL MFMAs of K-tile it-1 (they read Wx(it-1)), a second
             // barrier (every wave's fragment reads are complete), and only then the fetch of Wx(it) into the same slab
-            if (it + 1 < nkt) { stage_taps(it + 1, 1 - P); stage_raw(it + 1, 1 - P); }
+            if (it + 1 < nkt) { stage_taps(kt0 + it + 1, 1 - P); stage_raw(kt0 + it + 1, 1 - P); }
             if (it > 0) { mfma_half(1 - P, 0); mfma_half(1 - P, 1); }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
             if (it < nkt) {
-                stage_w(it, P);
-                if (cdir) conv_pass(it, P, std::true_type{}, false);
-                else conv_pass(it, P, std::false_type{}, false);
+                stage_w(kt0 + it, P);
+                if (cdir) conv_pass(kt0 + it, P, std::true_type{}, false);
+                else conv_pass(kt0 + it, P, std::false_type{}, false);
             }
-            if (it > 0) copy_out(it - 1, 1 - P);
+            if (it > 0) copy_out(kt0 + it - 1, 1 - P);
             return;
         }
-        if (it < nkt) stage_w(it, P);
-        if (it + 1 < nkt) { stage_taps(it + 1, 1 - P); stage_raw(it + 1, 1 - P); }
+        if (it < nkt) stage_w(kt0 + it, P);
+        if (it + 1 < nkt) { stage_taps(kt0 + it + 1, 1 - P); stage_raw(kt0 + it + 1, 1 - P); }
         if (it < nkt) {
-            if (cdir) conv_pass(it, P, std::true_type{}, it > 0);
-            else conv_pass(it, P, std::false_type{}, it > 0);
+            if (cdir) conv_pass(kt0 + it, P, std::true_type{}, it > 0);
+            else conv_pass(kt0 + it, P, std::false_type{}, it > 0);
         } else {
             mfma_half(1 - P, 0);
             mfma_half(1 - P, 1);
-            copy_out(it - 1, 1 - P);
+            copy_out(kt0 + it - 1, 1 - P);
         }
     };
     for (int it = 0; it <= nkt; it += 2) {
@@ -433,6 +437,19 @@ __global__ __launch_bounds__(CX_THREADS, 2) void convx_kernel(const T* __restric
 
     // ---- epilogue: lane (li = row, lg): fragment j -> columns j*16 + lg*4 .. +3 --------------------------------
     const ConvxDir dd = cdir ? d1 : d0;
+    if (part != nullptr) {          // K-split: raw partial sums, reduced by convx_reduce_kernel
+        const int64_t rows_all = (int64_t)S * L;
+        float* pb = part + ((int64_t)blockIdx.y * 2 + cdir) * rows_all * (16 * NJ);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int t = t0 + mq * 32 + i * 16 + li;
+            if (t >= L) continue;
+            float* pr = pb + (row0 + t) * (16 * NJ);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) *reinterpret_cast<f32x4*>(pr + j * 16 + lg * 4) = acc[i][j];
+        }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int t = t0 + mq * 32 + i * 16 + li;
@@ -465,6 +482,60 @@ __global__ __launch_bounds__(CX_THREADS, 2) void convx_kernel(const T* __restric
             *reinterpret_cast<f32x4*>(bcr + (j - (NJ - 2)) * 16 + lg * 4) = v;
         }
     }
+}
+
+// K-split reduction: x_dbl[dir][row][col] = sum_ks part[ks][dir][row][col] (index order), written as the epilogue above writes it:
+// columns [0, 16 (NJ - 2)) -> dt_low (model dtype, or the bf16 [hi | lo | hi] form), the last 32 -> B_t | C_t fp32 rounded to the model dtype
+template <typename T>
+__global__ __launch_bounds__(256) void convx_reduce_kernel(const float* __restrict__ part, int KS, int64_t rows, int XPW, ConvxDir d0, ConvxDir d1) {
+    const int q4 = XPW / 4;
+    const int64_t total = 2 * rows * q4;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % q4) * 4;
+        const int64_t rr = i / q4;
+        const int dir = (int)(rr / rows);
+        const int64_t row = rr - (int64_t)dir * rows;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        for (int ks = 0; ks < KS; ++ks) v += *reinterpret_cast<const f32x4*>(part + (((int64_t)ks * 2 + dir) * rows + row) * XPW + c4);
+        const ConvxDir dd = dir ? d1 : d0;
+        const int RPW = XPW - 32;
+        if (c4 < RPW) {
+            if constexpr (sizeof(T) == 2) {
+                *reinterpret_cast<u32x2*>((T*)dd.dtl + row * RPW + c4) = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+            } else if (dd.dtl_split) {
+                bf16_t* ds = (bf16_t*)dd.dtl + row * (3 * RPW) + c4;
+                const u32x2 hi = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+                const u32x2 lo = {pack_bf16x2(v[0] - bf16lo_to_f32(hi[0]), v[1] - bf16hi_to_f32(hi[0])),
+                                  pack_bf16x2(v[2] - bf16lo_to_f32(hi[1]), v[3] - bf16hi_to_f32(hi[1]))};
+                *reinterpret_cast<u32x2*>(ds) = hi;
+                *reinterpret_cast<u32x2*>(ds + RPW) = lo;
+                *reinterpret_cast<u32x2*>(ds + 2 * RPW) = hi;
+            } else {
+                *reinterpret_cast<f32x4*>((T*)dd.dtl + row * RPW + c4) = v;
+            }
+        } else {
+            *reinterpret_cast<f32x4*>(dd.bc + row * 32 + (c4 - RPW)) = f32x4{Elem<T>::round(v[0]), Elem<T>::round(v[1]), Elem<T>::round(v[2]), Elem<T>::round(v[3])};
+        }
+    }
+}
+
+// K-split policy (a function of the launch shape only): split when the row tiles alone leave at least half of the chip's 256 CUs
+// idle - the 512-bp windows of the reference's interactive use in batches of up to 8 at l32 - into the largest divisor KS of the
+// K-tile count with tiles * KS <= 256 and at least 2 K-tiles per block.  One window at l32: 8 blocks x 32 K-tiles -> 128 blocks x 2.
+int convx_ksplit(int S, int L, int E, int dt) {
+    const int KC = CX_ROWB / (dt == BF16 ? 2 : 4);
+    const int nkt = E / KC;
+    const int64_t tiles = (int64_t)S * ((L + CX_ROWS - 1) / CX_ROWS);
+    if (tiles <= 0 || tiles > 64) return 1;
+    int best = 1;
+    for (int ks = 2; ks <= nkt / 2; ++ks)
+        if (nkt % ks == 0 && tiles * ks <= 256) best = ks;
+    return best;
+}
+
+size_t convx_split_bytes(int S, int L, int E, int dt, int Rp) {
+    const int ks = convx_ksplit(S, L, E, dt);
+    return ks > 1 ? (size_t)ks * 2 * (size_t)S * L * (Rp + 32) * sizeof(float) : 0;
 }
 
 // conv taps of both directions -> per K-tile [dir][tap 0..3, bias][KC] fp32 (CX_CW_BYTES per K-tile, zero padded)
@@ -522,7 +593,7 @@ hipError_t launch_pack_convw(const float* wf, const float* bf, const float* wr, 
 
 hipError_t launch_convx(const void* x, const float* convw, const void* Wx0, void* xc0, void* dtl0, float* bc0,
                         const void* Wx1, void* xc1, void* dtl1, float* bc1, int S, int L, int E, int dt, hipStream_t s, int Rp, bool dtl_split,
-                        bool w_split) {
+                        bool w_split, float* part_ws) {
     if (S <= 0 || L <= 0) return hipSuccess;
     if ((dtl_split || w_split) && dt != F32) return hipErrorInvalidValue;
     const int esz = dt == BF16 ? 2 : 4;
@@ -531,12 +602,14 @@ hipError_t launch_convx(const void* x, const float* convw, const void* Wx0, void
     ConvxDir d0{Wx0, xc0, dtl0, bc0, dtl_split ? 1 : 0}, d1{Wx1, xc1, dtl1, bc1, dtl_split ? 1 : 0};
     const int tiles = S * ((L + CX_ROWS - 1) / CX_ROWS);
     const bool zfill = L % 8 == 0;
+    const int ks = part_ws ? convx_ksplit(S, L, E, dt) : 1;
+    float* part = ks > 1 ? part_ws : nullptr;
 #define PCAD_CONVX(T, Z, NJ_)                                                                                         \
     do {                                                                                                                \
         auto k = convx_kernel<T, Z, NJ_>;                                                                               \
         if constexpr (std::is_same<T, float>::value) { if (w_split) k = convx_kernel<T, Z, NJ_, true>; }                \
         if (hipError_t ae = ensure_dynamic_lds((const void*)k, CxGeom<NJ_>::LDS)) return ae;                            \
-        hipLaunchKernelGGL(k, dim3((unsigned)tiles), dim3(CX_THREADS), CxGeom<NJ_>::LDS, s, (const T*)x, convw, d0, d1, S, L, E); \
+        hipLaunchKernelGGL(k, dim3((unsigned)tiles, (unsigned)ks), dim3(CX_THREADS), CxGeom<NJ_>::LDS, s, (const T*)x, convw, d0, d1, S, L, E, part); \
     } while (0)
 #define PCAD_CONVX_NJ(NJ_)                                                                                            \
     do {                                                                                                                \
@@ -546,6 +619,12 @@ hipError_t launch_convx(const void* x, const float* convw, const void* Wx0, void
     if (Rp == 64) PCAD_CONVX_NJ(6); else PCAD_CONVX_NJ(8);
 #undef PCAD_CONVX_NJ
 #undef PCAD_CONVX
+    if (part) {
+        const int64_t rows = (int64_t)S * L;
+        const unsigned nb = (unsigned)((2 * rows * ((Rp + 32) / 4) + 255) / 256);
+        if (dt == BF16) hipLaunchKernelGGL(convx_reduce_kernel<bf16_t>, dim3(nb > 4096 ? 4096 : nb), dim3(256), 0, s, part, ks, rows, Rp + 32, d0, d1);
+        else hipLaunchKernelGGL(convx_reduce_kernel<float>, dim3(nb > 4096 ? 4096 : nb), dim3(256), 0, s, part, ks, rows, Rp + 32, d0, d1);
+    }
     return hipGetLastError();
 }
 

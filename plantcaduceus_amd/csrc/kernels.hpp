@@ -104,8 +104,12 @@ hipError_t launch_pack_convw(const float* wf, const float* bf, const float* wr, 
 hipError_t launch_convx(const void* x, const float* convw, const void* Wx0, void* xc0, void* dtl0, float* bc0,
                         const void* Wx1, void* xc1, void* dtl1, float* bc1, int S, int L, int E, int dt, hipStream_t s, int Rp = 64,
                         bool dtl_split = false,       // dtl_split (dt == F32): dtl_d is written as bf16 [S*L, 3 Rp] = [hi | lo | hi]
-                        bool w_split = false);        // w_split (dt == F32): Wx_d is the bf16 [Rp + 32, 2E] copy of launch_pack_convx_wsplit and
+                        bool w_split = false,         // w_split (dt == F32): Wx_d is the bf16 [Rp + 32, 2E] copy of launch_pack_convx_wsplit and
                                                       // x_proj runs as three bf16 MFMA products per fp32 product
+                        float* part_ws = nullptr);    // scratch of convx_split_bytes(): small launches split the channel walk over several
+                                                      // blocks per row tile (convx_ksplit) and a second tiny kernel adds their partial x_dbl
+int convx_ksplit(int S, int L, int E, int dt);        // K-split factor for this launch shape (1: none)
+size_t convx_split_bytes(int S, int L, int E, int dt, int Rp);
 hipError_t launch_pack_convx_wsplit(const float* src, int64_t ld, void* dst, int rows, int E, hipStream_t s);
 // dt_rank padded to the K granule of the fused kernels: 64 up to dt_rank 64 (every PlantCaduceus size), else the next multiple of 32
 // (PlantCAD2 Large: dt_rank 96 -> 96)
@@ -135,19 +139,21 @@ hipError_t launch_scan(const void* u, const void* z, int64_t ldz, const void* de
 // Segments per strand for the scan of S strands of L steps over E channels.  Pass A + pass B cost ~1.8x the arithmetic of one
 // walk, and a single wave per SIMD already keeps the VALU ~65 % busy, so cutting only pays when most SIMDs would otherwise idle
 // (measured: 1 536 waves at L = 8 192 are 15 % FASTER uncut).  Cut when the launch has at most 768 waves (0.75 per SIMD): into
-// enough segments for ~2 300 waves, at most 8; long strands (L >= 2 048) into segments of at least 512 steps (16 blocks of 32),
+// enough segments for ~2 300 waves, at most 8 (16 for short strands); long strands (L >= 2 048) into segments of at least 512 steps (16 blocks of 32),
 // short ones (the reference's 512-bp windows in batches of at most 8 at l32: notebooks/examples.ipynb:141-170 runs B = 1) into
 // segments of at least 64 steps when the launch has at most 512 waves, where the chip is so empty that two 64-step passes beat one
 // 512-step walk (profiles/r04j_small_batch.txt, seq/s without -> with: l32 B = 1 61 -> 107, B = 8 455 -> 548; l20 B = 1 119 -> 257,
-// B = 8 929 -> 1682; at 768 waves - l20 B = 32 - it loses 13 %, hence the lower bound for short strands).
+// B = 8 929 -> 1682; at 768 waves - l20 B = 32 - it loses 13 %, hence the lower bound for short strands).  Round 5: short strands into up
+// to 16 segments of at least 32 steps (one delta tile): l32 B = 1 107 -> 118 seq/s, l20 B = 1 / 2 / 4 243 / 474 / 918 -> 283 / 546 / 996,
+// B >= 8 unchanged (profiles/r05g_small_batch.txt, same box).
 inline int scan_segments(int S, int L, int E, int* seg_blocks) {
     const int64_t waves = (int64_t)S * (E / 64);
     const int nblk = (L + 31) / 32;
-    const int min_blocks = L >= 2048 ? 16 : 2;
+    const int min_blocks = L >= 2048 ? 16 : 1;
     int G = 1;
     if (L >= 256 && waves > 0 && waves <= (L >= 2048 ? 768 : 512)) {
         G = (int)((2304 + waves - 1) / waves);
-        if (G > 8) G = 8;
+        if (G > (L >= 2048 ? 8 : 16)) G = L >= 2048 ? 8 : 16;
         if (G > nblk / min_blocks) G = nblk / min_blocks;
         if (G < 3) G = 1;                              // below ~3x the waves the second pass is not paid for
     }

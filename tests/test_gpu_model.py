@@ -251,7 +251,10 @@ def test_segmented_scan_equals_single_walk(dtype, D, L, B):
     """long windows, few strands: the scan cuts every strand into segments run by separate workgroups (zero-state pass, carry,
     real pass; csrc/kernels.hpp::scan_segments).  Same function as one workgroup walking the whole strand (`scan_segments` = 0):
     fp32 to 2e-5 of max (the carried decay is exp2(A * sum delta) instead of a product of per-step exps), bf16 to bf16 noise;
-    L = 2080: last segment shorter than the others and a partial 32-step block."""
+    L = 2080: last segment shorter than the others and a partial 32-step block.  Round 5: the same switch governs the K-split of
+    the fused conv + x_proj kernel on launches of at most 64 row tiles (csrc/convx.hip::convx_ksplit: several blocks per row tile,
+    partial x_proj sums added by convx_reduce_kernel), so the 512-bp cases compare split against unsplit walks of that kernel too
+    (another fp32 summation order of x_dbl), with the partial-sum scratch poisoned."""
     cfg = make_config("x", d_model=D, n_layer=2)
     sd = synthetic_state_dict(cfg, seed=31)
     ids = rand_ids(B, L, 3, mask=L // 2).to(DEV)
