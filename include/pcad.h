@@ -87,7 +87,7 @@ void   pcad_destroy(pcad_handle h);
  *   "chunk_seqs"  windows per pass through the layer stack (0 = default: as many as the kernels' unsigned 32-bit in-tensor
  *                 offsets allow, (2^32 - 2 MiB) / (d_inner * elem) token-rows = 1 023 windows of 512 bp at l32 bf16, the batch
  *                 split evenly into the fewest such chunks).  Results do not depend on it (rows are independent) - bit for bit
- *                 (up to the small-launch forms of "scan_segments", whose fp32 summation order follows the launch size)
+ *                 (the small-launch forms of "scan_segments" are chosen for the whole batch of the call, not per chunk)
  *                 whenever every chunking runs the same layer form, which holds for window lengths that are multiples of 128
  *                 (every shipped use); for other lengths "norm_fold" engages per chunk (whole 256-row tiles only), so two
  *                 chunkings of a bf16 batch can differ by bf16 rounding; the
@@ -144,6 +144,9 @@ void   pcad_destroy(pcad_handle h);
  *                 The same switch governs the K-split of the fused conv + x_proj kernel for launches of at most 64 row tiles (up to 8
  *                 windows of 512 bp): several blocks per row tile each walk a share of the channels and a second tiny kernel adds
  *                 their partial x_proj sums in a fixed order (deterministic; another fp32 summation order than the unsplit walk).
+ *                 Both forms are selected from the batch size of the pcad_forward call (not from the chunk), so two calls with the
+ *                 same batch agree bit for bit whatever "chunk_seqs" is; calls with different batch sizes may differ by fp32 rounding
+ *                 of these sums when one of them is small enough to take a split form.
  *                 Never used by the benchmark batch (1 024 windows: 65 536 waves).
  *   "debug_repeat_class" / "debug_repeat"  measurement aid (tools/power_probe.py): every idempotent launch of ONE pcad_kernel_class
  *                 (in_proj, conv + x_proj, the forward-direction scan, the reference-order out_proj) is issued `debug_repeat` times

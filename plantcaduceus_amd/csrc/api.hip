@@ -182,7 +182,9 @@ struct Workspace {
     size_t bytes;
 };
 
-Workspace carve_workspace(const pcad_engine* e, void* base, int Bc, int L) {
+// Bpol: windows of the whole pcad_forward call - the small-launch forms (segmented scan, conv + x_proj K-split) are chosen for the
+// call, not per chunk, so that results never depend on the chunking
+Workspace carve_workspace(const pcad_engine* e, void* base, int Bc, int L, int Bpol) {
     Carver c(base);
     const size_t rows = (size_t)2 * Bc * L;
     const size_t D = e->D, E = e->E, esz = e->esz;
@@ -209,11 +211,11 @@ Workspace carve_workspace(const pcad_engine* e, void* base, int Bc, int L) {
     w.ys = sp ? c.take(rows8 * 3 * E * 2) : nullptr;
     w.rstd = (float*)c.take(rows * 4);
     w.ssq = (float*)c.take(rows * (Dp / 128) * 4);
-    const size_t segb = e->segments ? scan_segment_bytes(2 * Bc, L, (int)E) : 0;
+    const size_t segb = e->segments ? scan_segment_bytes(2 * Bc, L, (int)E, 2 * Bpol) : 0;
     w.seg = segb ? (float*)c.take(segb) : nullptr;
     // small launches: the conv + x_proj kernel splits its channel walk over several blocks per row tile ("scan_segments" 0 turns this
     // off together with the segmented scan: both trade a different fp32 summation order for parallelism on an otherwise empty chip)
-    const size_t cxb = e->segments && e->convx ? convx_split_bytes(2 * Bc, L, (int)E, e->cfg.dtype, e->Rp) : 0;
+    const size_t cxb = e->segments && e->convx ? convx_split_bytes(2 * Bc, L, (int)E, e->cfg.dtype, e->Rp, 2 * Bpol) : 0;
     w.cxp = cxb ? (float*)c.take(cxb) : nullptr;
     w.bytes = c.off;
     return w;
@@ -473,11 +475,11 @@ static int chunk_for(const pcad_engine* e, int B, int L) {
     if (e->chunk > 0 && e->chunk < cap) cap = e->chunk;
     if (cap < 1) cap = 1;
     if (cap > B) cap = B;
-    if (e->ws_limit > 0 && carve_workspace(e, nullptr, (int)cap, L).bytes > (size_t)e->ws_limit) {
+    if (e->ws_limit > 0 && carve_workspace(e, nullptr, (int)cap, L, B).bytes > (size_t)e->ws_limit) {
         int64_t lo = 1, hi = cap;                     // largest chunk whose workspace fits (the size is monotone in the chunk)
         while (lo < hi) {
             const int64_t mid = (lo + hi + 1) / 2;
-            if (carve_workspace(e, nullptr, (int)mid, L).bytes <= (size_t)e->ws_limit) lo = mid; else hi = mid - 1;
+            if (carve_workspace(e, nullptr, (int)mid, L, B).bytes <= (size_t)e->ws_limit) lo = mid; else hi = mid - 1;
         }
         cap = lo;                                     // one window always runs, whatever the limit
     }
@@ -490,7 +492,7 @@ size_t pcad_workspace_bytes(pcad_handle h, int batch, int seqlen) {
     const int Bc = chunk_for(h, batch, seqlen);
     const int nchunks = (batch + Bc - 1) / Bc;
     (void)nchunks;                                                   // chunks run one after the other in ONE workspace slab
-    return carve_workspace(h, nullptr, Bc, seqlen).bytes;
+    return carve_workspace(h, nullptr, Bc, seqlen, batch).bytes;
 }
 
 static int forward_impl(pcad_handle h, const int32_t* ids, int B, int L, const int32_t* positions, int P,
@@ -627,7 +629,7 @@ static int forward_impl(pcad_handle h, const int32_t* ids, int B, int L, const i
         if (convx) for (int rep = 0; rep < reps(PCAD_K_CONV); ++rep) {
             ProfScope ps(e, PCAD_K_CONV, s);
             HIP_TRY(launch_convx(c.w.xz, W.convw, sp ? W.dir[0].Wx_s : W.dir[0].Wx, c.w.xc[0], c.w.dtl[0], c.w.bc[0], sp ? W.dir[1].Wx_s : W.dir[1].Wx, c.w.xc[1],
-                                 c.w.dtl[1], c.w.bc[1], S, L, E, dt, s, Rp, sp, sp, c.w.cxp));      // sp: dt_low as bf16 [hi | lo | hi] for the scan's split dt_proj
+                                 c.w.dtl[1], c.w.bc[1], S, L, E, dt, s, Rp, sp, sp, c.w.cxp, 2 * B));      // sp: dt_low as bf16 [hi | lo | hi] for the scan's split dt_proj
         } else {
             ProfScope ps(e, PCAD_K_CONV, s);
             HIP_TRY(launch_conv_bidir(c.w.xz, e->xzsplit ? E : 2 * E, W.dir[0].conv_w, W.dir[0].conv_b, W.dir[1].conv_w,
@@ -663,7 +665,7 @@ static int forward_impl(pcad_handle h, const int32_t* ids, int B, int L, const i
         // ... whose [hi | lo | hi] operand the gating (reverse) scan writes itself where it can (whole walk, unsegmented, L % 8 == 0),
         // instead of fp32 y + a conversion pass
         const bool ys_from_scan = sp && !(e->ref_order == 2 && !c.fold) && !last_short && L % 8 == 0 && e->blocked && e->xzsplit &&
-                                  !(c.w.seg && scan_segments(S, L, E, nullptr) > 1);
+                                  !(c.w.seg && scan_segments(2 * B, L, E, nullptr) > 1);
         auto out_proj_full = [&](const void* ysrc, void* dst) -> hipError_t {
             if (sp) {
                 if (!(ys_from_scan && ysrc == c.w.y))
@@ -683,7 +685,7 @@ static int forward_impl(pcad_handle h, const int32_t* ids, int B, int L, const i
             // dt_proj (on MFMA inside the scan) + bias + softplus + recurrence + D skip + SiLU(z) gate
             for (int rep = 1; rep < (d == 0 ? reps(PCAD_K_SCAN) : 1); ++rep)         // measurement aid: the forward-direction launch is idempotent
                 HIP_TRY(launch_scan(c.w.xc[d], nullptr, e->xzsplit ? E : 2 * E, nullptr, c.w.dtl[d], dts ? 3 * Rp : Rp, dts ? dw.Wdt_s : dw.Wdt, dts ? 3 * Rp : Rp, c.w.bc[d], dw.A2, 1.0f,
-                                    dw.Dskip, dw.dt_bias, c.w.y, S, L, E, false, 0, dt, s, e->blocked, e->xzsplit, c.w.seg, 0, nullptr, dts));
+                                    dw.Dskip, dw.dt_bias, c.w.y, S, L, E, false, 0, dt, s, e->blocked, e->xzsplit, c.w.seg, 0, nullptr, dts, 2 * B));
             ProfScope ps(e, PCAD_K_SCAN, s);
             const void* zp = e->xzsplit ? c.w.zb : (const void*)((const char*)c.w.xz + (size_t)E * esz);
             // gate_once: the forward scan stores its ungated output, the reverse scan adds its own and applies SiLU(z)
@@ -693,7 +695,7 @@ static int forward_impl(pcad_handle h, const int32_t* ids, int B, int L, const i
             HIP_TRY(launch_scan(c.w.xc[d], gated ? zp : nullptr, e->xzsplit ? E : 2 * E, nullptr, c.w.dtl[d], dts ? 3 * Rp : Rp, dts ? dw.Wdt_s : dw.Wdt, dts ? 3 * Rp : Rp,
                                 c.w.bc[d], dw.A2, 1.0f, dw.Dskip, dw.dt_bias, d == 1 ? y_rev : c.w.y, S, L, E, d == 1,
                                 strict ? 0 : (d == 1 ? (e->gate_once ? 2 : 1) : 0), dt, s, e->blocked, e->xzsplit, c.w.seg, last_short ? walk_len : 0,
-                                d == 1 && ys_from_scan ? c.w.ys : nullptr, dts));
+                                d == 1 && ys_from_scan ? c.w.ys : nullptr, dts, 2 * B));
         }
         if (strict) {
             // out = round(out_proj(y_fwd)) + round(out_proj(y_rev)), rounded: BiMambaWrapper's "add" of two Mamba calls that each end
@@ -759,7 +761,7 @@ static int forward_impl(pcad_handle h, const int32_t* ids, int B, int L, const i
         Lane c;
         c.b0 = ck * chunk;
         c.Bc = (B - c.b0) < chunk ? (B - c.b0) : chunk;
-        c.w = carve_workspace(e, workspace, c.Bc, L);
+        c.w = carve_workspace(e, workspace, c.Bc, L, B);
         c.fold = fold_for(c);
         for (int li = 0; li < e->nl; ++li) {
             if (int rc = phase_N(c, li)) return rc;

@@ -533,8 +533,8 @@ int convx_ksplit(int S, int L, int E, int dt) {
     return best;
 }
 
-size_t convx_split_bytes(int S, int L, int E, int dt, int Rp) {
-    const int ks = convx_ksplit(S, L, E, dt);
+size_t convx_split_bytes(int S, int L, int E, int dt, int Rp, int policy_S) {
+    const int ks = convx_ksplit(policy_S > 0 ? policy_S : S, L, E, dt);
     return ks > 1 ? (size_t)ks * 2 * (size_t)S * L * (Rp + 32) * sizeof(float) : 0;
 }
 
@@ -593,7 +593,7 @@ hipError_t launch_pack_convw(const float* wf, const float* bf, const float* wr, 
 
 hipError_t launch_convx(const void* x, const float* convw, const void* Wx0, void* xc0, void* dtl0, float* bc0,
                         const void* Wx1, void* xc1, void* dtl1, float* bc1, int S, int L, int E, int dt, hipStream_t s, int Rp, bool dtl_split,
-                        bool w_split, float* part_ws) {
+                        bool w_split, float* part_ws, int policy_S) {
     if (S <= 0 || L <= 0) return hipSuccess;
     if ((dtl_split || w_split) && dt != F32) return hipErrorInvalidValue;
     const int esz = dt == BF16 ? 2 : 4;
@@ -602,7 +602,7 @@ hipError_t launch_convx(const void* x, const float* convw, const void* Wx0, void
     ConvxDir d0{Wx0, xc0, dtl0, bc0, dtl_split ? 1 : 0}, d1{Wx1, xc1, dtl1, bc1, dtl_split ? 1 : 0};
     const int tiles = S * ((L + CX_ROWS - 1) / CX_ROWS);
     const bool zfill = L % 8 == 0;
-    const int ks = part_ws ? convx_ksplit(S, L, E, dt) : 1;
+    const int ks = part_ws ? convx_ksplit(policy_S > 0 ? policy_S : S, L, E, dt) : 1;
     float* part = ks > 1 ? part_ws : nullptr;
 #define PCAD_CONVX(T, Z, NJ_)                                                                                         \
     do {                                                                                                                \

@@ -106,10 +106,11 @@ hipError_t launch_convx(const void* x, const float* convw, const void* Wx0, void
                         bool dtl_split = false,       // dtl_split (dt == F32): dtl_d is written as bf16 [S*L, 3 Rp] = [hi | lo | hi]
                         bool w_split = false,         // w_split (dt == F32): Wx_d is the bf16 [Rp + 32, 2E] copy of launch_pack_convx_wsplit and
                                                       // x_proj runs as three bf16 MFMA products per fp32 product
-                        float* part_ws = nullptr);    // scratch of convx_split_bytes(): small launches split the channel walk over several
+                        float* part_ws = nullptr,     // scratch of convx_split_bytes(): small launches split the channel walk over several
                                                       // blocks per row tile (convx_ksplit) and a second tiny kernel adds their partial x_dbl
+                        int policy_S = 0);            // strands the K-split policy is evaluated for (0: S; see scan_segment_bytes)
 int convx_ksplit(int S, int L, int E, int dt);        // K-split factor for this launch shape (1: none)
-size_t convx_split_bytes(int S, int L, int E, int dt, int Rp);
+size_t convx_split_bytes(int S, int L, int E, int dt, int Rp, int policy_S = 0);
 hipError_t launch_pack_convx_wsplit(const float* src, int64_t ld, void* dst, int rows, int E, hipStream_t s);
 // dt_rank padded to the K granule of the fused kernels: 64 up to dt_rank 64 (every PlantCaduceus size), else the next multiple of 32
 // (PlantCAD2 Large: dt_rank 96 -> 96)
@@ -130,7 +131,7 @@ hipError_t launch_scan(const void* u, const void* z, int64_t ldz, const void* de
                        const void* Wdt, int Rp, const float* bc, const float* A2, float a_scale, const float* Dskip,
                        const float* dbias, void* y, int S, int L, int E, bool reverse, int accumulate, int dt,
                        hipStream_t s, bool uy_blocked = false, bool z_blocked = false, float* seg_ws = nullptr, int walk_len = 0,
-                       void* ysplit = nullptr, bool dt_split = false);
+                       void* ysplit = nullptr, bool dt_split = false, int policy_S = 0);
 // dt_split (dt == F32, fused dt_proj): dt_low is bf16 [rows, lddt >= Rp] = [hi | lo | hi] and Wdt bf16 [E, Rp] = [hi | hi | lo] with Rp = 3 x
 // the padded dt_rank: the fp32 model's dt_proj as three bf16 MFMA products per fp32 product ("f32_gemm_split").
 // ysplit (fp32 engine layouts only: dt == F32, fused dt_proj, blocked u / y / z, L % 8 == 0; reverse gating launch, unsegmented, whole
@@ -162,8 +163,11 @@ inline int scan_segments(int S, int L, int E, int* seg_blocks) {
     if (seg_blocks) *seg_blocks = sb;
     return G;
 }
-inline size_t scan_segment_bytes(int S, int L, int E) {
-    const int G = scan_segments(S, L, E, nullptr);
+// policy_S (here and in launch_scan / launch_convx; 0: S): the strand count the small-launch policy is evaluated for.  The engine
+// passes the strands of the WHOLE pcad_forward batch, so that every chunk of a call runs the same form and results do not depend on
+// how the batch was cut into chunks, bit for bit; the scratch is sized for the S strands of the launch.
+inline size_t scan_segment_bytes(int S, int L, int E, int policy_S = 0) {
+    const int G = scan_segments(policy_S > 0 ? policy_S : S, L, E, nullptr);
     return G > 1 ? (size_t)S * G * E * 17 * sizeof(float) : 0;        // [S][G][E][16] states + [S][G][E] delta sums
 }
 

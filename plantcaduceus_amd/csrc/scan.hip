@@ -451,14 +451,15 @@ static hipError_t launch_scan_t(const void* u, const void* z, int64_t ldz, const
                                 const void* Wdt, int Rp, const float* bc, const float* A2, float a_scale,
                                 const float* Dskip, const float* dbias, void* y, int S, int L, int E, bool reverse,
                                 int accumulate, hipStream_t s, bool uyb, bool zblk = false, float* seg_ws = nullptr, int walk_len = 0,
-                                void* ysplit = nullptr, bool dt_split = false) {
+                                void* ysplit = nullptr, bool dt_split = false, int policy_S = 0) {
     const int dts = dt_split ? 1 : 0;
+    const int Sp = policy_S > 0 ? policy_S : S;          // strands the segment policy is evaluated for (kernels.hpp scan_segment_bytes)
     dim3 grid((unsigned)(E / 64), (unsigned)S), block(64);
     const bool hz = z != nullptr;
     if (ysplit != nullptr) {
         // out_proj's split-bf16 operand written by the walk itself: the fp32 engine's reverse (gating) launch only
         if constexpr (std::is_same<T, float>::value && FUSED && BLK8 && ZB) {
-            const bool seg = seg_ws && scan_segments(S, L, E, nullptr) > 1;
+            const bool seg = seg_ws && scan_segments(Sp, L, E, nullptr) > 1;
             if (!reverse || !hz || (accumulate != 1 && accumulate != 2) || seg || (walk_len > 0 && walk_len < L)) return hipErrorInvalidValue;
 #define PCAD_SCAN_SPLITY(ACCM)                                                                                                       \
             hipLaunchKernelGGL((scan_kernel<T, true, ACCM, true, FUSED, PRE, BLK8, 0, true, true>), grid, block, 0, s, (const T*)u, (const T*)z, ldz, \
@@ -477,7 +478,7 @@ static hipError_t launch_scan_t(const void* u, const void* z, int64_t ldz, const
     // ---- long strands, few of them: G segments per strand as separate workgroups (pass A, carry, pass B) --------------------
     if constexpr (FUSED) {
         int sb = 0;
-        const int G = seg_ws ? scan_segments(S, L, E, &sb) : 1;
+        const int G = seg_ws ? scan_segments(Sp, L, E, &sb) : 1;
         const bool combo = (!reverse && accumulate == 0) || (reverse && accumulate == 2 && hz) || (reverse && accumulate == 1 && hz) ||
                            (reverse && accumulate == 0 && hz);
         if (G > 1 && combo) {
@@ -513,7 +514,7 @@ static hipError_t launch_scan_t(const void* u, const void* z, int64_t ldz, const
 hipError_t launch_scan(const void* u, const void* z, int64_t ldz, const void* delta, const void* dt_low, int64_t lddt,
                        const void* Wdt, int Rp, const float* bc, const float* A2, float a_scale, const float* Dskip,
                        const float* dbias, void* y, int S, int L, int E, bool reverse, int accumulate, int dt,
-                       hipStream_t s, bool uyb, bool zblk, float* seg_ws, int walk_len, void* ysplit, bool dt_split) {
+                       hipStream_t s, bool uyb, bool zblk, float* seg_ws, int walk_len, void* ysplit, bool dt_split, int policy_S) {
     if (zblk && !uyb) return hipErrorInvalidValue;
     if (dt_split && !(dt == F32 && delta == nullptr && Rp % 16 == 0 && lddt % 8 == 0)) return hipErrorInvalidValue;   // bf16 [hi | lo | hi] x [hi | hi | lo]
     if (ysplit && !(dt == F32 && delta == nullptr && uyb && zblk && L % 8 == 0 && ((int64_t)S * L + 7) / 8 * 8 * 3 * E * 2 < ((int64_t)1 << 32)))
@@ -527,25 +528,25 @@ hipError_t launch_scan(const void* u, const void* z, int64_t ldz, const void* de
     if (fused && (!dt_low || !Wdt || Rp <= 0 || Rp % 32)) return hipErrorInvalidValue;
     if (dt == BF16) {
         if (fused && Rp == 64 && lddt % 8 == 0 && uyb && L % 8 == 0 && zblk)      // the engine's case: every layout known at compile time
-            return launch_scan_t<bf16_t, true, 64, true, true>(u, z, ldz, dt_low, lddt, Wdt, Rp, bc, A2, a_scale, Dskip, dbias, y, S, L, E, reverse, accumulate, s, uyb, zblk, seg_ws, walk_len);
+            return launch_scan_t<bf16_t, true, 64, true, true>(u, z, ldz, dt_low, lddt, Wdt, Rp, bc, A2, a_scale, Dskip, dbias, y, S, L, E, reverse, accumulate, s, uyb, zblk, seg_ws, walk_len, nullptr, false, policy_S);
         static const bool nopre96 = dev_env("PCAD_SCAN_NOPRE96") != nullptr;       // PCAD_DEV=1 A/B: the non-prefetching walk instead
         if (!nopre96 && fused && Rp == 96 && lddt % 8 == 0 && uyb && L % 8 == 0 && zblk)      // the engine's case at dt_rank 65..96 (PlantCAD2 Large)
-            return launch_scan_t<bf16_t, true, 96, true, true>(u, z, ldz, dt_low, lddt, Wdt, Rp, bc, A2, a_scale, Dskip, dbias, y, S, L, E, reverse, accumulate, s, uyb, zblk, seg_ws, walk_len);
+            return launch_scan_t<bf16_t, true, 96, true, true>(u, z, ldz, dt_low, lddt, Wdt, Rp, bc, A2, a_scale, Dskip, dbias, y, S, L, E, reverse, accumulate, s, uyb, zblk, seg_ws, walk_len, nullptr, false, policy_S);
         if (fused && Rp == 64 && lddt % 8 == 0 && uyb && L % 8 == 0)
-            return launch_scan_t<bf16_t, true, 64, true>(u, z, ldz, dt_low, lddt, Wdt, Rp, bc, A2, a_scale, Dskip, dbias, y, S, L, E, reverse, accumulate, s, uyb, zblk, seg_ws, walk_len);
+            return launch_scan_t<bf16_t, true, 64, true>(u, z, ldz, dt_low, lddt, Wdt, Rp, bc, A2, a_scale, Dskip, dbias, y, S, L, E, reverse, accumulate, s, uyb, zblk, seg_ws, walk_len, nullptr, false, policy_S);
         if (fused && Rp == 64 && lddt % 8 == 0)
-            return launch_scan_t<bf16_t, true, 64>(u, z, ldz, dt_low, lddt, Wdt, Rp, bc, A2, a_scale, Dskip, dbias, y, S, L, E, reverse, accumulate, s, uyb, zblk, seg_ws, walk_len);
-        if (fused) return launch_scan_t<bf16_t, true>(u, z, ldz, dt_low, lddt, Wdt, Rp, bc, A2, a_scale, Dskip, dbias, y, S, L, E, reverse, accumulate, s, uyb, zblk, seg_ws, walk_len);
-        return launch_scan_t<bf16_t, false>(u, z, ldz, delta, E, nullptr, 0, bc, A2, a_scale, Dskip, dbias, y, S, L, E, reverse, accumulate, s, uyb, zblk, seg_ws, walk_len);
+            return launch_scan_t<bf16_t, true, 64>(u, z, ldz, dt_low, lddt, Wdt, Rp, bc, A2, a_scale, Dskip, dbias, y, S, L, E, reverse, accumulate, s, uyb, zblk, seg_ws, walk_len, nullptr, false, policy_S);
+        if (fused) return launch_scan_t<bf16_t, true>(u, z, ldz, dt_low, lddt, Wdt, Rp, bc, A2, a_scale, Dskip, dbias, y, S, L, E, reverse, accumulate, s, uyb, zblk, seg_ws, walk_len, nullptr, false, policy_S);
+        return launch_scan_t<bf16_t, false>(u, z, ldz, delta, E, nullptr, 0, bc, A2, a_scale, Dskip, dbias, y, S, L, E, reverse, accumulate, s, uyb, zblk, seg_ws, walk_len, nullptr, false, policy_S);
     }
     // the fp32 engine's case (blocked u / y / z, L % 8 == 0): layouts known at compile time like the bf16 instantiation above (one
     // scalar block offset per 4-step chunk, per-step offsets in the immediates); dt_proj stays on v_mfma_f32_32x32x2_f32, unprefetched
     static const bool f32_generic = dev_env("PCAD_SCAN_F32_GENERIC") != nullptr;       // PCAD_DEV=1 A/B: the run-time-layout instantiation
     if (!f32_generic && fused && uyb && L % 8 == 0 && zblk)
-        return launch_scan_t<float, true, 0, true, true>(u, z, ldz, dt_low, lddt, Wdt, Rp, bc, A2, a_scale, Dskip, dbias, y, S, L, E, reverse, accumulate, s, uyb, zblk, seg_ws, walk_len, ysplit, dt_split);
+        return launch_scan_t<float, true, 0, true, true>(u, z, ldz, dt_low, lddt, Wdt, Rp, bc, A2, a_scale, Dskip, dbias, y, S, L, E, reverse, accumulate, s, uyb, zblk, seg_ws, walk_len, ysplit, dt_split, policy_S);
     if (ysplit) return hipErrorInvalidValue;
-    if (fused) return launch_scan_t<float, true>(u, z, ldz, dt_low, lddt, Wdt, Rp, bc, A2, a_scale, Dskip, dbias, y, S, L, E, reverse, accumulate, s, uyb, zblk, seg_ws, walk_len, nullptr, dt_split);
-    return launch_scan_t<float, false>(u, z, ldz, delta, E, nullptr, 0, bc, A2, a_scale, Dskip, dbias, y, S, L, E, reverse, accumulate, s, uyb, zblk, seg_ws, walk_len);
+    if (fused) return launch_scan_t<float, true>(u, z, ldz, dt_low, lddt, Wdt, Rp, bc, A2, a_scale, Dskip, dbias, y, S, L, E, reverse, accumulate, s, uyb, zblk, seg_ws, walk_len, nullptr, dt_split, policy_S);
+    return launch_scan_t<float, false>(u, z, ldz, delta, E, nullptr, 0, bc, A2, a_scale, Dskip, dbias, y, S, L, E, reverse, accumulate, s, uyb, zblk, seg_ws, walk_len, nullptr, false, policy_S);
 }
 
 }  // namespace pcad
