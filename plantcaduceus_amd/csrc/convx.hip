@@ -21,6 +21,7 @@
 // arithmetic is about half); removing the conv math, the MFMAs or the xc stores from the kernel saves 7 %, 6 % and 16 %.
 // Register pressure is a hard constraint: a spilled value is reloaded by a scratch load that shares vmcnt with the
 // DMAs in flight and drains them (an early version with 19 spilled dwords ran 1.8x slower).
+#include <cstdlib>
 #include <type_traits>
 
 #include "common.hpp"
@@ -526,7 +527,8 @@ int convx_ksplit(int S, int L, int E, int dt) {
     const int KC = CX_ROWB / (dt == BF16 ? 2 : 4);
     const int nkt = E / KC;
     const int64_t tiles = (int64_t)S * ((L + CX_ROWS - 1) / CX_ROWS);
-    if (tiles <= 0 || tiles > 64) return 1;
+    static const int max_tiles = [] { const char* v = dev_env("PCAD_CX_SPLIT_TILES"); return v ? atoi(v) : 64; }();     // PCAD_DEV=1 A/B knob
+    if (tiles <= 0 || tiles > max_tiles) return 1;
     int best = 1;
     for (int ks = 2; ks <= nkt / 2; ++ks)
         if (nkt % ks == 0 && tiles * ks <= 256) best = ks;
