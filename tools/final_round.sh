@@ -7,7 +7,7 @@
 #   cp gpurun_out/<tag>/{bench.json,bench_under_rocprof.json,gpu_tests.log,...} profiles/<tag>_*
 TAG="${1:-final}"
 ROOT="${GRAFT_REPO_ROOT:-$(pwd)}"; O="$ROOT/gpurun_out/$TAG"; mkdir -p "$O"; cd "$ROOT"
-timeout 2000 python3 -m pytest tests -q -m gpu -s 2>&1 | grep -v "^$" | tail -70 > "$O/gpu_tests.log"; tail -3 "$O/gpu_tests.log"
+timeout 2400 python3 -m pytest tests -q -m gpu -s --durations=25 2>&1 | grep -v "^$" | tail -110 > "$O/gpu_tests.log"; tail -3 "$O/gpu_tests.log"
 tools/profile_round.sh "$TAG" > "$O/profile_round.log" 2>&1; tail -2 "$O/profile_round.log"
 tools/kpmc.sh scan_kernel "$TAG" > /dev/null 2>&1
 tools/kpmc.sh convx_kernel "${TAG}_convx" > /dev/null 2>&1

@@ -15,3 +15,7 @@ timeout 600 python3 bench.py --opt reference_order=2 --cpu-seqs 0 > $O/bench_l32
 timeout 600 python tools/argmax_census.py --model l32 --fixture tests/golden/census_l32.npz > $O/argmax_census_l32.txt 2>&1
 timeout 600 python tools/argmax_census.py --model l20 --fixture tests/golden/census_l20.npz --batch 1024 > $O/argmax_census_l20.txt 2>&1
 echo "all done" >> $O/status.txt
+# counters of the staggered-DMA GEMM variant next to the shipped kernel's (kpmc_<tag>_gemm.txt)
+PCAD_ALLOW_STALE=1 PCAD_LIB=$PWD/plantcaduceus_amd/variants/libpcad_stagger.so tools/kpmc.sh gemm256q "${TAG}_gemm_stagger" > /dev/null 2>&1
+python3 -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.txt 2>&1; echo "smoke rc=$?" >> $O/status.txt
+echo "really all done" >> $O/status.txt
