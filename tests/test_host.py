@@ -124,9 +124,12 @@ def test_workspace_limit_option_bounds_the_slab(lib):
     for B in (64, 1024, 5000):
         assert lib.pcad_workspace_bytes(h, B, 512) <= 2048 << 20
     assert lib.pcad_workspace_bytes(h, 1024, 512) > 1024 << 20          # and not needlessly small
-    one = lib.pcad_workspace_bytes(h, 1, 512)
-    assert lib.pcad_set_option(h, b"workspace_limit_mb", 1) == 0
+    assert lib.pcad_set_option(h, b"workspace_limit_mb", 0) == 0 and lib.pcad_set_option(h, b"chunk_seqs", 1) == 0
+    one = lib.pcad_workspace_bytes(h, 1024, 512)                        # one window per chunk (of a 1024-window call)
+    assert lib.pcad_set_option(h, b"chunk_seqs", 0) == 0 and lib.pcad_set_option(h, b"workspace_limit_mb", 1) == 0
     assert lib.pcad_workspace_bytes(h, 1024, 512) == one                # below one window's need: one window per chunk
+    # a one-window CALL additionally carries the scratch of the small-launch forms (segmented scan, conv K-split)
+    assert lib.pcad_workspace_bytes(h, 1, 512) >= one
     assert lib.pcad_set_option(h, b"workspace_limit_mb", 0) == 0 and lib.pcad_workspace_bytes(h, 1024, 512) == full
     assert lib.pcad_set_option(h, b"workspace_limit_mb", -1) == -1
     lib.pcad_destroy(h)
