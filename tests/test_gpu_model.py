@@ -455,3 +455,23 @@ def test_options_that_need_bind_time_copies_are_refused_afterwards():
     m2._engine().set_option("f32_gemm_split", 0)                 # off again: the plain fp32 GEMMs, bit-identical to a plain engine
     assert torch.equal(m2(input_ids=ids).logits.cpu(), ref)
     assert ((a - ref).abs().max() / ref.abs().max()).item() < 1e-5
+
+
+def test_workspace_limit_bounds_the_allocation_without_changing_results():
+    """pcad_set_option("workspace_limit_mb"): the engine's workspace slab stays under the limit (smaller chunks) and the results are
+    the unlimited run's, bit for bit; Engine.release_workspace() frees the slab and the next forward re-allocates it."""
+    cfg = make_config("x", d_model=512, n_layer=2)
+    sd = synthetic_state_dict(cfg, seed=6)
+    ids = rand_ids(24, 256, 8, mask=100).to(DEV)
+    for dtype in (torch.bfloat16, torch.float32):
+        ref_m = build(cfg, sd, dtype)
+        ref = ref_m(input_ids=ids, output_hidden_states=True)
+        full = ref_m._engine()._ws.numel()
+        m = build(cfg, sd, dtype, workspace_limit_mb=48)
+        out = m(input_ids=ids, output_hidden_states=True)
+        eng = m._engine()
+        assert eng._ws.numel() <= (48 << 20) + 256 < full
+        assert torch.equal(out.logits, ref.logits) and torch.equal(out.hidden_states[-1], ref.hidden_states[-1])
+        eng.release_workspace()
+        assert eng._ws is None
+        assert torch.equal(m(input_ids=ids).logits, ref.logits) and eng._ws is not None
