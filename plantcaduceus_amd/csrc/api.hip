@@ -660,22 +660,23 @@ static int forward_impl(pcad_handle h, const int32_t* ids, int B, int L, const i
         const bool dts = sp && e->convx && ((int64_t)rows + 16) * E * esz < ((int64_t)1 << 32);
         // strict reference order ("reference_order" 2; never with norm_fold): the reverse direction's gated output goes to its own
         // tensor (xc[0]: the forward scan, its only reader, has run) and each direction gets its own tied out_proj below
-        // the full-size tied out_proj of one [rows, E] tensor (y, or in the strict order each direction's own): fp32 / bf16 GEMM, or the
-        // split-bf16 form (operand conversion + bf16 GEMM with K' = 3E, fp32 result)
-        // ... whose [hi | lo | hi] operand the gating (reverse) scan writes itself where it can (whole walk, unsegmented, L % 8 == 0),
-        // instead of fp32 y + a conversion pass
-        const bool ys_from_scan = sp && !(e->ref_order == 2 && !c.fold) && !last_short && L % 8 == 0 && e->blocked && e->xzsplit &&
+        const bool strict = e->ref_order == 2 && !c.fold;
+        void* y_rev = strict ? c.w.xc[0] : c.w.y;
+        // "f32_gemm_split": out_proj's [hi | lo | hi] operand is written by the gating (reverse) scan itself where it can (whole walk,
+        // unsegmented, L % 8 == 0, one out_proj for both directions), instead of fp32 y + a conversion pass
+        const bool ys_from_scan = sp && !strict && !last_short && L % 8 == 0 && e->blocked && e->xzsplit &&
                                   !(c.w.seg && scan_segments(2 * B, L, E, nullptr) > 1);
+        // the full-size tied out_proj of one [rows, E] tensor (y, or in the strict order each direction's own): fp32 / bf16 GEMM, or the
+        // split-bf16 form (operand conversion unless the scan wrote it + bf16 GEMM with K' = 3E, fp32 result)
         auto out_proj_full = [&](const void* ysrc, void* dst) -> hipError_t {
             if (sp) {
-                if (!(ys_from_scan && ysrc == c.w.y))
-                if (hipError_t er = launch_split3_rows((const float*)ysrc, E, c.w.ys, rows, E, e->blocked, e->blocked, s)) return er;
+                if (!(ys_from_scan && ysrc == c.w.y)) {
+                    if (hipError_t er = launch_split3_rows((const float*)ysrc, E, c.w.ys, rows, E, e->blocked, e->blocked, s)) return er;
+                }
                 return launch_gemm_nt(c.w.ys, 3 * E, W.W_out_s, 3 * E, dst, D, rows, D, 3 * E, BF16, F32, false, s, e->blocked);
             }
             return launch_gemm_nt(ysrc, E, W.W_out, E, dst, D, rows, D, E, dt, dt, false, s, e->blocked);
         };
-        const bool strict = e->ref_order == 2 && !c.fold;
-        void* y_rev = strict ? c.w.xc[0] : c.w.y;
         for (int d = 0; d < 2; ++d) {
             const DirWeights& dw = W.dir[d];
             // x_proj -> dt_low [rows, Rp] (model dtype, zero padded) and B_t | C_t [rows, 32] (fp32 side output)
