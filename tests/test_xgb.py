@@ -339,3 +339,22 @@ def test_train_cli_on_gpu_from_snapshot(tmp_path, golden_dir, monkeypatch):
     os.remove(out / "seed_42_te_predictions.npz")
     xgb_train.main(["-test", str(paths["te"]), "-model", d, "-output", str(out), "-device", "cuda:0", "-test_only"])
     np.testing.assert_allclose(np.load(out / "seed_42_te_predictions.npz")["predictions"], want, rtol=1e-6)
+
+
+def test_reader_against_a_file_written_by_real_xgboost(tmp_path):
+    """where the `xgboost` package exists (not in the build container: this test skips there), a classifier trained and
+    saved by xgboost itself must load through XGBJsonClassifier and reproduce xgboost's own predict_proba - the reader is otherwise
+    pinned only by hand-built JSON files."""
+    xgb = pytest.importorskip("xgboost")
+    rng = np.random.default_rng(0)
+    X = rng.standard_normal((400, 12)).astype(np.float32)
+    X[rng.random(X.shape) < 0.05] = np.nan                      # missing values take the default direction
+    y = (np.nan_to_num(X[:, 0]) + 0.5 * np.nan_to_num(X[:, 3]) > 0).astype(int)
+    clf = xgb.XGBClassifier(n_estimators=20, max_depth=4, learning_rate=0.3, random_state=1)
+    clf.fit(X, y)
+    path = str(tmp_path / "real.json")
+    clf.save_model(path)
+    mine = xgb_predict.XGBJsonClassifier().load_model(path)
+    want = clf.predict_proba(X)[:, 1]
+    got = xgb_predict.infer_xgboost_model(mine, X)
+    np.testing.assert_allclose(np.asarray(got, dtype=np.float64), want, rtol=0, atol=2e-6)
