@@ -5,8 +5,10 @@ HIP path (through the HF surface / C ABI) against the C oracle port on the same 
               a/c/g/t call on every window, over all 512 positions.
   bf16 model  (what the reference's dtype policy selects on this GPU) against the oracle in its bf16-emulating mode in
               BOTH operation orders — the reference's (each direction's tied out_proj computed and rounded, then summed:
-              `ref_order=True`) and the engine's (out_proj of the sum) — and against the fp32 oracle.  Tolerance on the
-              probabilities 1e-2 (32 layers of bf16 rounding-order noise; measured ~4e-3); the argmax must be exact
+              `ref_order=True`) and the engine's (out_proj of the sum) — and against the fp32 oracle; since round 5 on the
+              first 64 windows of the committed full-depth oracle runs (tests/golden/census_*.npz) instead of 16 / 32 windows
+              run live, which is most of what the suite's time was (tests/test_gpu_census.py counts calls on all 512 / 256).
+              Tolerance on the probabilities 1.2e-2 (32 layers of bf16 rounding-order noise); the argmax must be exact
               wherever the oracle's top-2 margin exceeds twice that tolerance, at least half of the windows must be that
               confident (non-vacuous), and the fraction of ALL windows whose call equals the fp32 oracle's is printed and
               bounded below.
@@ -45,6 +47,23 @@ def softmax4(z):
     return p / p.sum(1, keepdims=True)
 
 
+def census_oracle(size, n):
+    """The first n windows of the committed full-depth oracle runs (tests/golden/census_<size>.npz, oracle/gen_census_golden.py:
+    benchmark checkpoint seed 1234, windows default_rng(0), mask at 255) -> (ids [n, 512], {mode: probabilities [n, 4]}) for the
+    modes f32 / ref (bf16 emulation, reference order) / eng (bf16 emulation, tied out_proj folded).  The same oracle, run once on
+    the GPU box's host instead of inside every GPU test run (each l32 mode costs ~1.3 s per window on 128 threads);
+    tests/test_oracle.py::test_census_fixture_is_not_stale ties the file to the oracle source."""
+    import hashlib
+    import os
+    from oracle.gen_census_golden import census_windows
+    fx = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", f"census_{size}.npz"))
+    ids = census_windows(int(fx["meta"][0]), int(fx["meta"][1]))
+    assert hashlib.sha1(ids.tobytes()).digest() == fx["ids_sha1"].tobytes()
+    probs = {k: softmax4(fx["logits_" + k][:n, 3:7]) for k in ("f32", "ref", "eng")}
+    assert all(len(v) == n for v in probs.values())
+    return ids[:n], probs
+
+
 @pytest.mark.parametrize("size,n", [("l20", 16), ("l32", 16)])
 def test_full_depth_fp32(size, n):
     cfg = make_config(size)
@@ -67,26 +86,21 @@ def test_full_depth_fp32(size, n):
     assert (lg[..., 3:7].argmax(-1)[sure] == lg_ref[..., 3:7].argmax(-1)[sure]).all()
 
 
-@pytest.mark.parametrize("size,n", [("l20", 32), ("l32", 16)])
+@pytest.mark.parametrize("size,n", [("l20", 64), ("l32", 64)])
 def test_full_depth_bf16_both_orders(size, n):
     cfg = make_config(size)
     sd = synthetic_state_dict(cfg, seed=1234, stress=False)   # BASELINE configs 2/3's checkpoint
-    ids = windows(n, 0)
+    ids, orc = census_oracle(size, n)                        # committed oracle runs (round 5; before: 16 / 32 windows run live)
     m = hip_model(cfg, sd, torch.bfloat16)
     lg = m(input_ids=torch.from_numpy(ids).to(DEV), positions=[P]).logits[:, 0].cpu().numpy()
     p_hip = softmax4(lg[:, 3:7])
-
-    def oracle(**kw):
-        return softmax4(oracle_forward((size, 1234, False), sd, cfg, ids, **kw)[0][:, P, 3:7])
-    p_ref = oracle(dtype=torch.bfloat16, emulate_bf16=True, ref_order=True)     # the reference's order
-    p_eng = oracle(dtype=torch.bfloat16, emulate_bf16=True, ref_order=False)    # the engine's order
-    p_f32 = oracle()
+    p_ref, p_eng, p_f32 = orc["ref"], orc["eng"], orc["f32"]   # reference order / tied out_proj folded / fp32
     d_ref, d_eng, d_f32 = (np.abs(p_hip - q).max() for q in (p_ref, p_eng, p_f32))
     d_orders = np.abs(p_ref - p_eng).max()
     agree = {k: float((p_hip.argmax(1) == q.argmax(1)).mean()) for k, q in (("ref", p_ref), ("eng", p_eng), ("f32", p_f32))}
     print(f"{size} bf16 x{n}: max|dp| vs ref-order emulation {d_ref:.2e}, vs engine-order {d_eng:.2e}, vs fp32 {d_f32:.2e}; "
           f"the two emulations differ by {d_orders:.2e}; argmax agreement {agree}")
-    TOL = 1e-2
+    TOL = 1.2e-2        # max over 64 windows (1e-2 held on the 16 / 32 of earlier rounds; over 512 windows the census sees 1.06e-2)
     assert d_ref < TOL and d_eng < TOL
     assert d_f32 < 2 * TOL
     for q in (p_ref, p_eng, p_f32):
@@ -109,14 +123,10 @@ def test_full_depth_bf16_engine_options_against_reference_order():
     All three must stay inside the same 1e-2 bar on the probabilities and make the same confident calls."""
     cfg = make_config("l32")
     sd = synthetic_state_dict(cfg, seed=1234, stress=False)
-    n = 16
-    ids = windows(n, 0)
+    n = 64
+    ids, orc = census_oracle("l32", n)                       # the committed oracle runs test_full_depth_bf16_both_orders uses
     tids = torch.from_numpy(ids).to(DEV)
-
-    def oracle(**kw):       # the same two runs as test_full_depth_bf16_both_orders[l32-16]: shared through the memo
-        return softmax4(oracle_forward(("l32", 1234, False), sd, cfg, ids, **kw)[0][:, P, 3:7])
-    p_ref = oracle(dtype=torch.bfloat16, emulate_bf16=True, ref_order=True)
-    p_eng = oracle(dtype=torch.bfloat16, emulate_bf16=True, ref_order=False)
+    p_ref, p_eng = orc["ref"], orc["eng"]
     floor = np.abs(p_ref - p_eng).max()                      # what reordering alone does to a bf16 restatement
     d = {}
     for name, opts in (("default", dict(norm_fold=0)), ("gate_each", dict(gate_each=1, norm_fold=0)), ("norm_fold", dict(norm_fold=1)),
@@ -129,7 +139,7 @@ def test_full_depth_bf16_engine_options_against_reference_order():
         assert conf.sum() >= n // 2
         assert (p.argmax(1)[conf] == p_ref.argmax(1)[conf]).all(), name
     print(f"l32 bf16 x{n}: max|dp| vs the reference-order emulation {d}; the two emulations differ by {floor:.2e}")
-    assert all(v < 1e-2 for v in d.values())
+    assert all(v < 1.2e-2 for v in d.values())
     assert d["gate_each"] <= d["default"] + floor            # the reference-order option is not further from the reference's order
     assert d["norm_fold"] <= 2 * max(d["default"], floor) + 1e-3
 
