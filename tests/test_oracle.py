@@ -206,3 +206,21 @@ def test_census_fixture_is_not_stale(golden_dir):
     lg = COracle(sd, cfg, blas=True).forward(ids[:1])[0][:, P, :]
     ref = fx["logits_f32"][:1]
     assert np.abs(lg - ref).max() / np.abs(ref).max() < 1e-5
+
+
+def test_census_helpers_count_calls_and_margins():
+    """tools/argmax_census.py `compare` / `margins` (what tests/test_gpu_census.py asserts on): indices of differing 4-way calls,
+    the ORACLE's top-2 margin at those windows, max |dp| - on a hand-built case."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("argmax_census", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "argmax_census.py"))
+    ac = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ac)
+    q = np.array([[0.40, 0.30, 0.20, 0.10], [0.26, 0.25, 0.25, 0.24], [0.10, 0.20, 0.30, 0.40]])
+    p = np.array([[0.39, 0.31, 0.20, 0.10], [0.25, 0.27, 0.24, 0.24], [0.10, 0.20, 0.30, 0.40]])
+    c = ac.compare(p, q)
+    assert c["n"] == 3 and c["flips"].tolist() == [1] and abs(c["max_dp"] - 0.02) < 1e-12
+    np.testing.assert_allclose(c["flip_margins"], [0.01])
+    np.testing.assert_allclose(ac.margins(q), [0.10, 0.01, 0.10])
+    np.testing.assert_allclose(ac.softmax4(np.log(q)), q, rtol=1e-12)
+    assert ac.compare(p[:2], q)["n"] == 2                      # the shorter run decides
