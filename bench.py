@@ -49,6 +49,72 @@ CYC_PK = 0.5 * (CYC_PK_MUL + CYC_PK_FMA)
 CYC_PAIR_MIX = 34.16
 SIMDS, CLOCK = 1024, 2.4e9
 CPU_REPEATS = 2                            # timed runs of the CPU baseline after one warm-up run (value = best, value_median beside it)
+CPU_MIN_SEQS = 16                          # windows of the CPU baseline's sample (>= 16: every operator of the port has work for all cores)
+CPU_BUDGET_S = 30.0                        # warm-up + timed runs of the CPU baseline stay inside this; the 2nd repeat is dropped if it would not fit
+PARITY_STEPS, PARITY_WARMUP = 3, 1         # the parity_config leg (fp32 model with f32_gemm_split) of the default run
+
+
+def host_peak_from_cpuinfo(cpuinfo: str, max_khz=None):
+    """Nominal fp32 peak of the host from /proc/cpuinfo text: physical cores x FMA lanes x 2 flop x 2 FMA ports x clock.
+    Lanes from the ISA flags (avx512f: 16, avx2/fma: 8, else 4 without FMA -> 1 flop per lane and port); clock = max_khz
+    (cpufreq's cpuinfo_max_freq) when given, else the largest 'cpu MHz' line, else the 'model name ... @ x.xxGHz' figure.
+    An ESTIMATE for orientation (real chips clock down under AVX-512 and may have one 512-bit port): the CPU baseline is
+    reported as a fraction of it so that a number two orders below the host's capability says so itself."""
+    import re
+    cores, phys, core, mhz, flags, ghz_name, threads = set(), None, None, [], "", None, 0
+    for line in cpuinfo.splitlines():
+        k, _, v = line.partition(":")
+        k, v = k.strip(), v.strip()
+        if k == "processor":
+            threads += 1
+        elif k == "physical id":
+            phys = v
+        elif k == "core id":
+            core = v
+            cores.add((phys, core))
+        elif k == "cpu MHz":
+            try:
+                mhz.append(float(v))
+            except ValueError:
+                pass
+        elif k == "flags" and not flags:
+            flags = " " + v + " "
+        elif k == "model name" and ghz_name is None:
+            m = re.search(r"@\s*([0-9.]+)\s*GHz", v)
+            if m:
+                ghz_name = float(m.group(1))
+    ncores = len(cores) if cores else max(1, threads)
+    if " avx512f " in flags:
+        lanes, fma, isa = 16, 2, "avx512f"
+    elif " avx2 " in flags or " fma " in flags:
+        lanes, fma, isa = 8, 2, "avx2+fma"
+    else:
+        lanes, fma, isa = 4, 1, "sse"
+    if max_khz:
+        ghz, src = max_khz / 1e6, "cpufreq cpuinfo_max_freq"
+    elif mhz:
+        ghz, src = max(mhz) / 1e3, "largest 'cpu MHz' in /proc/cpuinfo"
+    elif ghz_name:
+        ghz, src = ghz_name, "model name"
+    else:
+        ghz, src = 2.0, "assumed"
+    ports = 2
+    gflops = ncores * lanes * fma * ports * ghz
+    return {"physical_cores": ncores, "threads": threads or ncores, "isa": isa, "clock_GHz": round(ghz, 3), "clock_source": src,
+            "flop_per_cycle_per_core": lanes * fma * ports, "host_peak_gflops_est": gflops}
+
+
+def host_peak_estimate():
+    try:
+        txt = open("/proc/cpuinfo").read()
+    except OSError:
+        txt = ""
+    khz = None
+    try:
+        khz = float(open("/sys/devices/system/cpu/cpu0/cpufreq/cpuinfo_max_freq").read())
+    except (OSError, ValueError):
+        pass
+    return host_peak_from_cpuinfo(txt, khz)
 
 
 def parse():
@@ -61,7 +127,10 @@ def parse():
     ap.add_argument("--batch", type=int, default=1024, help="512-bp windows (ism: masked forwards) per GPU per step")
     ap.add_argument("--seqlen", type=int, default=512)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
-    ap.add_argument("--cpu-seqs", type=int, default=-1, help="sample size for the CPU baseline (0 = skip)")
+    ap.add_argument("--cpu-seqs", type=int, default=-1, help="sample size for the CPU baseline (0 = skip; -1 = %d windows)" % CPU_MIN_SEQS)
+    ap.add_argument("--no-parity-leg", action="store_true",
+                    help="skip the parity_config leg (the fp32 model with f32_gemm_split = the configuration that meets north_star's "
+                         "1e-4 / exact-argmax clause, timed for a few steps on the same windows after the headline's timed region)")
     ap.add_argument("--chunk-seqs", type=int, default=0, help="pcad_set_option chunk_seqs (0 = engine default)")
     ap.add_argument("--opt", action="append", default=[], metavar="KEY=VALUE", help="extra pcad_set_option, e.g. scan_segments=0")
     ap.add_argument("--no-profile", action="store_true")
@@ -465,7 +534,7 @@ def main():
                                      "rows, the scans beyond the furthest evaluated row: %.2f %% of the flops), x windows / timed wall clock"
                                      % (100.0 * fl_skip / fl_seq)}
         res["box"] = box
-        chunk_max = max(1, ((((1 << 32) - (2 << 20)) // (cfg.d_inner * (6 if split else esz))) & ~7) // (2 * L))   # as api.hip chunk_row_limit
+        chunk_max = max(1, ((((1 << 32) - (2 << 20)) // (cfg.d_inner * esz)) & ~7) // (2 * L))   # as api.hip chunk_row_limit
         if args.chunk_seqs:
             chunk_max = args.chunk_seqs
         elif os.environ.get("PCAD_DEV") == "1" and os.environ.get("PCAD_CHUNK_SEQS"):
@@ -558,32 +627,46 @@ def main():
             res["kernels"] = kern
         # ---- host-CPU baseline: the oracle port, same model / same kind of input, bounded sample ------
         ncpu = args.cpu_seqs if world == 1 else 0                 # reported at N=1 only
+        cpu_logits = None                                          # oracle logits [ncpu, 8] at the evaluated position (parity leg's checker)
         if ncpu != 0:
             try:
                 from oracle.c_oracle import COracle
                 co = COracle(sd, cfg, blas=True)
                 threads = co.threads
                 if ncpu < 0:
-                    ncpu = max(2, threads // 16)                  # bounded: warm-up + CPU_REPEATS runs stay within ~30 s of all-core work
+                    ncpu = min(B, CPU_MIN_SEQS)
                 sample = ids_np[:ncpu]
+                t_leg = time.perf_counter()
                 t1 = time.perf_counter()
                 co.forward(ids_np[:1])                            # warm-up: OpenMP team, BLAS threads, first touch of the buffers
                 t_warm = time.perf_counter() - t1
                 times = []
-                for _ in range(CPU_REPEATS):
+                for rep in range(CPU_REPEATS):
+                    # bounded: a repeat is only started if it fits the budget by the previous one's duration
+                    if rep and (time.perf_counter() - t_leg) + times[-1] > CPU_BUDGET_S:
+                        break
                     t1 = time.perf_counter()
                     lg, hd = co.forward(sample, want_hidden=args.workload == "embed")
                     times.append(time.perf_counter() - t1)
                 import statistics
                 tc, tmed = min(times), statistics.median(times)
+                hp = host_peak_estimate()
+                gf = fl_seq * ncpu / tc / 1e9
                 res["cpu_baseline"] = {"value": ncpu / tc, "unit": "sequences/s", "cores": threads, "kind": "port",
                                        "value_median": ncpu / tmed, "repeats": len(times), "run_s": [round(t, 2) for t in times],
                                        "warmup_s": round(t_warm, 2),
-                                       "GFLOP/s": fl_seq * ncpu / tc / 1e9,
+                                       "GFLOP/s": gf,
+                                       "host_peak_gflops_est": round(hp["host_peak_gflops_est"], 1),
+                                       "frac_of_host_peak": gf / hp["host_peak_gflops_est"],
+                                       "host": hp,
                                        "sample": "%d of the same synthetic %d-bp windows, PlantCaduceus_%s fp32, oracle/c "
                                                  "(C + OpenMP norm/conv/scan on all cores, the four projections through the "
-                                                 "host BLAS sgemm via numpy): one 1-window warm-up run, then %d timed runs; value = "
-                                                 "best (%.1f s), value_median = median" % (ncpu, L, args.model, len(times), tc)}
+                                                 "host BLAS sgemm via numpy): one 1-window warm-up run, then %d timed run(s) inside a "
+                                                 "%.0f s budget; value = best (%.1f s), value_median = median.  A scalar-source port: "
+                                                 "%.0f GFLOP/s = %.1f %% of this host's nominal fp32 peak (%d cores x %d flop/cycle x "
+                                                 "%.2f GHz = %.0f GFLOP/s, an estimate) - a stated baseline, not a tuned CPU implementation"
+                                                 % (ncpu, L, args.model, len(times), CPU_BUDGET_S, tc, gf, 100.0 * gf / hp["host_peak_gflops_est"],
+                                                    hp["physical_cores"], hp["flop_per_cycle_per_core"], hp["clock_GHz"], hp["host_peak_gflops_est"])}
                 # cross-check while we are here: GPU result vs the CPU port on the sample
                 gp = out[:ncpu].float().cpu().numpy()
                 if args.workload == "embed":
@@ -591,18 +674,59 @@ def main():
                     cp = (e[:, :D] + e[:, D:][:, ::-1]) / 2
                     res["cpu_baseline"]["max_rel_diff"] = float(np.abs(gp - cp).max() / np.abs(cp).max())
                 else:
-                    cp = lg[np.arange(ncpu), pos_np[:ncpu] if pos_np is not None else p][:, 3:7]
+                    cpu_logits = lg[np.arange(ncpu), pos_np[:ncpu] if pos_np is not None else p]
+                    cp = cpu_logits[:, 3:7]
                     res["cpu_baseline"]["argmax_agree"] = float((gp.argmax(1) == cp.argmax(1)).mean())
-                # the plain-C GEMM variant of the same port (no BLAS), on a smaller sample
-                n2 = max(2, ncpu // 2)
-                t1 = time.perf_counter()
-                COracle(sd, cfg).forward(ids_np[:n2])
-                t2 = time.perf_counter() - t1
-                res["cpu_baseline"]["plain_c"] = {"value": n2 / t2, "GFLOP/s": fl_seq * n2 / t2 / 1e9,
-                                                  "sample": "%d windows, plain-C blocked GEMM loops instead of BLAS, %.1f s" % (n2, t2)}
             except Exception as ex:   # the baseline is a reported extra; never lose the bench line over it
                 res["cpu_baseline"] = {"value": None, "unit": "sequences/s", "cores": os.cpu_count(), "kind": "port",
                                        "sample": "failed: %r" % (ex,)}
+        # ---- parity_config: the configuration that meets north_star's accuracy clause, on the driver's record -------------------
+        # The headline is the bf16 model (what the reference's dtype rule selects on this GPU: src/zero_shot_score.py:69-85); bf16
+        # storage cannot meet "<= 1e-4 rel on logits".  The fp32 model with "f32_gemm_split" (projections as three bf16 MFMA products per
+        # fp32 product) does; it is timed here for a few steps on the SAME windows, after the headline's timed region, and its
+        # logits are compared with the CPU oracle's on the cpu_baseline sample.  The bf16 engine is released first.
+        if (world == 1 and not dist_on and not args.no_parity_leg and args.workload == "zeroshot"
+                and not (args.dtype == "f32" and split)):
+            try:
+                eng.close()
+                eng = None
+                torch.cuda.empty_cache()
+                cfg2 = make_config(args.model)
+                popts = {"f32_gemm_split": 1}
+                cfg2.engine_options = dict(popts)
+                eng2 = Engine(cfg2, sd, torch.float32, device)
+
+                def pstep():
+                    return eng2.forward(ids, positions=[p], want_logits=True)[0]
+
+                for _ in range(PARITY_WARMUP):
+                    plog = pstep()
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(PARITY_STEPS):
+                    plog = pstep()
+                torch.cuda.synchronize()
+                tp = time.perf_counter() - t1
+                eng2.check_status()
+                pl = plog[:, 0, :].float().cpu().numpy()
+                pc = {"dtype": "f32", "engine_options": popts, "value": B * PARITY_STEPS / tp, "unit": "sequences/s",
+                      "ms_per_step": 1e3 * tp / PARITY_STEPS, "steps": PARITY_STEPS, "warmup": PARITY_WARMUP, "batch_per_gpu": B,
+                      "max_rel_err_vs_cpu_sample": None, "argmax_agree": None,
+                      "note": "PlantCaduceus_%s fp32 weights / activations, in_proj / out_proj / x_proj / dt_proj as split-bf16 MFMA "
+                              "products (three per fp32 product, fp32 accumulation); same %d windows as the headline, timed after it; "
+                              "max_rel_err = max |logits - oracle| / max |oracle| over the 8 vocabulary logits at the masked index of the "
+                              "cpu_baseline sample (oracle/c fp32); argmax over a,c,g,t" % (args.model, B)}
+                if cpu_logits is not None:
+                    n = cpu_logits.shape[0]
+                    pc["max_rel_err_vs_cpu_sample"] = float(np.abs(pl[:n] - cpu_logits).max() / np.abs(cpu_logits).max())
+                    pc["argmax_agree"] = float((pl[:n, 3:7].argmax(1) == cpu_logits[:, 3:7].argmax(1)).mean())
+                    pc["sample_windows"] = int(n)
+                    # the headline (bf16) run against the same oracle rows, for the contrast the leg exists to show
+                    pc["headline_dtype_argmax_agree"] = res.get("cpu_baseline", {}).get("argmax_agree")
+                res["parity_config"] = pc
+                eng2.close()
+            except Exception as ex:
+                res["parity_config"] = {"value": None, "failed": repr(ex)}
         nh = args.host_seqs if world == 1 else 0
         if nh != 0:
             try:

@@ -122,10 +122,12 @@ void   pcad_destroy(pcad_handle h);
  *                 as split-bf16 GEMMs (pcad_gemm_nt_split below: three bf16 products per fp32 product, fp32 accumulation and
  *                 result); everything else of the fp32 model is unchanged.  Measured 4e-7 of the logits' range against the fp32
  *                 oracle after 32 layers (the plain fp32 GEMMs: 1e-6), arg-max exact - inside north_star's 1e-4 - at about twice
- *                 the fp32 model's speed.  0 (default): fp32 MFMA.  Needs [hi | hi | lo] weight copies (+1.5x the two weights) packed
- *                 at bind time: set it before pcad_weight_arena_bytes / pcad_bind_weights.  Ignored by the bf16 model and while
- *                 "norm_fold" 1 is forced.  Chunks are capped at (2^32 - 2 MiB) / (6 d_inner) token-rows (out_proj's 3 d_inner-wide
- *                 bf16 operand).
+ *                 the fp32 model's speed.  0 (default): fp32 MFMA.  Needs bf16 [hi | lo] weight copies (the size of the fp32 weights
+ *                 again) packed at bind time: set it before pcad_weight_arena_bytes / pcad_bind_weights.  Ignored by the bf16 model
+ *                 and while "norm_fold" 1 is forced.  Operands are stored once as [hi | lo] (the byte size of the fp32 tensor) and
+ *                 the GEMMs' K-tile cursor wraps around them (hi.hi, lo.hi, hi.lo), so the chunk cap is the fp32 model's own,
+ *                 (2^32 - 2 MiB) / (4 d_inner) token-rows.  "last_layer_shortcut" runs the evaluated rows through the same
+ *                 split-bf16 product (bit-identical to the full layer).
  *   "reference_order"  one switch over the options above, for users who want every rounding point where the reference has it
  *                 (BiMambaWrapper "add" of two Mamba calls, rms_norm_fn(prenorm=True, residual_in_fp32=True), mamba_inner_fn):
  *                 0 (default): the engine's defaults ("gate_each" 0, "norm_fold" default, layer 0's in_proj as a table);
@@ -290,8 +292,9 @@ int pcad_gemm_nt(const void* A, int64_t lda, const void* W, int64_t ldw, void* C
 
 /* F.linear(a, w) of fp32 tensors on the bf16 matrix pipes - the form the fp32 model's in_proj / out_proj take with
  * pcad_set_option("f32_gemm_split", 1): each operand is carried as two bf16 values (hi = bf16(v), lo = bf16(v - hi): 16 mantissa
- * bits) and C = A_hi W_hi^T + A_lo W_hi^T + A_hi W_lo^T is ONE bf16 GEMM with K' = 3 K on [hi | lo | hi] x [hi | hi | lo] operands,
- * fp32 accumulation, fp32 result (3/16 of the fp32-MFMA cost per flop; operand error 2^-17, dropped term 2^-16 relative).
+ * bits) and C = A_hi W_hi^T + A_lo W_hi^T + A_hi W_lo^T is ONE bf16 GEMM of 3 K / 64 K-tiles whose cursor wraps around operands
+ * stored once as [hi | lo] (A: hi, lo, hi;  W: hi, hi, lo), fp32 accumulation in that order, fp32 result (3/16 of the fp32-MFMA
+ * cost per flop; operand error 2^-17, dropped term 2^-16 relative).
  *   A [M, K] (lda), W [N, K] (ldw), C [M, N] (ldc) fp32, K % 64 == 0; scratch: device buffer of
  *   pcad_gemm_nt_split_scratch_bytes(M, N, K) bytes (the split operands; the engine keeps the weights' split copy in its arena). */
 size_t pcad_gemm_nt_split_scratch_bytes(int64_t M, int N, int K);

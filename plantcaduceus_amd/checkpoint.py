@@ -170,6 +170,75 @@ def load_state_dict(path: str) -> Dict[str, torch.Tensor]:
     return sd
 
 
+def expected_keys(config: CaduceusConfig) -> Dict[str, tuple]:
+    """name -> shape of every tensor `CaduceusForMaskedLM` of this configuration holds (module tree of reference
+    notebooks/examples.ipynb:61-100; SURVEY.md §8a "State-dict key names")."""
+    D, E, N, R, W, V = (config.d_model, config.d_inner, config.d_state, config.dt_rank, config.d_conv, config.padded_vocab_size)
+    exp = {EMB_KEY: (V, D), NORMF_KEY: (D,), LMHEAD_KEY: (V, D)}
+    for i in range(config.n_layer):
+        exp[norm_key(i)] = (D,)
+        for d in ("fwd", "rev"):
+            k = layer_keys(i, d)
+            exp.update({k["in_proj"]: (2 * E, D), k["conv_w"]: (E, 1, W), k["conv_b"]: (E,), k["x_proj"]: (R + 2 * N, E),
+                        k["dt_w"]: (E, R), k["dt_b"]: (E,), k["A_log"]: (E, N), k["D"]: (E,), k["out_proj"]: (D, E)})
+    return exp
+
+
+def audit_snapshot(path: str, strict: bool = True) -> dict:
+    """Everything a hub snapshot directory must satisfy for this implementation to reproduce the reference on it, checked without
+    a GPU: config.json keys (configuration_caduceus.audit_config_dict: unknown keys fail), the configuration is one the engine
+    implements, every tensor of the module tree is present with the right shape, tensors the forward does not read are listed
+    (only `...complement_map` buffers are expected among them), the tied pairs really are tied (lm_head = embedding; mamba_rev
+    in_proj / out_proj = mamba_fwd's) where the file stores both.  -> report dict; problems raise ValueError when strict."""
+    from .configuration_caduceus import audit_config_dict, config_from_dict
+    with open(os.path.join(path, "config.json")) as f:
+        raw = json.load(f)
+    rep = {"config_keys": audit_config_dict(raw), "problems": []}
+    cfg = config_from_dict(raw, strict=False)
+    bad_keys = rep["config_keys"]["unknown"] + ["ssm_cfg." + k for k in rep["config_keys"]["ssm_unknown"]]
+    if bad_keys:
+        rep["problems"].append("config.json keys this implementation would ignore: %s" % bad_keys)
+    try:
+        cfg.check_supported()
+    except ValueError as e:
+        rep["problems"].append(str(e))
+    rep["geometry"] = dict(d_model=cfg.d_model, n_layer=cfg.n_layer, d_inner=cfg.d_inner, d_state=cfg.d_state, dt_rank=cfg.dt_rank,
+                           vocab=cfg.padded_vocab_size, norm_epsilon=cfg.norm_epsilon, residual_in_fp32=bool(cfg.residual_in_fp32))
+    # the raw file contents (before load_state_dict restores the tied keys), so that stored duplicates can be compared
+    sd = load_state_dict(path)
+    exp = expected_keys(cfg)
+    missing = [k for k in exp if k not in sd]
+    wrong = [(k, tuple(sd[k].shape), exp[k]) for k in exp if k in sd and tuple(sd[k].shape) != tuple(exp[k])]
+    extra = [k for k in sd if k not in exp]
+    unexpected = [k for k in extra if not k.endswith("complement_map")]
+    if missing:
+        rep["problems"].append("missing tensors: %s%s" % (missing[:4], " ..." if len(missing) > 4 else ""))
+    if wrong:
+        rep["problems"].append("shape mismatches (name, file, expected): %s" % wrong[:4])
+    if unexpected:
+        rep["problems"].append("tensors the forward does not read: %s%s" % (unexpected[:4], " ..." if len(unexpected) > 4 else ""))
+    untied = []
+    if not missing and not wrong:
+        if not torch.equal(sd[LMHEAD_KEY], sd[EMB_KEY]):
+            untied.append(LMHEAD_KEY)
+        for i in range(cfg.n_layer):
+            f, r = layer_keys(i, "fwd"), layer_keys(i, "rev")
+            for nm in ("in_proj", "out_proj"):
+                if not torch.equal(sd[f[nm]], sd[r[nm]]):
+                    untied.append(r[nm])
+        cm = [k for k in extra if k.endswith("complement_map")]
+        for k in cm:
+            got = [int(v) for v in sd[k].flatten().tolist()]
+            if got != cfg.complement_list()[:len(got)]:
+                rep["problems"].append("%s = %s differs from config.complement_map -> %s" % (k, got, cfg.complement_list()))
+    if untied:
+        rep["problems"].append("tied tensors stored with different values (the engine reads the first of each pair): %s" % untied[:4])
+    rep["tensors"] = dict(expected=len(exp), in_file=len(sd), extra=extra[:8], dtypes=sorted({str(v.dtype) for v in sd.values()}))
+    if strict and rep["problems"]:
+        raise ValueError("snapshot %s does not pass the audit:\n  - " % path + "\n  - ".join(rep["problems"]))
+    return rep
+
+
 def make_synthetic_checkpoint(path: str, size: str = "l20", seed: int = 1234, stress: bool = True, **overrides):
     cfg = make_config(size, **overrides)
     sd = synthetic_state_dict(cfg, seed=seed, stress=stress)

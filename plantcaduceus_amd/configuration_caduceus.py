@@ -123,6 +123,70 @@ class CaduceusConfig(PretrainedConfig):
             raise ValueError("unsupported Caduceus configuration for the MI355X engine: " + "; ".join(bad))
 
 
+# ---- config.json audit (tools/real_weights.sh; CaduceusForMaskedLM.from_pretrained warns with it) ----------------------------------
+# Keys of a hub snapshot's config.json, by what this implementation does with them.  PretrainedConfig accepts ANY keyword and
+# stores it as an attribute, so a key this forward would need to honour but does not know would be ignored silently: the audit
+# names every key and `config_from_dict(strict=True)` refuses the unknown ones.
+_CONSUMED_KEYS = ("d_model", "n_layer", "vocab_size", "ssm_cfg", "rms_norm", "residual_in_fp32", "fused_add_norm",
+                  "pad_vocab_size_multiple", "norm_epsilon", "initializer_cfg", "bidirectional", "bidirectional_strategy",
+                  "bidirectional_weight_tie", "rcps", "complement_map")
+# written by save_pretrained / the hub machinery; no effect on the arithmetic of the forward
+_BOOKKEEPING_KEYS = ("architectures", "auto_map", "model_type", "torch_dtype", "dtype", "transformers_version", "_name_or_path",
+                     "_commit_hash", "_attn_implementation_autoset", "tokenizer_class", "name_or_path")
+# mamba_ssm.Mamba keyword arguments (mamba-ssm 2.2.2): the first group shapes the forward and is read here; the second only
+# initialises parameters (training) or picks among numerically equivalent code paths
+# attributes transformers 4.x's PretrainedConfig (the reference pins 4.40.0, env/requirements.txt:8) may serialise beyond the installed version's
+_HF_GENERIC_4X = ("return_dict", "output_hidden_states", "output_attentions", "torchscript", "use_bfloat16", "tf_legacy_loss",
+                  "pruned_heads", "tie_word_embeddings", "chunk_size_feed_forward", "is_encoder_decoder", "is_decoder",
+                  "cross_attention_hidden_size", "add_cross_attention", "tie_encoder_decoder", "max_length", "min_length",
+                  "do_sample", "early_stopping", "num_beams", "num_beam_groups", "diversity_penalty", "temperature", "top_k",
+                  "top_p", "typical_p", "repetition_penalty", "length_penalty", "no_repeat_ngram_size",
+                  "encoder_no_repeat_ngram_size", "bad_words_ids", "num_return_sequences", "output_scores",
+                  "return_dict_in_generate", "forced_bos_token_id", "forced_eos_token_id", "remove_invalid_values",
+                  "exponential_decay_length_penalty", "suppress_tokens", "begin_suppress_tokens", "finetuning_task", "id2label",
+                  "label2id", "prefix", "bos_token_id", "pad_token_id", "eos_token_id", "sep_token_id",
+                  "decoder_start_token_id", "task_specific_params", "problem_type")
+_SSM_FORWARD_KEYS = ("d_state", "d_conv", "expand", "dt_rank", "conv_bias", "bias")
+_SSM_INIT_KEYS = ("dt_min", "dt_max", "dt_init", "dt_scale", "dt_init_floor", "use_fast_path", "layer_idx", "device", "dtype")
+
+
+def audit_config_dict(raw: dict) -> dict:
+    """-> {"consumed": [...], "bookkeeping": [...], "hf_generic": [...], "unknown": [...], "ssm_unknown": [...]} for the keys of a
+    config.json.  hf_generic = attributes every PretrainedConfig serialises (return_dict, id2label, ...), which the masked-LM forward
+    does not read."""
+    generic = set(PretrainedConfig().to_dict().keys()) | set(_HF_GENERIC_4X)
+    out = {"consumed": [], "bookkeeping": [], "hf_generic": [], "unknown": [], "ssm_unknown": []}
+    for k in raw:
+        if k in _CONSUMED_KEYS:
+            out["consumed"].append(k)
+        elif k in _BOOKKEEPING_KEYS:
+            out["bookkeeping"].append(k)
+        elif k in generic:
+            out["hf_generic"].append(k)
+        else:
+            out["unknown"].append(k)
+    for k in (raw.get("ssm_cfg") or {}):
+        if k not in _SSM_FORWARD_KEYS and k not in _SSM_INIT_KEYS:
+            out["ssm_unknown"].append(k)
+    return out
+
+
+def config_from_dict(raw: dict, strict: bool = False) -> "CaduceusConfig":
+    """CaduceusConfig from the dict of a snapshot's config.json.  Unknown keys (top level or inside ssm_cfg) raise with strict=True
+    and are logged as a warning otherwise; bookkeeping keys are dropped; the configuration must be one the engine implements."""
+    import logging
+    rep = audit_config_dict(raw)
+    bad = rep["unknown"] + ["ssm_cfg." + k for k in rep["ssm_unknown"]]
+    if bad:
+        msg = ("config.json holds keys this implementation does not know and would ignore: %s (known: %s; ssm_cfg: %s)"
+               % (bad, list(_CONSUMED_KEYS), list(_SSM_FORWARD_KEYS + _SSM_INIT_KEYS)))
+        if strict:
+            raise ValueError(msg)
+        logging.warning(msg)
+    kw = {k: v for k, v in raw.items() if k not in _BOOKKEEPING_KEYS}
+    return CaduceusConfig(**kw)
+
+
 # Published PlantCaduceus sizes (reference README.md:58-63); l20 dims confirmed by
 # notebooks/examples.ipynb:66,74-79.  Used only to build synthetic checkpoints.
 PLANTCADUCEUS_SIZES = {

@@ -46,7 +46,7 @@ struct DirWeights {
     void* Wx;                 // [XP, E] dtype
     void* Wx_s;               // [XP, 2E] bf16, per 32-channel K-tile [hi | lo] ("f32_gemm_split": x_proj inside the fused conv kernel), else nullptr
     void* Wdt;                // [E, Rp] dtype
-    void* Wdt_s;              // [E, 3 Rp] bf16 = [hi | hi | lo] of Wdt ("f32_gemm_split": the fp32 model's dt_proj on the bf16 pipes), else nullptr
+    void* Wdt_s;              // [E, 2 Rp] bf16 = [hi | lo] of Wdt ("f32_gemm_split": the fp32 model's dt_proj on the bf16 pipes), else nullptr
     float *dt_bias, *A2, *Dskip;
 };
 
@@ -57,8 +57,8 @@ struct LayerWeights {
     void* W_in_f;    // [2E, D] = W_in . diag(norm_w), rounded once from the source precision: in_proj of the norm-folded form
     void* W_out;     // [D, E]
     void* W_out_p;   // [Dp, E]: W_out with zero rows up to Dp = round_up(D, 256) for the folded out_proj (== W_out when D % 256 == 0)
-    void* W_in_s;    // [2E, 3D] bf16 = [hi | hi | lo] of W_in: split-bf16 in_proj of the fp32 model ("f32_gemm_split"), else nullptr
-    void* W_out_s;   // [D, 3E] bf16 = [hi | hi | lo] of W_out
+    void* W_in_s;    // [2E, 2D] bf16 = [hi | lo] of W_in: split-bf16 in_proj of the fp32 model ("f32_gemm_split"), else nullptr
+    void* W_out_s;   // [D, 2E] bf16 = [hi | lo] of W_out
     DirWeights dir[2];
 };
 
@@ -84,7 +84,7 @@ struct pcad_engine {
     bool bound = false;
     int64_t ws_limit = 0;       // pcad_set_option("workspace_limit_mb"): chunks are sized so that the workspace stays below it (0: no limit)
     bool f32_split = false;     // pcad_set_option("f32_gemm_split", 1): the fp32 model's in_proj / out_proj as split-bf16 GEMMs (split_wanted)
-    bool split_packed = false;  // ... and their [hi | hi | lo] weight copies exist in the arena (decided like fold_packed)
+    bool split_packed = false;  // ... and their [hi | lo] weight copies exist in the arena (decided like fold_packed)
     bool fold_packed = false;   // the norm-folded form's extra weight copies (W_in_f, xz_tab0, padded W_out) exist in the arena: decided
                                 // from the options in force when pcad_weight_arena_bytes / pcad_bind_weights run (fold_wanted)
     int32_t* status = nullptr;   // caller-owned device word for asynchronous input-validation flags (pcad_set_status_buffer)
@@ -130,9 +130,9 @@ bool split_wanted(const pcad_engine* e) {
 }
 
 // token-rows per pass through the layer stack: the kernels address their tensors with unsigned 32-bit byte offsets; the widest
-// per-row tensor is E * esz bytes (x, z, xc, y) - or, with the split-bf16 GEMMs, the 3 E bf16 columns of out_proj's operand
+// per-row tensor is E * esz bytes (x, z, xc, y; with the split-bf16 GEMMs out_proj's operand is 2 E bf16 columns = the same 4 E bytes)
 int64_t chunk_row_limit(const pcad_engine* e) {
-    const int64_t per_row = split_wanted(e) ? (int64_t)e->E * 6 : (int64_t)e->E * e->esz;
+    const int64_t per_row = (int64_t)e->E * e->esz;
     return ((((int64_t)1 << 32) - ((int64_t)2 << 20)) / per_row) & ~(int64_t)7;
 }
 
@@ -155,8 +155,8 @@ void carve_weights(pcad_engine* e, Carver& c) {
         L.W_in_f = pf ? c.take(2 * E * D * esz) : nullptr;
         L.W_out = c.take(D * E * esz);
         L.W_out_p = pf && (size_t)fold_padded_width((int)D) != D ? c.take((size_t)fold_padded_width((int)D) * E * esz) : L.W_out;
-        L.W_in_s = ps ? c.take(2 * E * 3 * D * 2) : nullptr;
-        L.W_out_s = ps ? c.take(D * 3 * E * 2) : nullptr;
+        L.W_in_s = ps ? c.take(2 * E * 2 * D * 2) : nullptr;
+        L.W_out_s = ps ? c.take(D * 2 * E * 2) : nullptr;
         for (int d = 0; d < 2; ++d) {
             DirWeights& w = L.dir[d];
             w.conv_w = (float*)c.take(E * 4 * 4);
@@ -164,7 +164,7 @@ void carve_weights(pcad_engine* e, Carver& c) {
             w.Wx = c.take((size_t)e->XP * E * esz);
             w.Wx_s = ps && e->convx ? c.take((size_t)e->XP * 2 * E * 2) : nullptr;
             w.Wdt = c.take(E * (size_t)e->Rp * esz);
-            w.Wdt_s = ps && e->convx ? c.take(E * (size_t)e->Rp * 3 * 2) : nullptr;
+            w.Wdt_s = ps && e->convx ? c.take(E * (size_t)e->Rp * 2 * 2) : nullptr;
             w.dt_bias = (float*)c.take(E * 4);
             w.A2 = (float*)c.take(E * N * 4);
             w.Dskip = (float*)c.take(E * 4);
@@ -174,7 +174,7 @@ void carve_weights(pcad_engine* e, Carver& c) {
 
 struct Workspace {
     void *res, *u, *h, *xz, *zb, *xc[2], *dtl[2], *y;
-    void* ys;        // "f32_gemm_split": out_proj's operand, bf16 [rows8, 3E] blocked = [hi | lo | hi] of y; else nullptr
+    void* ys;        // "f32_gemm_split": out_proj's operand, bf16 [rows8, 2E] blocked = [hi | lo] of y; else nullptr
     float* bc[2];
     float *rstd, *ssq;   // norm-folded form: rstd [rows]; partial sums of squares [rows, D / 128]
     float* seg;      // segmented-scan scratch (long sequences with few strands), or nullptr
@@ -192,7 +192,7 @@ Workspace carve_workspace(const pcad_engine* e, void* base, int Bc, int L, int B
     const size_t Dp = fold_padded_width((int)D);       // the folded form keeps res / u Dp = round_up(D, 256) columns wide
     w.res = c.take(rows * Dp * (e->rdt == F32 ? 4 : esz));
     const bool sp = split_wanted(e);
-    w.u = c.take(sp && rows * 3 * D * 2 > rows * Dp * esz ? rows * 3 * D * 2 : rows * Dp * esz);   // split: bf16 [rows, 3D] = [hi | lo | hi]
+    w.u = c.take(rows * Dp * esz);                     // split: bf16 [rows, 2D] = [hi | lo] (the same 4 D bytes per row)
     w.h = c.take(rows * D * esz);
     const size_t rows8z = (rows + 7) / 8 * 8;
     // in_proj output: plain xz [rows, 2E]; or (xzsplit) x [rows8, E] in `xz` and z [rows8, E] in `zb`, both blocked
@@ -201,14 +201,14 @@ Workspace carve_workspace(const pcad_engine* e, void* base, int Bc, int L, int B
     const size_t rows8 = (rows + 7) / 8 * 8;   // xc and y use the blocked layout: whole 8-row blocks
     w.xc[0] = c.take(rows8 * E * esz);
     w.xc[1] = c.take(rows8 * E * esz);
-    // dt_low (x_proj columns [0, Rp), zero padded past R); split: bf16 [rows, 3 Rp] = [hi | lo | hi]
-    const size_t dtl_bytes = sp && e->convx ? rows * e->Rp * 3 * 2 : rows * e->Rp * esz;
+    // dt_low (x_proj columns [0, Rp), zero padded past R); split: bf16 [rows, 2 Rp] = [hi | lo]
+    const size_t dtl_bytes = sp && e->convx ? rows * e->Rp * 2 * 2 : rows * e->Rp * esz;
     w.dtl[0] = c.take(dtl_bytes);
     w.dtl[1] = c.take(dtl_bytes);
     w.bc[0] = (float*)c.take(rows * 2 * e->N * 4);   // B_t | C_t rows, fp32 (values rounded to the model dtype)
     w.bc[1] = (float*)c.take(rows * 2 * e->N * 4);
     w.y = c.take(rows8 * E * esz);
-    w.ys = sp ? c.take(rows8 * 3 * E * 2) : nullptr;
+    w.ys = sp ? c.take(rows8 * 2 * E * 2) : nullptr;
     w.rstd = (float*)c.take(rows * 4);
     w.ssq = (float*)c.take(rows * (Dp / 128) * 4);
     const size_t segb = e->segments ? scan_segment_bytes(2 * Bc, L, (int)E, 2 * Bpol) : 0;
@@ -430,8 +430,8 @@ int pcad_bind_weights(pcad_handle h, const pcad_tensor* tensors, int n, void* ar
         NEED(t_out, mf + "out_proj.weight", (int64_t)D * E);
         HIP_TRY(launch_pack2d(t_out->data, t_out->dtype, E, L.W_out, dt, E, D, E, D, E, s));
         if (L.W_out_p != L.W_out) HIP_TRY(launch_pack2d(t_out->data, t_out->dtype, E, L.W_out_p, dt, E, D, E, fold_padded_width(D), E, s));
-        if (L.W_in_s) HIP_TRY(launch_pack_split3_w(t_in->data, t_in->dtype, D, L.W_in_s, 2 * E, D, s));
-        if (L.W_out_s) HIP_TRY(launch_pack_split3_w(t_out->data, t_out->dtype, E, L.W_out_s, D, E, s));
+        if (L.W_in_s) HIP_TRY(launch_pack_split_w(t_in->data, t_in->dtype, D, L.W_in_s, 2 * E, D, s));
+        if (L.W_out_s) HIP_TRY(launch_pack_split_w(t_out->data, t_out->dtype, E, L.W_out_s, D, E, s));
         for (int d = 0; d < 2; ++d) {
             DirWeights& w = L.dir[d];
             const std::string mp = lp + "mixer.submodule.mamba_" + (d == 0 ? "fwd." : "rev.");
@@ -448,7 +448,7 @@ int pcad_bind_weights(pcad_handle h, const pcad_tensor* tensors, int n, void* ar
             if (w.Wx_s) HIP_TRY(launch_pack_convx_wsplit((const float*)w.Wx, E, w.Wx_s, e->XP, E, s));     // from the padded fp32 copy
             NEED(t_dw, mp + "dt_proj.weight", (int64_t)E * R);
             HIP_TRY(launch_pack2d(t_dw->data, t_dw->dtype, R, w.Wdt, dt, Rp, E, R, E, Rp, s));
-            if (w.Wdt_s) HIP_TRY(launch_pack_split3_w(w.Wdt, dt, Rp, w.Wdt_s, E, Rp, s));        // from the zero-padded fp32 copy
+            if (w.Wdt_s) HIP_TRY(launch_pack_split_w(w.Wdt, dt, Rp, w.Wdt_s, E, Rp, s));         // from the zero-padded fp32 copy
             NEED(t_db, mp + "dt_proj.bias", (int64_t)E);
             HIP_TRY(launch_pack2d(t_db->data, t_db->dtype, E, w.dt_bias, F32, E, 1, E, 1, E, s));
             NEED(t_A, mp + "A_log", (int64_t)E * N);
@@ -565,8 +565,9 @@ static int forward_impl(pcad_handle h, const int32_t* ids, int B, int L, const i
         return fail(PCAD_ERR_INVALID, "pcad_forward: \"f32_gemm_split\" 1 was set after pcad_bind_weights; the split weight copies are packed at "
                                       "bind time - set the option before pcad_weight_arena_bytes / pcad_bind_weights");
     // Split-bf16 GEMMs of the fp32 model ("f32_gemm_split"; pack.hip): in_proj and out_proj - 3/4 of the fp32 model's time on the
-    // fp32 MFMA instructions - run as bf16 GEMMs with K' = 3 K on [hi | lo | hi] x [hi | hi | lo] operands and an fp32 result:
-    // operand error 2^-17, measured 4e-7 of the logits' range after 32 layers (fp32 MFMA: 1e-6 from summation order alone).
+    // fp32 MFMA instructions - run as bf16 GEMMs of 3 K / 64 K-tiles on [hi | lo] x [hi | lo] operands (wrap-around K cursor: hi.hi,
+    // lo.hi, hi.lo; gemm.hip) with an fp32 result: operand error 2^-17, measured 4e-7 of the logits' range after 32 layers (fp32 MFMA:
+    // 1e-6 from summation order alone).
     const bool sp = split_wanted(e) && e->split_packed;
     bool fold_all = fold_wanted(e) && e->fold_packed && !all_hidden;
     for (int ck = 0; ck < nchunks && fold_all; ++ck) {
@@ -621,7 +622,7 @@ static int forward_impl(pcad_handle h, const int32_t* ids, int B, int L, const i
         for (int rep = 0; rep < reps(PCAD_K_GEMM_IN); ++rep)
         { ProfScope ps(e, PCAD_K_GEMM_IN, s);
         if (c.fold) HIP_TRY(launch_gemm_nt_two(c.w.u, Dp, W.W_in_f, D, c.w.xz, c.w.zb, E, true, rows, 2 * E, D, dt, s, c.w.rstd));
-        else if (sp) HIP_TRY(launch_gemm_nt_two(c.w.u, 3 * D, W.W_in_s, 3 * D, c.w.xz, c.w.zb, E, true, rows, 2 * E, 3 * D, BF16, s, nullptr, F32));
+        else if (sp) HIP_TRY(launch_gemm_nt_two(c.w.u, 2 * D, W.W_in_s, 2 * D, c.w.xz, c.w.zb, E, true, rows, 2 * E, 3 * D, BF16, s, nullptr, F32, D / 64));
         else if (e->xzsplit) HIP_TRY(launch_gemm_nt_two(c.w.u, D, W.W_in, D, c.w.xz, c.w.zb, E, true, rows, 2 * E, D, dt, s));
         else HIP_TRY(launch_gemm_nt(c.w.u, D, W.W_in, D, c.w.xz, 2 * E, rows, 2 * E, D, dt, dt, false, s)); }
         // conv1d + SiLU, causal and anti-causal from one read of x (fused with x_proj of both directions when possible)
@@ -629,7 +630,7 @@ static int forward_impl(pcad_handle h, const int32_t* ids, int B, int L, const i
         if (convx) for (int rep = 0; rep < reps(PCAD_K_CONV); ++rep) {
             ProfScope ps(e, PCAD_K_CONV, s);
             HIP_TRY(launch_convx(c.w.xz, W.convw, sp ? W.dir[0].Wx_s : W.dir[0].Wx, c.w.xc[0], c.w.dtl[0], c.w.bc[0], sp ? W.dir[1].Wx_s : W.dir[1].Wx, c.w.xc[1],
-                                 c.w.dtl[1], c.w.bc[1], S, L, E, dt, s, Rp, sp, sp, c.w.cxp, 2 * B));      // sp: dt_low as bf16 [hi | lo | hi] for the scan's split dt_proj
+                                 c.w.dtl[1], c.w.bc[1], S, L, E, dt, s, Rp, sp, sp, c.w.cxp, 2 * B));      // sp: dt_low as bf16 [hi | lo] for the scan's split dt_proj
         } else {
             ProfScope ps(e, PCAD_K_CONV, s);
             HIP_TRY(launch_conv_bidir(c.w.xz, e->xzsplit ? E : 2 * E, W.dir[0].conv_w, W.dir[0].conv_b, W.dir[1].conv_w,
@@ -662,7 +663,7 @@ static int forward_impl(pcad_handle h, const int32_t* ids, int B, int L, const i
         // tensor (xc[0]: the forward scan, its only reader, has run) and each direction gets its own tied out_proj below
         const bool strict = e->ref_order == 2 && !c.fold;
         void* y_rev = strict ? c.w.xc[0] : c.w.y;
-        // "f32_gemm_split": out_proj's [hi | lo | hi] operand is written by the gating (reverse) scan itself where it can (whole walk,
+        // "f32_gemm_split": out_proj's [hi | lo] operand is written by the gating (reverse) scan itself where it can (whole walk,
         // unsegmented, L % 8 == 0, one out_proj for both directions), instead of fp32 y + a conversion pass
         const bool ys_from_scan = sp && !strict && !last_short && L % 8 == 0 && e->blocked && e->xzsplit &&
                                   !(c.w.seg && scan_segments(2 * B, L, E, nullptr) > 1);
@@ -671,9 +672,9 @@ static int forward_impl(pcad_handle h, const int32_t* ids, int B, int L, const i
         auto out_proj_full = [&](const void* ysrc, void* dst) -> hipError_t {
             if (sp) {
                 if (!(ys_from_scan && ysrc == c.w.y)) {
-                    if (hipError_t er = launch_split3_rows((const float*)ysrc, E, c.w.ys, rows, E, e->blocked, e->blocked, s)) return er;
+                    if (hipError_t er = launch_split_rows((const float*)ysrc, E, c.w.ys, rows, E, e->blocked, e->blocked, s)) return er;
                 }
-                return launch_gemm_nt(c.w.ys, 3 * E, W.W_out_s, 3 * E, dst, D, rows, D, 3 * E, BF16, F32, false, s, e->blocked);
+                return launch_gemm_nt(c.w.ys, 2 * E, W.W_out_s, 2 * E, dst, D, rows, D, 3 * E, BF16, F32, false, s, e->blocked, E / 64);
             }
             return launch_gemm_nt(ysrc, E, W.W_out, E, dst, D, rows, D, E, dt, dt, false, s, e->blocked);
         };
@@ -685,7 +686,7 @@ static int forward_impl(pcad_handle h, const int32_t* ids, int B, int L, const i
                                          e->blocked)); }
             // dt_proj (on MFMA inside the scan) + bias + softplus + recurrence + D skip + SiLU(z) gate
             for (int rep = 1; rep < (d == 0 ? reps(PCAD_K_SCAN) : 1); ++rep)         // measurement aid: the forward-direction launch is idempotent
-                HIP_TRY(launch_scan(c.w.xc[d], nullptr, e->xzsplit ? E : 2 * E, nullptr, c.w.dtl[d], dts ? 3 * Rp : Rp, dts ? dw.Wdt_s : dw.Wdt, dts ? 3 * Rp : Rp, c.w.bc[d], dw.A2, 1.0f,
+                HIP_TRY(launch_scan(c.w.xc[d], nullptr, e->xzsplit ? E : 2 * E, nullptr, c.w.dtl[d], dts ? 2 * Rp : Rp, dts ? dw.Wdt_s : dw.Wdt, Rp, c.w.bc[d], dw.A2, 1.0f,
                                     dw.Dskip, dw.dt_bias, c.w.y, S, L, E, false, 0, dt, s, e->blocked, e->xzsplit, c.w.seg, 0, nullptr, dts, 2 * B));
             ProfScope ps(e, PCAD_K_SCAN, s);
             const void* zp = e->xzsplit ? c.w.zb : (const void*)((const char*)c.w.xz + (size_t)E * esz);
@@ -693,7 +694,7 @@ static int forward_impl(pcad_handle h, const int32_t* ids, int B, int L, const i
             // to the sum (one SiLU per element instead of two, z read once; a rounding-order difference from
             // y_f*g + y_r*g, like the out_proj fold below).  PCAD_GATE_EACH=1: each direction gated and rounded.
             const bool gated = strict || !e->gate_once || d == 1;
-            HIP_TRY(launch_scan(c.w.xc[d], gated ? zp : nullptr, e->xzsplit ? E : 2 * E, nullptr, c.w.dtl[d], dts ? 3 * Rp : Rp, dts ? dw.Wdt_s : dw.Wdt, dts ? 3 * Rp : Rp,
+            HIP_TRY(launch_scan(c.w.xc[d], gated ? zp : nullptr, e->xzsplit ? E : 2 * E, nullptr, c.w.dtl[d], dts ? 2 * Rp : Rp, dts ? dw.Wdt_s : dw.Wdt, Rp,
                                 c.w.bc[d], dw.A2, 1.0f, dw.Dskip, dw.dt_bias, d == 1 ? y_rev : c.w.y, S, L, E, d == 1,
                                 strict ? 0 : (d == 1 ? (e->gate_once ? 2 : 1) : 0), dt, s, e->blocked, e->xzsplit, c.w.seg, last_short ? walk_len : 0,
                                 d == 1 && ys_from_scan ? c.w.ys : nullptr, dts, 2 * B));
@@ -726,6 +727,11 @@ static int forward_impl(pcad_handle h, const int32_t* ids, int B, int L, const i
         if (last_short) {       // out_proj on the evaluated rows only: gather (-> u, dead since in_proj) and a small GEMM (-> first rows of h)
             ProfScope ps(e, PCAD_K_HEAD, s);          // counted with the head: not a full-size out_proj launch
             HIP_TRY(launch_gather_rows(c.w.y, c.w.u, c.Bc, L, E, pos, dt, e->blocked, s));
+            if (sp) {           // the same split-bf16 product as the full-size out_proj (same operand values, same K order: bit-identical rows)
+                HIP_TRY(launch_split_rows((const float*)c.w.u, E, c.w.ys, (int64_t)S * P, E, false, false, s));
+                HIP_TRY(launch_gemm_nt(c.w.ys, 2 * E, W.W_out_s, 2 * E, c.w.h, D, (int64_t)S * P, D, 3 * E, BF16, F32, false, s, false, E / 64));
+                return PCAD_OK;
+            }
             HIP_TRY(launch_gemm_nt(c.w.u, E, W.W_out, E, c.w.h, D, (int64_t)S * P, D, E, dt, dt, false, s, false));
             return PCAD_OK;
         }
@@ -921,7 +927,7 @@ int pcad_gemm_nt(const void* A, int64_t lda, const void* W, int64_t ldw, void* C
 
 size_t pcad_gemm_nt_split_scratch_bytes(int64_t M, int N, int K) {
     if (M <= 0 || N <= 0 || K <= 0) return 0;
-    return align_up((size_t)M * 3 * K * 2) + align_up((size_t)N * 3 * K * 2);
+    return align_up((size_t)M * 2 * K * 2) + align_up((size_t)N * 2 * K * 2);       // bf16 [M, 2K] = [hi | lo] of A, bf16 [N, 2K] of W
 }
 
 int pcad_gemm_nt_split(const float* A, int64_t lda, const float* W, int64_t ldw, float* C, int64_t ldc, int64_t M, int N, int K,
@@ -934,10 +940,11 @@ int pcad_gemm_nt_split(const float* A, int64_t lda, const float* W, int64_t ldw,
     if (M == 0) return PCAD_OK;
     hipStream_t s = (hipStream_t)stream;
     void* As = scratch;
-    void* Ws = (char*)scratch + align_up((size_t)M * 3 * K * 2);
-    HIP_TRY(launch_split3_rows(A, lda, As, M, K, false, false, s));               // [hi | lo | hi]
-    HIP_TRY(launch_pack_split3_w(W, PCAD_F32, ldw, Ws, N, K, s));                 // [hi | hi | lo]
-    hipError_t err = launch_gemm_nt(As, 3 * (int64_t)K, Ws, 3 * (int64_t)K, C, ldc, M, N, 3 * K, BF16, F32, false, s, false);
+    void* Ws = (char*)scratch + align_up((size_t)M * 2 * K * 2);
+    HIP_TRY(launch_split_rows(A, lda, As, M, K, false, false, s));                // [hi | lo]
+    HIP_TRY(launch_pack_split_w(W, PCAD_F32, ldw, Ws, N, K, s));                  // [hi | lo]
+    // 3 K / 64 K-tiles, the cursor wrapping around both operands: a_hi w_hi + a_lo w_hi + a_hi w_lo
+    hipError_t err = launch_gemm_nt(As, 2 * (int64_t)K, Ws, 2 * (int64_t)K, C, ldc, M, N, 3 * K, BF16, F32, false, s, false, K / 64);
     if (err != hipSuccess) return fail(PCAD_ERR_HIP, "pcad_gemm_nt_split: %s", hipGetErrorString(err));
     return PCAD_OK;
 }

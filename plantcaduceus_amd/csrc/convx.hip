@@ -125,7 +125,7 @@ struct ConvxDir {
     void* xc;            // [rows8, E] blocked
     void* dtl;           // [rows, Rp]
     float* bc;           // [rows, 32]
-    int dtl_split;       // T == float only: dtl is a bf16 tensor [rows, 3 Rp] = [hi | lo | hi] (the scan's split-bf16 dt_proj operand)
+    int dtl_split;       // T == float only: dtl is a bf16 tensor [rows, 2 Rp] = [hi | lo] (the scan's split-bf16 dt_proj operand)
 };
 
 // convw: per K-tile CX_CW_BYTES of fp32 [dir][tap 0..3, bias][KC]  (packed at bind time by launch_pack_convw)
@@ -465,13 +465,12 @@ __global__ __launch_bounds__(CX_THREADS, 2) void convx_kernel(const T* __restric
                 *reinterpret_cast<u32x2*>(dl + j * 16 + lg * 4) = v;
             } else if (dd.dtl_split) {
                 constexpr int RPW = 16 * (NJ - 2);
-                bf16_t* ds = (bf16_t*)dd.dtl + row * (3 * RPW) + j * 16 + lg * 4;
+                bf16_t* ds = (bf16_t*)dd.dtl + row * (2 * RPW) + j * 16 + lg * 4;
                 const u32x2 hi = {pack_bf16x2(acc[i][j][0], acc[i][j][1]), pack_bf16x2(acc[i][j][2], acc[i][j][3])};
                 const u32x2 lo = {pack_bf16x2(acc[i][j][0] - bf16lo_to_f32(hi[0]), acc[i][j][1] - bf16hi_to_f32(hi[0])),
                                   pack_bf16x2(acc[i][j][2] - bf16lo_to_f32(hi[1]), acc[i][j][3] - bf16hi_to_f32(hi[1]))};
                 *reinterpret_cast<u32x2*>(ds) = hi;
                 *reinterpret_cast<u32x2*>(ds + RPW) = lo;
-                *reinterpret_cast<u32x2*>(ds + 2 * RPW) = hi;
             } else {
                 *reinterpret_cast<f32x4*>(dl + j * 16 + lg * 4) = acc[i][j];
             }
@@ -486,7 +485,7 @@ __global__ __launch_bounds__(CX_THREADS, 2) void convx_kernel(const T* __restric
 }
 
 // K-split reduction: x_dbl[dir][row][col] = sum_ks part[ks][dir][row][col] (index order), written as the epilogue above writes it:
-// columns [0, 16 (NJ - 2)) -> dt_low (model dtype, or the bf16 [hi | lo | hi] form), the last 32 -> B_t | C_t fp32 rounded to the model dtype
+// columns [0, 16 (NJ - 2)) -> dt_low (model dtype, or the bf16 [hi | lo] form), the last 32 -> B_t | C_t fp32 rounded to the model dtype
 template <typename T>
 __global__ __launch_bounds__(256) void convx_reduce_kernel(const float* __restrict__ part, int KS, int64_t rows, int XPW, ConvxDir d0, ConvxDir d1) {
     const int q4 = XPW / 4;
@@ -504,13 +503,12 @@ __global__ __launch_bounds__(256) void convx_reduce_kernel(const float* __restri
             if constexpr (sizeof(T) == 2) {
                 *reinterpret_cast<u32x2*>((T*)dd.dtl + row * RPW + c4) = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
             } else if (dd.dtl_split) {
-                bf16_t* ds = (bf16_t*)dd.dtl + row * (3 * RPW) + c4;
+                bf16_t* ds = (bf16_t*)dd.dtl + row * (2 * RPW) + c4;
                 const u32x2 hi = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
                 const u32x2 lo = {pack_bf16x2(v[0] - bf16lo_to_f32(hi[0]), v[1] - bf16hi_to_f32(hi[0])),
                                   pack_bf16x2(v[2] - bf16lo_to_f32(hi[1]), v[3] - bf16hi_to_f32(hi[1]))};
                 *reinterpret_cast<u32x2*>(ds) = hi;
                 *reinterpret_cast<u32x2*>(ds + RPW) = lo;
-                *reinterpret_cast<u32x2*>(ds + 2 * RPW) = hi;
             } else {
                 *reinterpret_cast<f32x4*>((T*)dd.dtl + row * RPW + c4) = v;
             }

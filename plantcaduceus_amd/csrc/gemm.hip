@@ -86,13 +86,15 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_kernel(const T* __res
                                                                   OutT* __restrict__ C, int64_t ldc, int64_t M, int N,
                                                                   int K, int tiles_m, int tiles_n,
                                                                   float* __restrict__ C2, int64_t ldc2, int nsplit,
-                                                                  int a_blocked) {
+                                                                  int a_blocked, int ksplit) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);    // 0..7
     const int nblk = tiles_m * tiles_n;
     const int nkt = (K * (int)sizeof(T)) / ROWB;
+    // ksplit != 0 (split-bf16 product of two fp32 operands, see "wrap-around K cursor" below): K = 3 Ko, both operands are stored
+    // [hi | lo] (2 Ko columns) and K-tile kt reads A at kt mod-wrapped after 2 ksplit tiles, W after ksplit tiles
 
     // ---- XCD-aware tile map: block b runs on XCD b & 7 (observed dispatch order; speed only) and walks the
     // contiguous logical range of that XCD, m-fastest inside groups of GROUP_M m-panels -------------------------
@@ -138,8 +140,10 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_kernel(const T* __res
     auto stage = [&](int kt, int st) {
         char* as = smem + st * STAGE_BYTES + (wave * 32) * ROWB;
         char* ws = smem + st * STAGE_BYTES + A_BYTES + (wave * 16) * ROWB;
-        const int64_t ko = (int64_t)kt * ROWB;
-        const int64_t koa = a_blocked ? (int64_t)kt * 1024 : ko;     // blocked A: consecutive k-pieces are 1 KiB apart
+        const int kta = ksplit && kt >= 2 * ksplit ? kt - 2 * ksplit : kt;      // A: hi, lo, hi
+        const int ktw = ksplit && kt >= ksplit ? kt - ksplit : kt;              // W: hi, hi, lo
+        const int64_t ko = (int64_t)ktw * ROWB;
+        const int64_t koa = a_blocked ? (int64_t)kta * 1024 : (int64_t)kta * ROWB;     // blocked A: consecutive k-pieces are 1 KiB apart
 #pragma unroll
         for (int i = 0; i < 4; ++i) glds16(pa[i] + koa, as + i * 8 * ROWB);
 #pragma unroll
@@ -338,7 +342,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm256r_kernel(const T* __re
                                                                    const T* __restrict__ W, int64_t ldw,
                                                                    OutT* __restrict__ C, int64_t ldc, int64_t M, int N,
                                                                    int K, int tiles_m, int tiles_n, int a_blocked,
-                                                                   OutT* __restrict__ C2, int nsplit, int out_blocked) {
+                                                                   OutT* __restrict__ C2, int nsplit, int out_blocked, int ksplit) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -394,7 +398,8 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm256r_kernel(const T* __re
     int w_tile = blockIdx.x, w_kt = 0, w_g = 0;
     auto a_piece = [&](int sa, int p) {               // piece p of A(a_g) -> A stage sa
         if (a_g < G) {
-            const int64_t koa = a_blocked ? (int64_t)a_kt * 1024 : (int64_t)a_kt * ROWB;
+            const int kta = ksplit && a_kt >= 2 * ksplit ? a_kt - 2 * ksplit : a_kt;      // wrap-around K cursor (A: hi, lo, hi)
+            const int64_t koa = a_blocked ? (int64_t)kta * 1024 : (int64_t)kta * ROWB;
             glds16(pa[p] + koa, smem + sa * A2_BYTES + (wave * 32 + p * 8) * ROWB);
         }
     };
@@ -410,7 +415,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm256r_kernel(const T* __re
     };
     auto w_pieces = [&](int sw, int p0) {             // pieces p0, p0 + 1 of W(w_g) -> W stage sw
         if (w_g < G) {
-            const int64_t ko = (int64_t)w_kt * ROWB;
+            const int64_t ko = (int64_t)(ksplit && w_kt >= ksplit ? w_kt - ksplit : w_kt) * ROWB;   // W: hi, hi, lo
             glds16(pw[p0] + ko, smem + GEMM3_OFF_W + sw * W2_BYTES + (wave * 32 + p0 * 8) * ROWB);
             glds16(pw[p0 + 1] + ko, smem + GEMM3_OFF_W + sw * W2_BYTES + (wave * 32 + (p0 + 1) * 8) * ROWB);
         }
@@ -692,7 +697,7 @@ __global__ __launch_bounds__(GEMMQ_THREADS, 1) void gemm256q_kernel(const T* __r
                                                                     OutT* __restrict__ C, int64_t ldc, int64_t M, int N,
                                                                     int K, int tiles_m, int tiles_n, int a_blocked,
                                                                     OutT* __restrict__ C2, int nsplit, int out_blocked, int epi_swap,
-                                                                    GemmEpi epi) {
+                                                                    GemmEpi epi, int ksplit) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -744,8 +749,17 @@ __global__ __launch_bounds__(GEMMQ_THREADS, 1) void gemm256q_kernel(const T* __r
     auto set_pw = [&](int n0) __attribute__((always_inline)) { w_base = (uint32_t)((int64_t)n0 * ldw * (int64_t)sizeof(T)); };
     int a_tile = blockIdx.x, a_kt = 0, a_g = 0;
     int w_tile = blockIdx.x, w_kt = 0, w_g = 0;
+    // Wrap-around K cursor (KSPLIT: the bf16 -> fp32 instantiation only, i.e. the split-bf16 GEMMs of the fp32 model, api.hip
+    // "f32_gemm_split"): an fp32 product a . w is three bf16 products a_hi w_hi + a_lo w_hi + a_hi w_lo.  Both operands are stored ONCE
+    // as [hi | lo] (2 Ko columns, ksplit = Ko / 64 K-tiles per part) and the K-tile cursor visits 3 ksplit tiles: A reads hi, lo, hi
+    // (back to column 0 after 2 ksplit tiles), W reads hi, hi, lo (back to column 0 after ksplit tiles).  Against the concatenated
+    // [hi | lo | hi] x [hi | hi | lo] form the producers write a third less, the operands take a third less memory and HBM traffic
+    // (the second visit of a part is served by the L2 / Infinity Cache), and the in-tensor offsets allow 1.5x larger chunks.
+    constexpr bool KSPLIT = !std::is_same<T, OutT>::value;
+    int a_kx = 0, w_kx = 0;                           // K-tile INDEX in memory of the cursors (== a_kt / w_kt without the wrap)
+    const int a_wrap = KSPLIT && ksplit ? 2 * ksplit : -1, w_wrap = KSPLIT && ksplit ? ksplit : -1;
     auto a_piece = [&](int sa, int p) __attribute__((always_inline)) {               // piece p of A(a_g) -> A stage sa
-        const uint32_t soff = a_base + (uint32_t)a_kt * (a_blocked ? 1024u : (uint32_t)ROWB);
+        const uint32_t soff = a_base + (uint32_t)(KSPLIT ? a_kx : a_kt) * (a_blocked ? 1024u : (uint32_t)ROWB);
         blds16(A, a_lo[p], soff, smem + sa * A2_BYTES + (wave * 64 + p * 8) * ROWB);
     };
     auto a_issue = [&](int sa) __attribute__((always_inline)) {
@@ -753,7 +767,7 @@ __global__ __launch_bounds__(GEMMQ_THREADS, 1) void gemm256q_kernel(const T* __r
         for (int p = 0; p < 8; ++p) a_piece(sa, p);
     };
     auto w_piece = [&](int sw, int p) __attribute__((always_inline)) {
-        const uint32_t soff = w_base + (uint32_t)w_kt * (uint32_t)ROWB;
+        const uint32_t soff = w_base + (uint32_t)(KSPLIT ? w_kx : w_kt) * (uint32_t)ROWB;
         blds16(W, w_lo[p], soff, smem + GEMM3_OFF_W + sw * W2_BYTES + (wave * 64 + p * 8) * ROWB);
     };
     auto w_issue = [&](int sw) __attribute__((always_inline)) {
@@ -763,6 +777,7 @@ __global__ __launch_bounds__(GEMMQ_THREADS, 1) void gemm256q_kernel(const T* __r
     auto a_advance = [&]() __attribute__((always_inline)) {
         if (a_g + 1 < G) {
             ++a_g;
+            if constexpr (KSPLIT) { ++a_kx; if (a_kt + 1 == a_wrap || a_kt + 1 == nkt) a_kx = 0; }
             if (++a_kt == nkt) {
                 a_kt = 0;
                 a_tile += gstride;
@@ -775,6 +790,7 @@ __global__ __launch_bounds__(GEMMQ_THREADS, 1) void gemm256q_kernel(const T* __r
     auto w_advance = [&]() __attribute__((always_inline)) {
         if (w_g + 1 < G) {
             ++w_g;
+            if constexpr (KSPLIT) { ++w_kx; if (w_kt + 1 == w_wrap || w_kt + 1 == nkt) w_kx = 0; }
             if (++w_kt == nkt) {
                 w_kt = 0;
                 w_tile += gstride;
@@ -1066,7 +1082,7 @@ static int persistent_grid(int nblk) {
 
 template <typename T, typename OutT, bool ROUND>
 static hipError_t launch_gemm_t(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc,
-                                int64_t M, int N, int K, hipStream_t s, bool a_blocked) {
+                                int64_t M, int N, int K, hipStream_t s, bool a_blocked, int ksplit = 0) {
     const int tiles_m = (int)((M + BM - 1) / BM), tiles_n = (N + BN - 1) / BN;
     const bool vec = ((ldc * (int64_t)sizeof(OutT)) % 16 == 0) && (((uintptr_t)C) % 16 == 0);
     dim3 grid((unsigned)persistent_grid(tiles_m * tiles_n)), block(GEMM_THREADS);
@@ -1074,12 +1090,12 @@ static hipError_t launch_gemm_t(const void* A, int64_t lda, const void* W, int64
         auto kfn = gemm_nt_kernel<T, OutT, ROUND, true, false>;
         if (hipError_t ae = ensure_dynamic_lds((const void*)kfn, GEMM_LDS)) return ae;
         hipLaunchKernelGGL(kfn, grid, block, GEMM_LDS, s, (const T*)A, lda, (const T*)W, ldw, (OutT*)C, ldc, M, N, K,
-                           tiles_m, tiles_n, (float*)nullptr, (int64_t)0, 0, (int)a_blocked);
+                           tiles_m, tiles_n, (float*)nullptr, (int64_t)0, 0, (int)a_blocked, ksplit);
     } else {
         auto kfn = gemm_nt_kernel<T, OutT, ROUND, false, false>;
         if (hipError_t ae = ensure_dynamic_lds((const void*)kfn, GEMM_LDS)) return ae;
         hipLaunchKernelGGL(kfn, grid, block, GEMM_LDS, s, (const T*)A, lda, (const T*)W, ldw, (OutT*)C, ldc, M, N, K,
-                           tiles_m, tiles_n, (float*)nullptr, (int64_t)0, 0, (int)a_blocked);
+                           tiles_m, tiles_n, (float*)nullptr, (int64_t)0, 0, (int)a_blocked, ksplit);
     }
     return hipGetLastError();
 }
@@ -1093,7 +1109,7 @@ static hipError_t launch_gemm_split_t(const void* A, int64_t lda, const void* W,
     auto kfn = gemm_nt_kernel<T, T, false, true, true>;
     if (hipError_t ae = ensure_dynamic_lds((const void*)kfn, GEMM_LDS)) return ae;
     hipLaunchKernelGGL(kfn, grid, block, GEMM_LDS, s, (const T*)A, lda, (const T*)W, ldw, (T*)C, ldc, M, N, K, tiles_m,
-                       tiles_n, C2, ldc2, nsplit, (int)a_blocked);
+                       tiles_n, C2, ldc2, nsplit, (int)a_blocked, 0);
     return hipGetLastError();
 }
 
@@ -1122,7 +1138,8 @@ static bool quad_ok(int64_t lda, int64_t ldw, int64_t M, int N, bool two, int ns
 template <typename T, typename OutT = T>
 static hipError_t launch_gemm256_t(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc, int64_t M,
                                    int N, int K, hipStream_t s, bool a_blocked, void* C2 = nullptr, int nsplit = 0,
-                                   bool out_blocked = false, int epi_kind = EPI_NONE, GemmEpi epi = GemmEpi{nullptr, nullptr, nullptr}) {
+                                   bool out_blocked = false, int epi_kind = EPI_NONE, GemmEpi epi = GemmEpi{nullptr, nullptr, nullptr},
+                                   int ksplit = 0) {
     const int tiles_m = (int)((M + BM2 - 1) / BM2), tiles_n = (N + BN2 - 1) / BN2;
     dim3 grid((unsigned)persistent_grid(tiles_m * tiles_n)), block(GEMM_THREADS);
     static const bool quad = dev_env("PCAD_GEMM_NOQUAD") == nullptr;   // PCAD_DEV=1 only: the 8-wave kernel for A/B runs
@@ -1134,7 +1151,7 @@ static hipError_t launch_gemm256_t(const void* A, int64_t lda, const void* W, in
         auto kq = gemm256q_kernel<T, OutT, EPIK>;                                                                               \
         if (hipError_t ae = ensure_dynamic_lds((const void*)kq, GEMM3_LDS)) return ae;                                          \
         hipLaunchKernelGGL(kq, grid, dim3(GEMMQ_THREADS), GEMM3_LDS, s, (const T*)A, lda, (const T*)W, ldw, (OutT*)C, ldc, M, N, K, \
-                           tiles_m, tiles_n, (int)a_blocked, (OutT*)C2, nsplit, (int)out_blocked, (int)epi_swap, epi);         \
+                           tiles_m, tiles_n, (int)a_blocked, (OutT*)C2, nsplit, (int)out_blocked, (int)epi_swap, epi, ksplit); \
                                                                                              \
         return hipGetLastError();                                                                                               \
     } while (0)
@@ -1149,14 +1166,14 @@ static hipError_t launch_gemm256_t(const void* A, int64_t lda, const void* W, in
     auto kr = gemm256r_kernel<T, OutT>;
     if (hipError_t ae = ensure_dynamic_lds((const void*)kr, GEMM3_LDS)) return ae;
     hipLaunchKernelGGL(kr, grid, block, GEMM3_LDS, s, (const T*)A, lda, (const T*)W, ldw, (OutT*)C, ldc, M, N, K, tiles_m,
-                       tiles_n, (int)a_blocked, (OutT*)C2, nsplit, (int)out_blocked);
+                       tiles_n, (int)a_blocked, (OutT*)C2, nsplit, (int)out_blocked, ksplit);
     return hipGetLastError();
 }
 
 // in_proj form on the 256x256 kernel: columns [0, nsplit) -> C1, [nsplit, N) -> C2: two separate tensors of nsplit and
 // N - nsplit columns, plain (contiguous rows) or both in the blocked layout.
 hipError_t launch_gemm_nt_two(const void* A, int64_t lda, const void* W, int64_t ldw, void* C1, void* C2, int nsplit,
-                              bool out_blocked, int64_t M, int N, int K, int dt, hipStream_t s, const float* rscale, int out_dt) {
+                              bool out_blocked, int64_t M, int N, int K, int dt, hipStream_t s, const float* rscale, int out_dt, int ksplit) {
     if (M <= 0 || N <= 0) return hipSuccess;
     const int esz = dt == BF16 ? 2 : 4;
     if (out_dt < 0) out_dt = dt;
@@ -1169,8 +1186,10 @@ hipError_t launch_gemm_nt_two(const void* A, int64_t lda, const void* W, int64_t
     const GemmEpi epi{rscale, nullptr, nullptr};
     if (out_dt != dt) {                    // bf16 operands -> fp32 outputs (split-bf16 in_proj of the fp32 model)
         if (dt != BF16 || out_dt != F32 || rscale) return hipErrorInvalidValue;
-        return launch_gemm256_t<bf16_t, float>(A, lda, W, ldw, C1, nsplit, M, N, K, s, false, C2, nsplit, out_blocked, EPI_NONE, epi);
+        if (ksplit && (ksplit < 0 || K != 3 * ksplit * (ROWB / 2))) return hipErrorInvalidValue;     // K = 3 Ko, ksplit = Ko / 64 K-tiles per part
+        return launch_gemm256_t<bf16_t, float>(A, lda, W, ldw, C1, nsplit, M, N, K, s, false, C2, nsplit, out_blocked, EPI_NONE, epi, ksplit);
     }
+    if (ksplit) return hipErrorInvalidValue;
     if (dt == BF16) return launch_gemm256_t<bf16_t>(A, lda, W, ldw, C1, nsplit, M, N, K, s, false, C2, nsplit, out_blocked, ek, epi);
     return launch_gemm256_t<float>(A, lda, W, ldw, C1, nsplit, M, N, K, s, false, C2, nsplit, out_blocked, ek, epi);
 }
@@ -1204,10 +1223,12 @@ hipError_t launch_gemm_nt_res(const void* A, int64_t lda, const void* W, int64_t
 }
 
 hipError_t launch_gemm_nt(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc, int64_t M,
-                          int N, int K, int dt, int out_dt, bool round_bf16, hipStream_t s, bool a_blocked) {
+                          int N, int K, int dt, int out_dt, bool round_bf16, hipStream_t s, bool a_blocked, int ksplit) {
     if (M <= 0 || N <= 0) return hipSuccess;
     const int esz = dt == BF16 ? 2 : 4;
     if (K <= 0 || (K * esz) % ROWB) return hipErrorInvalidValue;
+    // wrap-around K cursor: bf16 [hi | lo] operands (2 Ko columns), fp32 result, K = 3 Ko, ksplit = Ko / 64
+    if (ksplit && (ksplit < 0 || dt != BF16 || out_dt != F32 || round_bf16 || K != 3 * ksplit * (ROWB / 2))) return hipErrorInvalidValue;
     if ((lda * esz) % 16 || (ldw * esz) % 16 || ((uintptr_t)A) % 16 || ((uintptr_t)W) % 16)
         return hipErrorInvalidValue;
     if (a_blocked && (lda * esz) % 128) return hipErrorInvalidValue;
@@ -1216,7 +1237,8 @@ hipError_t launch_gemm_nt(const void* A, int64_t lda, const void* W, int64_t ldw
     const bool big = !no256 && M >= 2048 && N >= 512 && N % 16 == 0 && (out_dt == dt || (dt == BF16 && out_dt == F32 && !round_bf16)) &&
                      (ldc * osz) % 16 == 0 && ((uintptr_t)C) % 16 == 0;
     if (big) {
-        if (dt == BF16 && out_dt == F32) return launch_gemm256_t<bf16_t, float>(A, lda, W, ldw, C, ldc, M, N, K, s, a_blocked);
+        if (dt == BF16 && out_dt == F32)
+            return launch_gemm256_t<bf16_t, float>(A, lda, W, ldw, C, ldc, M, N, K, s, a_blocked, nullptr, 0, false, EPI_NONE, GemmEpi{nullptr, nullptr, nullptr}, ksplit);
         if (dt == BF16) return launch_gemm256_t<bf16_t>(A, lda, W, ldw, C, ldc, M, N, K, s, a_blocked);
         return launch_gemm256_t<float>(A, lda, W, ldw, C, ldc, M, N, K, s, a_blocked);
     }
@@ -1224,7 +1246,7 @@ hipError_t launch_gemm_nt(const void* A, int64_t lda, const void* W, int64_t ldw
         return launch_gemm_t<bf16_t, bf16_t, false>(A, lda, W, ldw, C, ldc, M, N, K, s, a_blocked);
     if (dt == BF16 && out_dt == F32)
         return round_bf16 ? launch_gemm_t<bf16_t, float, true>(A, lda, W, ldw, C, ldc, M, N, K, s, a_blocked)
-                          : launch_gemm_t<bf16_t, float, false>(A, lda, W, ldw, C, ldc, M, N, K, s, a_blocked);
+                          : launch_gemm_t<bf16_t, float, false>(A, lda, W, ldw, C, ldc, M, N, K, s, a_blocked, ksplit);
     if (dt == F32 && out_dt == F32)
         return launch_gemm_t<float, float, false>(A, lda, W, ldw, C, ldc, M, N, K, s, a_blocked);
     return hipErrorInvalidValue;

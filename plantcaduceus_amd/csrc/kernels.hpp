@@ -28,7 +28,7 @@ struct Positions {            // by-value kernel argument: the positions evaluat
 
 // norm.hip --------------------------------------------------------------------------------------
 // fused residual add + RMSNorm (rms_norm_fn prenorm=True).  x/y dtype `dt`; residuals `rdt`.
-// split_y (dt == F32 only): y is written as a bf16 tensor [rows, 3 D] = [hi | lo | hi] (pack.hip launch_split3_rows' format).
+// split_y (dt == F32 only): y is written as a bf16 tensor [rows, 2 D] = [hi | lo] (pack.hip launch_split_rows' format).
 hipError_t launch_add_rmsnorm(const void* x, const void* res_in, const float* w, void* y, void* res_out,
                               int64_t rows, int D, float eps, int dt, int rdt, hipStream_t s, bool split_y = false);
 // layer-0 variant: x = Emb[strand token] gathered on the fly (RCPS strands by index arithmetic).
@@ -61,9 +61,12 @@ hipError_t launch_add_round(void* a, const void* b, int64_t n, int dt, hipStream
 // C[M,N] = A[M,K] W[N,K]^T.  K multiple of 128 bytes; lda/ldw multiples of 16 bytes.
 // out_dt: F32 or == dt.  round_bf16: round the fp32 result to bf16 precision before an F32 store.
 // a_blocked: A is in the blocked layout with rows of lda elements.
+// ksplit != 0 (dt == BF16, out_dt == F32 only): the wrap-around K cursor of the split-bf16 GEMMs (api.hip "f32_gemm_split") - both
+// operands are bf16 [hi | lo] tensors of 2 Ko columns, K = 3 Ko, ksplit = Ko / 64 (K-tiles per part): the cursor reads A as hi, lo, hi
+// and W as hi, hi, lo, i.e. C = a_hi w_hi + a_lo w_hi + a_hi w_lo accumulated in fp32 in that order.
 hipError_t launch_gemm_nt(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc,
                           int64_t M, int N, int K, int dt, int out_dt, bool round_bf16, hipStream_t s,
-                          bool a_blocked = false);
+                          bool a_blocked = false, int ksplit = 0);
 // x_proj form: columns [0, nsplit) -> C (dtype dt, ld ldc); columns [nsplit, N) -> C2 (fp32, rounded to dt's
 // precision, ld ldc2).  nsplit % 16 == 0.
 hipError_t launch_gemm_nt_split(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc,
@@ -73,10 +76,11 @@ hipError_t launch_gemm_nt_split(const void* A, int64_t lda, const void* W, int64
 // in_proj form on the 256x256 kernel: columns [0, nsplit) -> C1, [nsplit, N) -> C2 (separate tensors of nsplit and
 // N - nsplit columns; both plain or both blocked).
 // rscale (or nullptr): per-row factor [M] applied to the result before it is rounded (the norm-folded in_proj: rstd of the row).
-// out_dt: -1 = dt; F32 with dt == BF16: bf16 operands, fp32 outputs (no rscale) - the split-bf16 in_proj of the fp32 model.
+// out_dt: -1 = dt; F32 with dt == BF16: bf16 operands, fp32 outputs (no rscale) - the split-bf16 in_proj of the fp32 model, with
+// ksplit = Ko / 64 and [hi | lo] operands as in launch_gemm_nt.
 hipError_t launch_gemm_nt_two(const void* A, int64_t lda, const void* W, int64_t ldw, void* C1, void* C2, int nsplit,
                               bool out_blocked, int64_t M, int N, int K, int dt, hipStream_t s, const float* rscale = nullptr,
-                              int out_dt = -1);
+                              int out_dt = -1, int ksplit = 0);
 
 // out_proj of the norm-folded layer form, on the 4-wave kernel only (gemm_fold_shapes_ok):
 //   res [M, N] fp32 (FRAGMENT layout, common.hpp res_frag_off) += A . W^T (in place);  C [M, N] (plain rows, dtype dt; unused for
@@ -103,7 +107,7 @@ hipError_t launch_pack_convw(const float* wf, const float* bf, const float* wr, 
                              hipStream_t s);
 hipError_t launch_convx(const void* x, const float* convw, const void* Wx0, void* xc0, void* dtl0, float* bc0,
                         const void* Wx1, void* xc1, void* dtl1, float* bc1, int S, int L, int E, int dt, hipStream_t s, int Rp = 64,
-                        bool dtl_split = false,       // dtl_split (dt == F32): dtl_d is written as bf16 [S*L, 3 Rp] = [hi | lo | hi]
+                        bool dtl_split = false,       // dtl_split (dt == F32): dtl_d is written as bf16 [S*L, 2 Rp] = [hi | lo]
                         bool w_split = false,         // w_split (dt == F32): Wx_d is the bf16 [Rp + 32, 2E] copy of launch_pack_convx_wsplit and
                                                       // x_proj runs as three bf16 MFMA products per fp32 product
                         float* part_ws = nullptr,     // scratch of convx_split_bytes(): small launches split the channel walk over several
@@ -132,10 +136,10 @@ hipError_t launch_scan(const void* u, const void* z, int64_t ldz, const void* de
                        const float* dbias, void* y, int S, int L, int E, bool reverse, int accumulate, int dt,
                        hipStream_t s, bool uy_blocked = false, bool z_blocked = false, float* seg_ws = nullptr, int walk_len = 0,
                        void* ysplit = nullptr, bool dt_split = false, int policy_S = 0);
-// dt_split (dt == F32, fused dt_proj): dt_low is bf16 [rows, lddt >= Rp] = [hi | lo | hi] and Wdt bf16 [E, Rp] = [hi | hi | lo] with Rp = 3 x
-// the padded dt_rank: the fp32 model's dt_proj as three bf16 MFMA products per fp32 product ("f32_gemm_split").
+// dt_split (dt == F32, fused dt_proj): dt_low is bf16 [rows, lddt >= 2 Rp] = [hi | lo] and Wdt bf16 [E, 2 Rp] = [hi | lo] (Rp = the padded
+// dt_rank, <= 96): the fp32 model's dt_proj as three bf16 MFMA products per fp32 product ("f32_gemm_split"; K walk hi.hi, lo.hi, hi.lo).
 // ysplit (fp32 engine layouts only: dt == F32, fused dt_proj, blocked u / y / z, L % 8 == 0; reverse gating launch, unsegmented, whole
-// walk): the output is written NOT to y but as out_proj's split-bf16 operand, bf16 [rows8, 3E] blocked = [hi | lo | hi] (pack.hip).
+// walk): the output is written NOT to y but as out_proj's split-bf16 operand, bf16 [rows8, 2E] blocked = [hi | lo] (pack.hip).
 
 // Segments per strand for the scan of S strands of L steps over E channels.  Pass A + pass B cost ~1.8x the arithmetic of one
 // walk, and a single wave per SIMD already keeps the VALU ~65 % busy, so cutting only pays when most SIMDs would otherwise idle
@@ -188,12 +192,13 @@ hipError_t launch_embed_inproj_table(const void* emb, const void* Wf, void* tab,
 hipError_t launch_embed_xz_gather(const int32_t* ids, const int32_t* comp8, const void* tab, void* x, void* z, int B, int L, int E, int dt,
                                   hipStream_t s);
 // split-bf16 operands of the fp32 model's big GEMMs ("f32_gemm_split"): v = hi + lo, hi = bf16(v), lo = bf16(v - hi);
-//   weights     [rows, cols] (fp32 / bf16 source) -> bf16 [rows, 3 cols] = [hi | hi | lo]               (bind time)
-//   activations fp32 [rows, K] (plain or blocked) -> bf16 [rows, 3 K]    = [hi | lo | hi] (plain or blocked), K % 64 == 0
-// so that a_hi w_hi + a_lo w_hi + a_hi w_lo is ONE bf16 GEMM with K' = 3 K and an fp32 result.
-hipError_t launch_pack_split3_w(const void* src, int src_dt, int64_t src_ld, void* dst, int rows, int cols, hipStream_t s);
-hipError_t launch_split3_rows(const float* src, int64_t src_ld, void* dst, int64_t rows, int K, bool src_blocked, bool dst_blocked,
-                              hipStream_t s);      // src_ld: elements between plain source rows (ignored for a blocked source)
+//   weights     [rows, cols] (fp32 / bf16 source) -> bf16 [rows, 2 cols] = [hi | lo]                    (bind time)
+//   activations fp32 [rows, K] (plain or blocked) -> bf16 [rows, 2 K]    = [hi | lo] (plain or blocked), K % 64 == 0
+// so that a_hi w_hi + a_lo w_hi + a_hi w_lo is ONE bf16 GEMM of 3 K / 64 K-tiles whose cursor wraps around both operands
+// (gemm.hip "wrap-around K cursor": launch_gemm_nt(..., K = 3 K, ksplit = K / 64)) with an fp32 result.
+hipError_t launch_pack_split_w(const void* src, int src_dt, int64_t src_ld, void* dst, int rows, int cols, hipStream_t s);
+hipError_t launch_split_rows(const float* src, int64_t src_ld, void* dst, int64_t rows, int K, bool src_blocked, bool dst_blocked,
+                             hipStream_t s);       // src_ld: elements between plain source rows (ignored for a blocked source)
 // A2[e, n] = -exp(A_log[e, n]) * log2(e)   (A_log read through its storage dtype)
 hipError_t launch_pack_A(const void* A_log, int src_dt, float* A2, int64_t n, float scale, hipStream_t s);
 

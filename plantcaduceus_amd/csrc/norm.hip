@@ -18,7 +18,7 @@ constexpr int PCAD_STATUS_BAD_TOKEN_BIT = 1, PCAD_STATUS_BAD_POSITION_BIT = 2;  
 
 // FOLD (norm-folded layer form, api.hip): y = the UN-normalised sum rounded to the model dtype and rstd_out[row] = its rstd; the
 // norm weight lives in the in_proj weight (folded at bind time) and rstd is applied by in_proj's epilogue.
-// SPLIT (T == float only; api.hip "f32_gemm_split"): y is a bf16 tensor [rows, 3 D] = [hi | lo | hi] of the normalised row
+// SPLIT (T == float only; api.hip "f32_gemm_split"): y is a bf16 tensor [rows, 2 D] = [hi | lo] of the normalised row
 // (hi = bf16(v), lo = bf16(v - hi)): the A operand of the split-bf16 in_proj (pack.hip), written here instead of the fp32 row.
 template <typename T, typename RT, int MAXC, bool EMBED, bool FOLD = false, bool SPLIT = false>
 __global__ __launch_bounds__(256) void add_rmsnorm_kernel(const T* __restrict__ x, const RT* __restrict__ res_in,
@@ -95,13 +95,12 @@ __global__ __launch_bounds__(256) void add_rmsnorm_kernel(const T* __restrict__ 
 #pragma unroll
             for (int i = 0; i < 8; ++i) o[i] = v[j][i] * rstd * wv[i];
             if constexpr (SPLIT) {
-                bf16_t* ys = reinterpret_cast<bf16_t*>(y) + row * 3 * D + c * 8;
+                bf16_t* ys = reinterpret_cast<bf16_t*>(y) + row * 2 * D + c * 8;
                 float lo[8];
 #pragma unroll
                 for (int i = 0; i < 8; ++i) lo[i] = o[i] - round_to_bf16(o[i]);
                 store8<bf16_t>(ys, o);
                 store8<bf16_t>(ys + D, lo);
-                store8<bf16_t>(ys + 2 * D, o);
             } else {
                 store8<T>(y + row * D + c * 8, o);
             }

@@ -79,37 +79,39 @@ hipError_t launch_pack_scale_cols(const void* src, int src_dt, int64_t src_ld, c
 // ---- split-bf16 operands of the fp32 model's big GEMMs (api.hip "f32_gemm_split") ------------------------------------------------
 // An fp32 value v is carried as two bf16 values hi = bf16(v), lo = bf16(v - hi) (v = hi + lo up to 2^-17 |v|), and
 //     a . w  ~  a_hi w_hi + a_lo w_hi + a_hi w_lo          (the dropped a_lo w_lo term is 2^-16 relative)
-// runs as ONE bf16 GEMM with K' = 3 K on operands concatenated along K:  A' = [a_hi | a_lo | a_hi],  W' = [w_hi | w_hi | w_lo],
-// fp32 accumulation in the MFMA, fp32 result - three v_mfma_f32_16x16x32_bf16 products (3/16 of the fp32-MFMA cost per flop).
-// Weights (bind time): src [rows, cols] fp32 or bf16 -> dst [rows, 3 cols] bf16 = [hi | hi | lo].
+// runs as ONE bf16 GEMM of 3 K / 64 K-tiles on operands stored once as A' = [a_hi | a_lo], W' = [w_hi | w_lo]: the GEMM's K-tile
+// cursor wraps around (A: hi, lo, hi; W: hi, hi, lo - gemm.hip), fp32 accumulation in the MFMA, fp32 result - three
+// v_mfma_f32_16x16x32_bf16 products (3/16 of the fp32-MFMA cost per flop).  (Round 5 stored the concatenations [hi | lo | hi] and
+// [hi | hi | lo]: a third more bytes written by every producer and 1.5x the operand footprint.)
+// Weights (bind time): src [rows, cols] fp32 or bf16 -> dst [rows, 2 cols] bf16 = [hi | lo].
 template <typename SrcT>
-__global__ __launch_bounds__(256) void pack_split3_w_kernel(const SrcT* __restrict__ src, int64_t src_ld, bf16_t* __restrict__ dst,
-                                                            int rows, int cols) {
+__global__ __launch_bounds__(256) void pack_split_w_kernel(const SrcT* __restrict__ src, int64_t src_ld, bf16_t* __restrict__ dst,
+                                                           int rows, int cols) {
     const int64_t total = (int64_t)rows * cols;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int r = (int)(i / cols), c = (int)(i - (int64_t)r * cols);
         const float v = Elem<SrcT>::load(src + (int64_t)r * src_ld + c);
         const bf16_t hi = f32_to_bf16(v);
         const bf16_t lo = f32_to_bf16(v - bf16_to_f32(hi));
-        bf16_t* d = dst + (int64_t)r * 3 * cols + c;
-        d[0] = hi; d[cols] = hi; d[2 * cols] = lo;
+        bf16_t* d = dst + (int64_t)r * 2 * cols + c;
+        d[0] = hi; d[cols] = lo;
     }
 }
 
-hipError_t launch_pack_split3_w(const void* src, int src_dt, int64_t src_ld, void* dst, int rows, int cols, hipStream_t s) {
+hipError_t launch_pack_split_w(const void* src, int src_dt, int64_t src_ld, void* dst, int rows, int cols, hipStream_t s) {
     const int64_t total = (int64_t)rows * cols;
     if (total <= 0) return hipSuccess;
     int64_t nb = (total + 255) / 256;
     if (nb > 4096) nb = 4096;
-    if (src_dt == F32) hipLaunchKernelGGL(pack_split3_w_kernel<float>, dim3((unsigned)nb), dim3(256), 0, s, (const float*)src, src_ld, (bf16_t*)dst, rows, cols);
-    else hipLaunchKernelGGL(pack_split3_w_kernel<bf16_t>, dim3((unsigned)nb), dim3(256), 0, s, (const bf16_t*)src, src_ld, (bf16_t*)dst, rows, cols);
+    if (src_dt == F32) hipLaunchKernelGGL(pack_split_w_kernel<float>, dim3((unsigned)nb), dim3(256), 0, s, (const float*)src, src_ld, (bf16_t*)dst, rows, cols);
+    else hipLaunchKernelGGL(pack_split_w_kernel<bf16_t>, dim3((unsigned)nb), dim3(256), 0, s, (const bf16_t*)src, src_ld, (bf16_t*)dst, rows, cols);
     return hipGetLastError();
 }
 
-// Activations (per layer): src fp32 [rows, K] plain rows or blocked (32 floats per 128-byte piece) -> dst bf16 [rows, 3 K] =
-// [hi | lo | hi] in plain rows or blocked (64 bf16 per piece, rows of 3 K * 2 / 128 pieces).  One thread = 8 consecutive values:
-// 32 bytes in, 3 x 16 bytes out.  K % 64 == 0 (whole pieces of the destination per third).
-__global__ __launch_bounds__(256) void split3_rows_kernel(const float* __restrict__ src, int64_t src_ld, bf16_t* __restrict__ dst, int64_t rows, int K,
+// Activations (per layer): src fp32 [rows, K] plain rows or blocked (32 floats per 128-byte piece) -> dst bf16 [rows, 2 K] =
+// [hi | lo] in plain rows or blocked (64 bf16 per piece, rows of 2 K * 2 / 128 pieces).  One thread = 8 consecutive values:
+// 32 bytes in, 2 x 16 bytes out.  K % 64 == 0 (whole pieces of the destination per half).
+__global__ __launch_bounds__(256) void split_rows_kernel(const float* __restrict__ src, int64_t src_ld, bf16_t* __restrict__ dst, int64_t rows, int K,
                                                           int src_blocked, int dst_blocked) {
     const int nch = K >> 3;
     const int64_t total = rows * nch;
@@ -123,22 +125,21 @@ __global__ __launch_bounds__(256) void split3_rows_kernel(const float* __restric
 #pragma unroll
         for (int k = 0; k < 8; ++k) lo[k] = v[k] - round_to_bf16(v[k]);
         auto at = [&](int col) -> bf16_t* {
-            return dst_blocked ? reinterpret_cast<bf16_t*>(reinterpret_cast<char*>(dst) + blocked_off(r, (int64_t)col * 2, (int64_t)3 * K * 2 >> 7))
-                               : dst + r * 3 * K + col;
+            return dst_blocked ? reinterpret_cast<bf16_t*>(reinterpret_cast<char*>(dst) + blocked_off(r, (int64_t)col * 2, (int64_t)2 * K * 2 >> 7))
+                               : dst + r * 2 * K + col;
         };
         store8<bf16_t>(at(c), v);
         store8<bf16_t>(at(K + c), lo);
-        store8<bf16_t>(at(2 * K + c), v);
     }
 }
 
-hipError_t launch_split3_rows(const float* src, int64_t src_ld, void* dst, int64_t rows, int K, bool src_blocked, bool dst_blocked, hipStream_t s) {
+hipError_t launch_split_rows(const float* src, int64_t src_ld, void* dst, int64_t rows, int K, bool src_blocked, bool dst_blocked, hipStream_t s) {
     if (rows <= 0) return hipSuccess;
     if (K <= 0 || K % 64 || (!src_blocked && (src_ld < K || src_ld % 4)) || ((uintptr_t)src) % 16 || ((uintptr_t)dst) % 16) return hipErrorInvalidValue;
     const int64_t total = rows * (K >> 3);
     int64_t nb = (total + 255) / 256;
     if (nb > 65536) nb = 65536;
-    hipLaunchKernelGGL(split3_rows_kernel, dim3((unsigned)nb), dim3(256), 0, s, src, src_ld, (bf16_t*)dst, rows, K, (int)src_blocked, (int)dst_blocked);
+    hipLaunchKernelGGL(split_rows_kernel, dim3((unsigned)nb), dim3(256), 0, s, src, src_ld, (bf16_t*)dst, rows, K, (int)src_blocked, (int)dst_blocked);
     return hipGetLastError();
 }
 

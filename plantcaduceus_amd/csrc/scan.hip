@@ -21,6 +21,12 @@
 //   * The reverse direction walks t = L-1..0 on the same rows (no flipped copy); `accumulate` (1: after the gate, each
 //     direction rounded as the reference does; 2: before the gate, one SiLU(z) for both directions) adds the forward
 //     direction's output (BiMambaWrapper strategy "add", tied out_proj folded by linearity).
+//   * Block order is XCD-affine (round 6): the E/64 channel-block waves of a strand all run on ONE XCD (block b -> XCD b % 8 is the
+//     observed dispatch rule; speed only), so a strand's B_t | C_t rows and dt_low rows are fetched from HBM into one L2 instead of
+//     eight, and the rows of the NEXT 32-step block are pulled into that L2 one block ahead (two dword loads per lane whose values
+//     are never used): the per-step scalar loads then hit L2.  At full occupancy (4 waves per SIMD) the other waves hid those misses;
+//     with few long strands (PlantCAD2's 8 192-bp windows: 2 waves per SIMD) they were 45 % of a wave's cycles
+//     (profiles/r06a_kpmc_scan_pc2m_8192.txt: SQ_WAIT_ANY).
 // VALU/transcendental bound (measured on gfx950: v_exp_f32 8.5, v_fma_f32 3.7, v_pk_fma_f32 5.2 cycles per
 // wave-instruction at 4 waves/SIMD, not overlapping): ~19 cycles per (t, channel, state).
 #include <cstdlib>
@@ -150,6 +156,36 @@ template <> struct DeltaTile<float> {
     }
 };
 
+// Split-bf16 dt_proj of the fp32 model (api.hip "f32_gemm_split"): dt_low arrives as bf16 [rows, lddt >= 2 R'] = [hi | lo] (written by the
+// fused conv + x_proj epilogue) and Wdt as bf16 [E, 2 R'] = [hi | lo] (bind time), hi = bf16(v), lo = bf16(v - hi).  The K walk is the
+// wrap-around cursor of the split GEMMs (gemm.hip): (a_hi, w_hi), (a_lo, w_hi), (a_hi, w_lo) - three bf16 products per fp32 product
+// on v_mfma_f32_32x32x16_bf16, 3 R' / 16 x 2 MFMAs per 32-step tile instead of R' / 2 x 2 fp32 ones (4x slower each).
+struct DeltaTileSplit {
+    static __device__ __forceinline__ void run(const bf16_t* __restrict__ dtl, int64_t lddt, int64_t row_base, int t0,
+                                               int L, const bf16_t* __restrict__ Wdt, int c0, int Rp, int lane,
+                                               f32x16& acc0, f32x16& acc1) {
+        const int tr = max(0, min(t0 + (lane & 31), L - 1));
+        const bf16_t* arow = dtl + (row_base + tr) * lddt + (lane >> 5) * 8;
+        const bf16_t* b0 = Wdt + (int64_t)(c0 + (lane & 31)) * 2 * Rp + (lane >> 5) * 8;
+        const bf16_t* b1 = b0 + (int64_t)32 * 2 * Rp;
+#pragma unroll
+        for (int part = 0; part < 3; ++part) {
+            const bf16_t* ap = arow + (part == 1 ? Rp : 0);
+            const int wo = part == 2 ? Rp : 0;
+#pragma unroll 4
+            for (int k = 0; k < Rp; k += 16) {
+                const u32x4 a = *reinterpret_cast<const u32x4*>(ap + k);
+                const u32x4 w0 = *reinterpret_cast<const u32x4*>(b0 + wo + k);
+                const u32x4 w1 = *reinterpret_cast<const u32x4*>(b1 + wo + k);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a),
+                                                               __builtin_bit_cast(bf16x8_t, w0), acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a),
+                                                               __builtin_bit_cast(bf16x8_t, w1), acc1, 0, 0, 0);
+            }
+        }
+    }
+};
+
 // FUSED: delta comes from dt_low . Wdt^T (above);  !FUSED: delta is read from memory like u (operator entry).
 // PRE (bf16, FUSED; 0: off, else = Rp, 64 or 96): dt_low operand prefetched one block ahead.
 // BLK8: u / y in the blocked layout AND L % 8 == 0 (the engine's case): one scalar block offset per 4-step chunk, the
@@ -158,9 +194,9 @@ template <> struct DeltaTile<float> {
 // run as separate workgroups.  SEG = 1, pass A: from a ZERO state, no output - stores the segment's end state and its sum of delta
 // (the product of its decays is exp2(A2 * sum delta));  SEG = 2, pass B: the normal walk of the segment from the true initial state
 // that scan_carry_kernel derived from pass A.  SEG = 0: the whole strand in one workgroup (G = 1).
-// SPLITY (fp32 engine with "f32_gemm_split", BLK8 only): the output is ALSO NOT written as fp32 rows but as out_proj's split-bf16
-// operand - ysplit, bf16 [rows8, 3E] blocked = [hi | lo | hi] with hi = bf16(y), lo = bf16(y - hi) (pack.hip launch_split3_rows'
-// format) - which saves the separate conversion pass over y (read 4E + write 6E bytes per row).
+// SPLITY (fp32 engine with "f32_gemm_split", BLK8 only): the output is NOT written as fp32 rows but as out_proj's split-bf16
+// operand - ysplit, bf16 [rows8, 2E] blocked = [hi | lo] with hi = bf16(y), lo = bf16(y - hi) (pack.hip launch_split_rows'
+// format) - which saves the separate conversion pass over y (read 4E + write 4E bytes per row).
 template <typename T, bool REV, int ACC, bool HASZ, bool FUSED, int PRE, bool BLK8, int SEG = 0, bool ZB = false, bool SPLITY = false>
 __global__ __launch_bounds__(64, 4) void scan_kernel(const T* __restrict__ u, const T* __restrict__ z, int64_t ldz,
                                                   const T* __restrict__ dsrc, int64_t ldd,
@@ -174,11 +210,22 @@ __global__ __launch_bounds__(64, 4) void scan_kernel(const T* __restrict__ u, co
     // read at the block's ends, so that read needs no wrap (its address is a per-chunk base + a compile-time offset)
     __shared__ float dvs[TB + 2][64];
     const int lane = threadIdx.x;
-    const int c0 = blockIdx.x * 64;
+    // 1-D grid of (strands x segments) x (E / 64) blocks in XCD-affine order: block b runs on XCD b % 8 (observed; speed only), so
+    // the E / 64 channel blocks of strand-segment 8 q + x are the consecutive blocks j = b / 8 of XCD x = b % 8; a tail of fewer
+    // than 8 strand-segments keeps the natural order
+    const int ncb = E >> 6;
+    const int nss = (int)gridDim.x / ncb;             // strands x segments
+    int ss, cb;
+    {
+        const int b = (int)blockIdx.x, full = (nss & ~7) * ncb;
+        if (b < full) { const int j = b >> 3, q = j / ncb; ss = q * 8 + (b & 7); cb = j - q * ncb; }
+        else { const int r = b - full, q = r / ncb; ss = (nss & ~7) + q; cb = r - q * ncb; }
+    }
+    const int c0 = cb * 64;
     const int c = c0 + lane;
-    const int strand = SEG ? (int)blockIdx.y / G : (int)blockIdx.y;
-    const int seg = SEG ? (int)blockIdx.y - strand * G : 0;
-    const int nstrands = SEG ? (int)gridDim.y / G : (int)gridDim.y;
+    const int strand = SEG ? ss / G : ss;
+    const int seg = SEG ? ss - strand * G : 0;
+    const int nstrands = SEG ? nss / G : nss;
     const int64_t row0 = (int64_t)strand * L;
 
     f2 a2p[NSTATE / 2], hp[NSTATE / 2];
@@ -252,13 +299,13 @@ __global__ __launch_bounds__(64, 4) void scan_kernel(const T* __restrict__ u, co
         }
     };
     auto uy_voff = [&](int i) -> int { return BLK8 ? voff_uy + 128 * (REV ? CH - 1 - i : i) : voff_uy; };
-    // SPLITY: rows of 3E bf16 in the blocked layout; the wave's 64 channels are exactly one 128-byte piece of each third
-    const uint32_t pieces3 = (3u * (uint32_t)E * 2u) >> 7, third = ((uint32_t)E >> 6) << 10;
-    const auto ys_r = make_rsrc(SPLITY ? (const void*)ysplit : (const void*)u, SPLITY ? tot_rows * 3u * (uint32_t)E * 2u : 4u);
+    // SPLITY: rows of 2E bf16 in the blocked layout; the wave's 64 channels are exactly one 128-byte piece of each half
+    const uint32_t ys_pieces = (2u * (uint32_t)E * 2u) >> 7, ys_half = ((uint32_t)E >> 6) << 10;        // pieces per row; bytes from the hi to the lo piece
+    const auto ys_r = make_rsrc(SPLITY ? (const void*)ysplit : (const void*)u, SPLITY ? tot_rows * 2u * (uint32_t)E * 2u : 4u);
     auto ys_soff = [&](int s0) -> uint32_t {            // scalar offset of the chunk's lowest row (BLK8: a chunk never crosses an 8-row block)
         const int slo = min(REV ? s0 + CH - 1 : s0, L - 1);
         const uint32_t r = (uint32_t)row0 + (uint32_t)(REV ? (L - 1 - slo) : slo);
-        return (((r >> 3) * pieces3 + ((uint32_t)c0 >> 6)) << 10) + ((r & 7u) << 7);
+        return (((r >> 3) * ys_pieces + ((uint32_t)c0 >> 6)) << 10) + ((r & 7u) << 7);
     };
     auto ys_voff = [&](int i) -> int { return lane * 2 + 128 * (REV ? CH - 1 - i : i); };
 
@@ -336,10 +383,34 @@ __global__ __launch_bounds__(64, 4) void scan_kernel(const T* __restrict__ u, co
     DeltaPre<PRE ? PRE : 16> pre;
     if constexpr (PRE != 0) pre = delta_prefetch<PRE>((const bf16_t*)dsrc, ldd, row0, REV ? (L - (b_begin + 1) * TB) : b_begin * TB, L, lane);
 
+    // L2 prefetch of the NEXT block's B_t | C_t rows (32 x 128 bytes, contiguous) and - fp32 split dt_proj, whose operand is not held
+    // in registers - dt_low rows: one dword per 32-byte sector, values never used.  They are "consumed" by an empty asm at the top of the
+    // next block (a full 32-step walk later: long landed), which is what keeps the registers reserved until the loads have returned.
+    float pfb0 = 0.f, pfb1 = 0.f, pfd[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     const int b_end = SEG ? min(nblk, b_begin + seg_blocks) : nblk;
     for (int b = b_begin; b < b_end; ++b) {
         const int tb0 = REV ? (L - (b + 1) * TB) : b * TB;
         if constexpr (FUSED) {
+            asm volatile("" ::"v"(pfb0), "v"(pfb1));
+            const int tbn = max(0, min(REV ? (L - (b + 2) * TB) : (b + 1) * TB, L - 1));          // first row of the next block in memory order (clamped)
+            {
+                const int lim = L * (2 * NSTATE * 4) - 4;                                          // last dword of the strand's rows
+                const char* pb = reinterpret_cast<const char*>(bc_s);
+                pfb0 = *reinterpret_cast<const float*>(pb + min(tbn * (2 * NSTATE * 4) + lane * 32, lim));
+                pfb1 = *reinterpret_cast<const float*>(pb + min(tbn * (2 * NSTATE * 4) + (64 + lane) * 32, lim));
+            }
+            if constexpr (std::is_same<T, float>::value && PRE == 0) {
+                if (dts) {
+                    asm volatile("" ::"v"(pfd[0]), "v"(pfd[1]), "v"(pfd[2]), "v"(pfd[3]), "v"(pfd[4]), "v"(pfd[5]));
+                    const int64_t rb = (int64_t)ldd * 2;                                           // bytes per dt_low row (bf16 [hi | lo | pad])
+                    const char* pd = reinterpret_cast<const char*>(dsrc) + row0 * rb;
+                    const int64_t lim = (int64_t)L * rb - 4;
+                    const int nsec = (int)((TB * rb + 2047) >> 11);                               // 64 lanes x 32 bytes per load
+#pragma unroll
+                    for (int q = 0; q < 6; ++q)
+                        if (q < nsec) pfd[q] = *reinterpret_cast<const float*>(pd + min((int64_t)tbn * rb + (int64_t)(q * 64 + lane) * 32, lim));
+                }
+            }
             f32x16 acc0, acc1;
 #pragma unroll
             for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
@@ -348,10 +419,9 @@ __global__ __launch_bounds__(64, 4) void scan_kernel(const T* __restrict__ u, co
                 // next block's operand: in flight during this block's 32-step walk (rows clamp at the sequence ends)
                 pre = delta_prefetch<PRE>((const bf16_t*)dsrc, ldd, row0, REV ? (L - (b + 2) * TB) : (b + 1) * TB, L, lane);
             } else if constexpr (std::is_same<T, float>::value) {
-                // dts (fp32 engine with "f32_gemm_split"): dt_low arrives as bf16 [rows, 3 R'] = [hi | lo | hi] (convx epilogue) and Wdt as
-                // bf16 [E, 3 R'] = [hi | hi | lo] (bind time), Rp = 3 R': dt_low . Wdt^T as three bf16 products per fp32 product on
-                // v_mfma_f32_32x32x16_bf16 - 24 instead of 64 (4x slower) MFMAs per 32-step tile (wave-uniform branch, once per tile)
-                if (dts) DeltaTile<bf16_t>::run(reinterpret_cast<const bf16_t*>(dsrc), ldd, row0, tb0, L, reinterpret_cast<const bf16_t*>(Wdt), c0, Rp, lane, acc0, acc1);
+                // dts (fp32 engine with "f32_gemm_split"): dt_low bf16 [rows, 2 R'] = [hi | lo], Wdt bf16 [E, 2 R'] = [hi | lo], Rp = R':
+                // 24 bf16 MFMAs instead of 64 (4x slower) fp32 ones per 32-step tile at R' = 64 (wave-uniform branch, once per tile)
+                if (dts) DeltaTileSplit::run(reinterpret_cast<const bf16_t*>(dsrc), ldd, row0, tb0, L, reinterpret_cast<const bf16_t*>(Wdt), c0, Rp, lane, acc0, acc1);
                 else DeltaTile<T>::run(dsrc, ldd, row0, tb0, L, Wdt, c0, Rp, lane, acc0, acc1);
             } else {
                 DeltaTile<T>::run(dsrc, ldd, row0, tb0, L, Wdt, c0, Rp, lane, acc0, acc1);
@@ -380,8 +450,7 @@ __global__ __launch_bounds__(64, 4) void scan_kernel(const T* __restrict__ u, co
                 const bf16_t hi = (bf16_t)(pk & 0xffffu);
                 const bf16_t lo = f32_to_bf16(yv - bf16lo_to_f32(pk));                       // lo = bf16(y - hi)
                 BufIO<bf16_t>::store(hi, ys_r, ys_voff(i), oys);
-                BufIO<bf16_t>::store(lo, ys_r, ys_voff(i), oys + third);
-                BufIO<bf16_t>::store(hi, ys_r, ys_voff(i), oys + 2u * third);
+                BufIO<bf16_t>::store(lo, ys_r, ys_voff(i), oys + ys_half);
             } else if constexpr (SEG != 1) BufIO<T>::store(Elem<T>::from_f32(yv), y_r, vy, oy);
         };
         auto run_chunk = [&](int s0, T (&uu)[CH], T (&zz)[CH], T (&yy)[CH], T (&dd)[CH]) {
@@ -454,7 +523,7 @@ static hipError_t launch_scan_t(const void* u, const void* z, int64_t ldz, const
                                 void* ysplit = nullptr, bool dt_split = false, int policy_S = 0) {
     const int dts = dt_split ? 1 : 0;
     const int Sp = policy_S > 0 ? policy_S : S;          // strands the segment policy is evaluated for (kernels.hpp scan_segment_bytes)
-    dim3 grid((unsigned)(E / 64), (unsigned)S), block(64);
+    dim3 grid((unsigned)((int64_t)(E / 64) * S)), block(64);          // 1-D: the kernel maps blocks to (strand, channel block) XCD-affinely
     const bool hz = z != nullptr;
     if (ysplit != nullptr) {
         // out_proj's split-bf16 operand written by the walk itself: the fp32 engine's reverse (gating) launch only
@@ -482,7 +551,7 @@ static hipError_t launch_scan_t(const void* u, const void* z, int64_t ldz, const
         const bool combo = (!reverse && accumulate == 0) || (reverse && accumulate == 2 && hz) || (reverse && accumulate == 1 && hz) ||
                            (reverse && accumulate == 0 && hz);
         if (G > 1 && combo) {
-            dim3 gseg((unsigned)(E / 64), (unsigned)(S * G));
+            dim3 gseg((unsigned)((int64_t)(E / 64) * S * G));
 #define PCAD_SEG(REV, ACC, HZ, SEGM, ZP)                                                                                  \
             hipLaunchKernelGGL((scan_kernel<T, REV, ACC, HZ, FUSED, PRE, BLK8, SEGM, ZB && HZ>), gseg, block, 0, s, PCAD_SCAN_ARGS(ZP), G, sb, seg_ws, L, (bf16_t*)nullptr, dts)
             if (reverse) PCAD_SEG(true, 0, false, 1, nullptr); else PCAD_SEG(false, 0, false, 1, nullptr);
@@ -516,8 +585,8 @@ hipError_t launch_scan(const void* u, const void* z, int64_t ldz, const void* de
                        const float* dbias, void* y, int S, int L, int E, bool reverse, int accumulate, int dt,
                        hipStream_t s, bool uyb, bool zblk, float* seg_ws, int walk_len, void* ysplit, bool dt_split, int policy_S) {
     if (zblk && !uyb) return hipErrorInvalidValue;
-    if (dt_split && !(dt == F32 && delta == nullptr && Rp % 16 == 0 && lddt % 8 == 0)) return hipErrorInvalidValue;   // bf16 [hi | lo | hi] x [hi | hi | lo]
-    if (ysplit && !(dt == F32 && delta == nullptr && uyb && zblk && L % 8 == 0 && ((int64_t)S * L + 7) / 8 * 8 * 3 * E * 2 < ((int64_t)1 << 32)))
+    if (dt_split && !(dt == F32 && delta == nullptr && Rp % 32 == 0 && Rp <= 96 && lddt % 8 == 0 && lddt >= 2 * Rp)) return hipErrorInvalidValue;   // bf16 [hi | lo] operands
+    if (ysplit && !(dt == F32 && delta == nullptr && uyb && zblk && L % 8 == 0 && ((int64_t)S * L + 7) / 8 * 8 * 2 * E * 2 < ((int64_t)1 << 32)))
         return hipErrorInvalidValue;        // the split output exists in the fp32 engine's compile-time-layout instantiation only
     if (S <= 0 || L <= 0) return hipSuccess;
     if (E % 64) return hipErrorInvalidValue;

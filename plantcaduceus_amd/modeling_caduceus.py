@@ -24,7 +24,7 @@ from transformers import PreTrainedModel
 from transformers.modeling_outputs import BaseModelOutputWithNoAttention, MaskedLMOutput
 
 from .checkpoint import load_state_dict, resolve_snapshot
-from .configuration_caduceus import CaduceusConfig
+from .configuration_caduceus import CaduceusConfig, config_from_dict
 from .engine import Engine
 
 
@@ -160,13 +160,7 @@ class CaduceusPreTrainedModel(PreTrainedModel):
         if config is None:
             with open(os.path.join(path, "config.json")) as f:
                 raw = json.load(f)
-            raw.pop("auto_map", None)
-            raw.pop("architectures", None)
-            raw.pop("model_type", None)
-            raw.pop("torch_dtype", None)
-            raw.pop("dtype", None)
-            raw.pop("transformers_version", None)
-            config = CaduceusConfig(**raw)
+            config = config_from_dict(raw)          # warns about keys it would otherwise ignore silently (strict audit: tools/real_weights.sh)
         want = dtype if dtype is not None else torch_dtype
         if isinstance(want, str):
             want = getattr(torch, want) if want != "auto" else None

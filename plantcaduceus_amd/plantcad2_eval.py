@@ -23,42 +23,98 @@ from typing import Dict, List, Optional, Sequence, Union
 import numpy as np
 import torch
 
+from . import sharding
 from .zero_shot import check_model_inputs, tokenize_masked
 
 NUCLEOTIDES_LOWER = ("a", "c", "g", "t")
 
 
+GATHER_CHUNK = 4096      # windows per rank between two all-gathers of the sharded loops (not per batch: one collective per chunk)
+
+
+def _sharded_rows(n_total: int, run_rows, out: np.ndarray, chunk: int = GATHER_CHUNK) -> np.ndarray:
+    """The reference's loops (`_masked_probs` / `_unmasked_probs`, src/zero-shot-eval.py:129-178) are single-device loops over
+    independent windows.  Here every rank evaluates its contiguous block of the `n_total` windows (sharding.shard_bounds, as the
+    zero-shot path does: SURVEY.md §8(e)) in chunks of at most `chunk` windows; after each chunk ONE all-gather hands every rank
+    every rank's rows of that chunk, which are copied to their single-process position in the host array `out` - so every rank
+    returns the rows in the single-GPU order and the row arithmetic is the single-GPU one (windows are independent).
+    run_rows(lo, hi) -> device tensor [hi - lo, ...] for the global rows [lo, hi) (hi == lo: an empty tensor of the right trailing
+    shape).  Every rank runs the same number of gathers (chunks are cut over the common block length; short tails are padded with
+    a dummy row that is stripped).  Outside a process group: a plain loop."""
+    rank, ws = sharding.world()
+    start, stop, per = sharding.shard_bounds(n_total, rank, ws)
+    grouped = ws > 1 or (torch.distributed.is_available() and torch.distributed.is_initialized())
+    for c0 in range(0, per, max(1, chunk)):
+        c1 = min(c0 + chunk, per)
+        lo, hi = min(start + c0, stop), min(start + c1, stop)
+        local = run_rows(lo, hi)
+        if not grouped:
+            out[lo:hi] = local.cpu().numpy()
+            continue
+        g = sharding.all_gather_blocks(sharding.pad_rows(local, c1 - c0)).cpu().numpy()
+        for r in range(ws):
+            a, b = r * per + c0, min(r * per + c1, n_total)
+            if b > a:
+                out[a:b] = g[r * (c1 - c0): r * (c1 - c0) + (b - a)]
+    return out
+
+
 def masked_probs(model, tokenizer, sequences: Sequence[str], mask_idx: Union[int, Sequence[int]], device,
                  batch_size: int = 128) -> np.ndarray:
+    """Sharded under torchrun: each rank tokenises and evaluates its own block of the sequences only; all ranks return all rows."""
     idx = sorted({int(mask_idx)} if isinstance(mask_idx, (int, np.integer)) else {int(i) for i in mask_idx})
     cols = [tokenizer.get_vocab()[n] for n in NUCLEOTIDES_LOWER]
-    ids_all = torch.from_numpy(tokenize_masked(list(sequences), tokenizer, None).astype(np.int64))
-    if ids_all.shape[0] and ids_all.shape[1] <= max(idx):
-        raise ValueError(f"mask index {max(idx)} out of range for sequence length {ids_all.shape[1]}")
-    ids_all[:, idx] = tokenizer.mask_token_id
+    seqs = list(sequences)
+    n = len(seqs)
     fast = bool(getattr(model, "supports_positions", False)) and len(idx) <= 16
-    out = []
-    with torch.inference_mode():
-        for b0 in range(0, ids_all.shape[0], batch_size):
-            cur = ids_all[b0:b0 + batch_size].to(device)
+
+    def run_rows(lo, hi):
+        if hi <= lo:
+            return torch.zeros((0, len(idx), 4), dtype=torch.float32, device=device)
+        ids = torch.from_numpy(tokenize_masked(seqs[lo:hi], tokenizer, None).astype(np.int64))
+        if ids.shape[1] <= max(idx):
+            raise ValueError(f"mask index {max(idx)} out of range for sequence length {ids.shape[1]}")
+        ids[:, idx] = tokenizer.mask_token_id
+        parts = []
+        for b0 in range(0, ids.shape[0], batch_size):
+            cur = ids[b0:b0 + batch_size].to(device)
             lg = model(input_ids=cur, positions=idx).logits if fast else model(input_ids=cur).logits[:, idx, :]
-            out.append(torch.softmax(lg[..., cols].float(), dim=-1).reshape(-1, 4).cpu().numpy())
-    check_model_inputs(model, collective=False)   # the engine validates token ids on the device; raise here, where results are read back (unsharded loop: local bits)
-    return np.vstack(out) if out else np.zeros((0, 4), dtype=np.float32)
+            parts.append(torch.softmax(lg[..., cols].float(), dim=-1))
+        return torch.cat(parts, dim=0)
+
+    if n and min(len(str(q)) for q in seqs) <= max(idx):          # the reference's index error, raised on EVERY rank before any collective
+        raise ValueError(f"mask index {max(idx)} out of range for sequence length {min(len(str(q)) for q in seqs)}")
+    out = np.zeros((n, len(idx), 4), dtype=np.float32)
+    with torch.inference_mode():
+        _sharded_rows(n, run_rows, out)
+    check_model_inputs(model)   # the engine validates token ids on the device; raise here, where results are read back (bits OR-ed over the ranks)
+    return out.reshape(-1, 4)
 
 
 def unmasked_probs(sequences: Sequence[str], tokenizer, model, device, batch_size: int = 32) -> np.ndarray:
+    """Sharded under torchrun like masked_probs; [n, L, 4] probabilities are gathered per chunk of <= GATHER_CHUNK windows per rank."""
     cols = [tokenizer.get_vocab()[n] for n in NUCLEOTIDES_LOWER]
     seqs = [str(s) for s in sequences]
     if len({len(s) for s in seqs}) > 1:
         raise ValueError("All sequences must have same length")
-    ids_all = torch.from_numpy(tokenize_masked(seqs, tokenizer, None).astype(np.int64))
-    out = np.zeros((len(seqs), ids_all.shape[1] if len(seqs) else 0, 4), dtype=np.float32)
+    L = len(seqs[0]) if seqs else 0
+
+    def run_rows(lo, hi):
+        if hi <= lo:
+            return torch.zeros((0, L, 4), dtype=torch.float32, device=device)
+        ids = torch.from_numpy(tokenize_masked(seqs[lo:hi], tokenizer, None).astype(np.int64))
+        parts = []
+        for b0 in range(0, ids.shape[0], batch_size):
+            lg = model(input_ids=ids[b0:b0 + batch_size].to(device)).logits[..., cols]
+            parts.append(torch.softmax(lg.float(), dim=-1))
+        return torch.cat(parts, dim=0)
+
+    out = np.zeros((len(seqs), L, 4), dtype=np.float32)
+    # [rows, L, 4] fp32 per rank and chunk on the device: bound the chunk by bytes as well (8 192-bp windows: 128 KiB per window)
+    chunk = max(1, min(GATHER_CHUNK, (1 << 30) // max(1, L * 16)))
     with torch.inference_mode():
-        for b0 in range(0, len(seqs), batch_size):
-            lg = model(input_ids=ids_all[b0:b0 + batch_size].to(device)).logits[..., cols]
-            out[b0:b0 + batch_size] = torch.softmax(lg.float(), dim=-1).cpu().numpy()
-    check_model_inputs(model, collective=False)
+        _sharded_rows(len(seqs), run_rows, out, chunk)
+    check_model_inputs(model)
     return out
 
 
@@ -228,12 +284,14 @@ def _probs_or_infer(df_col, model, tokenizer, device, idx, batch_size, logits_pa
     if model is None:
         raise ValueError("either a model or logits_path is needed")
     probs = masked_probs(model, tokenizer, list(df_col), idx, device, batch_size)
-    if save_logits:
+    if save_logits and sharding.world()[0] == 0:
         pd.DataFrame(probs, columns=list(NUCLEOTIDES)).to_csv(save_logits, sep="\t", index=False)
     return probs
 
 
 def _emit(metrics: Dict[str, float], metrics_json: Optional[str], extra: Optional[dict] = None) -> Dict[str, float]:
+    if sharding.world()[0] != 0:            # under torchrun every rank holds the full probabilities and computes the (cheap) metrics;
+        return metrics                      # rank 0 alone prints and writes
     for key, v in metrics.items():
         print(f"{key}\t{v:.6f}")
     if metrics_json:
@@ -302,13 +360,14 @@ def sv_effect(data, model, tokenizer, device="cuda:0", batch_size: int = 64, fla
         raise KeyError(f"Missing required columns: {missing}")
     ref_p = unmasked_probs(df["RefSeq"], tokenizer, model, device, batch_size)
     mut_p = unmasked_probs(df["MutSeq"], tokenizer, model, device, batch_size)
-    if save_ref_logits:
+    rank0 = sharding.world()[0] == 0
+    if save_ref_logits and rank0:
         np.savez_compressed(save_ref_logits, logits=ref_p)
-    if save_mut_logits:
+    if save_mut_logits and rank0:
         np.savez_compressed(save_mut_logits, logits=mut_p)
     scores = sv_llr_boundary(df["left"], df["right"], df["MutSeq"], ref_p, mut_p, flanking)
     res = _emit({"AUPRC": average_precision(df["label"].astype(int).to_numpy(), scores)}, None)
-    if output:
+    if output and rank0:
         out = df.copy()
         out["score"] = scores
         out.drop(columns=["Left5_Positions", "Right5_Positions"], errors="ignore").to_csv(output, sep="\t", index=False)
@@ -364,21 +423,27 @@ def main(argv: Optional[Sequence[str]] = None):
     logging.basicConfig(level=logging.INFO, format="%(asctime)s %(levelname)s %(message)s")
     if a.data is None and not (a.repo_id and a.task):
         p.error("give --data <table> or --repo_id and --task")
-    data = a.data if a.data is not None else (a.repo_id, a.task, a.split)
-    need_model = a.cmd == "sv_effect" or getattr(a, "logits_path", None) is None
-    model, tok = _load_model(a.model, a.device) if need_model else (None, None)
-    if a.cmd == "evo_cons":
-        return evo_cons(data, model, tok, a.device, token_idx=a.token_idx, batch_size=a.batch_size, seq_column=a.seq_column,
-                        save_logits=a.save_logits, logits_path=a.logits_path, metrics_json=a.metrics_json)
-    if a.cmd == "motif_acc":
-        return motif_acc(data, model, tok, a.device, mask_idx=a.mask_idx, motif_len=a.motif_len, batch_size=a.batch_size,
-                         seq_column=a.seq_column, save_logits=a.save_logits, logits_path=a.logits_path, metrics_json=a.metrics_json)
-    if a.cmd == "core_noncore":
-        return core_noncore(data, model, tok, a.device, mask_idx=a.mask_idx, motif_len=a.motif_len, batch_size=a.batch_size,
-                            seq_column=a.seq_column, label_column=a.label_column, save_logits=a.save_logits,
-                            logits_path=a.logits_path, metrics_json=a.metrics_json)
-    return sv_effect(data, model, tok, a.device, batch_size=a.batch_size, flanking=a.flanking, output=a.output,
-                     save_ref_logits=a.save_ref_logits, save_mut_logits=a.save_mut_logits)
+    # under `torchrun --nproc-per-node N` the windows of every task are sharded over the N GPUs (masked_probs / unmasked_probs);
+    # rank 0 prints the metric lines and writes the files
+    a.device = sharding.init_from_env(a.device)
+    try:
+        data = a.data if a.data is not None else (a.repo_id, a.task, a.split)
+        need_model = a.cmd == "sv_effect" or getattr(a, "logits_path", None) is None
+        model, tok = _load_model(a.model, a.device) if need_model else (None, None)
+        if a.cmd == "evo_cons":
+            return evo_cons(data, model, tok, a.device, token_idx=a.token_idx, batch_size=a.batch_size, seq_column=a.seq_column,
+                            save_logits=a.save_logits, logits_path=a.logits_path, metrics_json=a.metrics_json)
+        if a.cmd == "motif_acc":
+            return motif_acc(data, model, tok, a.device, mask_idx=a.mask_idx, motif_len=a.motif_len, batch_size=a.batch_size,
+                             seq_column=a.seq_column, save_logits=a.save_logits, logits_path=a.logits_path, metrics_json=a.metrics_json)
+        if a.cmd == "core_noncore":
+            return core_noncore(data, model, tok, a.device, mask_idx=a.mask_idx, motif_len=a.motif_len, batch_size=a.batch_size,
+                                seq_column=a.seq_column, label_column=a.label_column, save_logits=a.save_logits,
+                                logits_path=a.logits_path, metrics_json=a.metrics_json)
+        return sv_effect(data, model, tok, a.device, batch_size=a.batch_size, flanking=a.flanking, output=a.output,
+                         save_ref_logits=a.save_ref_logits, save_mut_logits=a.save_mut_logits)
+    finally:
+        sharding.shutdown()
 
 
 if __name__ == "__main__":

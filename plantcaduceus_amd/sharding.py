@@ -99,6 +99,14 @@ def _all_gather(local: torch.Tensor, ws: int) -> torch.Tensor:
     return out
 
 
+def all_gather_blocks(local: torch.Tensor) -> torch.Tensor:
+    """local [rows, ...] (the same `rows` on every rank) -> [world * rows, ...] in rank order (nothing stripped): the raw collective
+    for callers that place the blocks themselves (plantcad2_eval's chunked gathers).  Outside a process group: `local`."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return local
+    return _all_gather(local, dist.get_world_size())
+
+
 def all_gather_rows(local: torch.Tensor, n_total: int) -> torch.Tensor:
     """local [per_rank, ...] (equal on every rank) -> [n_total, ...] in rank order, padding stripped."""
     rank, ws = world()

@@ -142,7 +142,10 @@ def _has_vocab(model_dir: str) -> bool:
 def effective_batch(model, batch_size: int, seqlen: int, explicit: bool = False) -> int:
     """Windows per forward call.  `-batchSize` is how the reference's user bounds memory, so a value the user PASSED is kept;
     the default (128, src/zero_shot_score.py:28) is raised to what the model advertises (`preferred_batch_size`: the HIP engine's
-    two full chunks, 1024 windows at l32) — windows are independent, so only launch count and workspace size depend on it."""
+    two full chunks, 1024 windows at l32) — windows are independent, so launch count and workspace size depend on it and, for
+    calls of only a few windows (at most 8 of 512 bp at l32), the engine's small-launch forms (segmented scan, conv + x_proj K-split:
+    include/pcad.h "scan_segments"), whose fp32 summation order differs from the large-batch walk: results of two runs that cut the
+    same windows into different batches (one GPU vs eight) agree to fp32 rounding, bit for bit with `engine_options={"scan_segments": 0}`."""
     if explicit:
         return int(batch_size)
     pref = getattr(model, "preferred_batch_size", None)

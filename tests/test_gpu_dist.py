@@ -54,7 +54,10 @@ def _visible_gpus():
 def test_rccl_multi_rank_equals_single_rank(world, tmp_path):
     """`world` ranks on `world` devices: each runs its block of the 185 example windows through the HIP engine, ONE
     all_gather_into_tensor over RCCL/xGMI per result; every rank must hold the full [185, 4] / [185, D] result, bit-identical to
-    the one-rank run, and the ranks must report `world` distinct devices on the nccl backend."""
+    the one-rank run, and the ranks must report `world` distinct devices on the nccl backend.  Also the sharded PlantCAD2 loops
+    (masked_probs at three positions of 37 windows, unmasked_probs of 21 windows; one gather per 3-window chunk).  The worker's
+    engine runs with "scan_segments" 0 so that per-call batch sizes (which differ between world 1 and world N) do not select
+    different small-launch forms (fp32 summation order)."""
     if _visible_gpus() < world:
         pytest.skip(f"needs {world} GPUs, {_visible_gpus()} visible")
     worker = os.path.join(ROOT, "tests", "_rccl_worker.py")
@@ -71,10 +74,11 @@ def test_rccl_multi_rank_equals_single_rank(world, tmp_path):
     assert sorted(x["rank"] for x in reports) == list(range(world))
     assert all(x["world"] == world and x["backend"] == "nccl" for x in reports)
     assert len({x["device"] for x in reports}) == world, reports            # one device per rank
+    assert ref["mp3"].shape == (37 * 3, 4) and ref["un"].shape == (21, 512, 4)
     for k in range(world):
         got = np.load(dn / f"r{k}.npz")
-        np.testing.assert_array_equal(got["p"], ref["p"])
-        np.testing.assert_array_equal(got["e"], ref["e"])
+        for key in ("p", "e", "mp3", "un"):
+            np.testing.assert_array_equal(got[key], ref[key])
 
 
 def test_rccl_worker_world1(tmp_path):
@@ -87,6 +91,8 @@ def test_rccl_worker_world1(tmp_path):
     got = np.load(tmp_path / "r0.npz")
     assert got["p"].shape == (185, 4) and got["e"].shape == (185, 128) and np.isfinite(got["p"]).all()
     np.testing.assert_allclose(got["p"].sum(1), 1.0, rtol=1e-5)
+    assert got["mp3"].shape == (111, 4) and got["un"].shape == (21, 512, 4)
+    np.testing.assert_allclose(got["un"].sum(-1), 1.0, rtol=1e-5)
 
 
 @pytest.mark.parametrize("world", [2, 4, 8])

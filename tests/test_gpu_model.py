@@ -422,7 +422,7 @@ def test_f32_gemm_split_matches_oracle(D, nl, B, L):
     assert torch.equal(m2(input_ids=ids.to(DEV)).logits.cpu(), lg)
     m3 = build(cfg, sd, torch.float32, f32_gemm_split=1, reference_order=2)
     assert ((m3(input_ids=ids.to(DEV)).logits.cpu() - ref["logits"]).abs().max() / ref["logits"].abs().max()).item() < 1e-4
-    # unsegmented scans (what large batches run): the reverse scan writes out_proj's [hi | lo | hi] operand itself when L % 8 == 0
+    # unsegmented scans (what large batches run): the reverse scan writes out_proj's [hi | lo] operand itself when L % 8 == 0
     m4 = build(cfg, sd, torch.float32, f32_gemm_split=1, scan_segments=0)
     out4 = m4(input_ids=ids.to(DEV), output_hidden_states=True)
     assert ((out4.logits.cpu() - ref["logits"]).abs().max() / ref["logits"].abs().max()).item() < 1e-4

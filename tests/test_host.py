@@ -281,7 +281,32 @@ def test_bench_work_formulas_match_survey_8d():
     assert abs(en["energy_J_per_window"] - 1.0) < 1e-12 and en["max_power_W"] == 1400.0 and en["samples"] == 3
     ps.samples = []
     assert ps.summary(1.0, 1) is None
-    assert bench.CPU_REPEATS >= 2
+    assert bench.CPU_REPEATS >= 2 and bench.CPU_MIN_SEQS >= 16 and bench.CPU_BUDGET_S <= 30.0
+
+
+def test_bench_host_peak_estimate_arithmetic():
+    """cpu_baseline.host_peak_gflops_est / frac_of_host_peak (bench.host_peak_from_cpuinfo): physical cores x FMA lanes x 2 flop x
+    2 ports x clock, from /proc/cpuinfo text - two sockets of two hyper-threaded AVX-512 cores at 2.5 GHz = 4 x 64 x 2.5 = 640 GFLOP/s;
+    an AVX2 part without cpufreq falls back to the largest 'cpu MHz' line."""
+    import bench
+
+    def cpu(i, phys, core, mhz, flags):
+        return ("processor\t: %d\nmodel name\t: Test CPU @ 2.00GHz\ncpu MHz\t\t: %s\nphysical id\t: %d\ncore id\t\t: %d\nflags\t\t: %s\n\n"
+                % (i, mhz, phys, core, flags))
+    f512 = "fpu sse sse2 avx avx2 fma avx512f avx512bw"
+    txt = "".join(cpu(i, i // 4, (i % 4) // 2, "1800.000", f512) for i in range(8))       # 8 threads = 2 sockets x 2 cores x 2 threads
+    hp = bench.host_peak_from_cpuinfo(txt, max_khz=2.5e6)
+    assert hp["physical_cores"] == 4 and hp["threads"] == 8 and hp["isa"] == "avx512f" and hp["flop_per_cycle_per_core"] == 64
+    assert abs(hp["host_peak_gflops_est"] - 640.0) < 1e-9 and hp["clock_source"].startswith("cpufreq")
+    txt2 = "".join(cpu(i, 0, i, "%d.000" % (2000 + 100 * i), "fpu sse sse2 avx avx2 fma") for i in range(4))
+    hp2 = bench.host_peak_from_cpuinfo(txt2)
+    assert hp2["physical_cores"] == 4 and hp2["isa"] == "avx2+fma" and hp2["flop_per_cycle_per_core"] == 32
+    assert abs(hp2["host_peak_gflops_est"] - 4 * 32 * 2.3) < 1e-9 and hp2["clock_GHz"] == 2.3
+    hp3 = bench.host_peak_from_cpuinfo("model name\t: Old CPU @ 3.00GHz\nflags\t\t: fpu sse sse2\n")
+    assert hp3["physical_cores"] == 1 and hp3["isa"] == "sse" and abs(hp3["host_peak_gflops_est"] - 1 * 8 * 3.0) < 1e-9
+    live = bench.host_peak_estimate()                      # this host: finite, positive, consistent with its own fields
+    assert live["host_peak_gflops_est"] > 0
+    assert abs(live["host_peak_gflops_est"] - live["physical_cores"] * live["flop_per_cycle_per_core"] * live["clock_GHz"]) < 0.1 * live["host_peak_gflops_est"]
 
 
 def test_effective_batch_keeps_an_explicit_batch_size():

@@ -110,6 +110,59 @@ def test_multi_rank_gather_equals_single_rank(tmp_path, ws, n):
         np.testing.assert_allclose(embeddings.extract_embeddings(model, seqs, "cpu", 11, tok, batch_size=16), r0["e"], rtol=1e-6, atol=1e-7)
 
 
+def _pc2_setup(n, L=24):
+    from oracle import caduceus_oracle as O
+    from plantcaduceus_amd.checkpoint import make_config, synthetic_state_dict
+    from plantcaduceus_amd.tokenization_caduceus import CaduceusTokenizer
+    cfg = make_config("x", d_model=32, n_layer=1)
+    model = O.OracleForMaskedLM(O.params_from_state_dict(synthetic_state_dict(cfg, seed=2), cfg))
+    model.config = cfg
+    rng = np.random.default_rng(3)
+    seqs = ["".join(rng.choice(list("ACGT"), size=L)) for _ in range(n)]
+    return model, CaduceusTokenizer(), seqs
+
+
+def _pc2_worker(rank, ws, port, n, chunk, outdir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=ws)
+    try:
+        from plantcaduceus_amd import plantcad2_eval as pe
+        torch.set_num_threads(1)
+        pe.GATHER_CHUNK = chunk                          # several gathers per call (the shipped chunk is 4 096 windows per rank)
+        model, tok, seqs = _pc2_setup(n)
+        seen = []
+        enc = tok.encode_batch
+        tok.encode_batch = lambda ss, mask_index=None: (seen.append(len(ss)), enc(ss, mask_index=mask_index))[1]
+        m1 = pe.masked_probs(model, tok, seqs, 11, "cpu", batch_size=4)
+        m3 = pe.masked_probs(model, tok, seqs, [13, 11, 12], "cpu", batch_size=5)
+        un = pe.unmasked_probs(seqs, tok, model, "cpu", batch_size=4)
+        a, b, _ = sharding.shard_bounds(n, rank, ws)
+        assert sum(seen) == 3 * (b - a), (seen, a, b)    # each rank tokenises its own block only, once per call
+        np.savez(os.path.join(outdir, f"q{rank}.npz"), m1=m1, m3=m3, un=un)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("ws,n,chunk", [(2, 11, 3), (4, 11, 2), (4, 3, 4096), (2, 0, 4)])
+def test_plantcad2_loops_sharded_equal_single_process(tmp_path, ws, n, chunk):
+    """plantcad2_eval.masked_probs / unmasked_probs (reference src/zero-shot-eval.py:129-178, single-device loops) under a process
+    group: every rank evaluates its block, ONE all-gather per chunk of windows (chunk forced small here: several gathers, ragged
+    last chunk, ranks with no rows at all), every rank returns all rows - bit-equal to the single-process run, in its order."""
+    mp.spawn(_pc2_worker, args=(ws, _free_port(), n, chunk, str(tmp_path)), nprocs=ws, join=True)
+    from plantcaduceus_amd import plantcad2_eval as pe
+    model, tok, seqs = _pc2_setup(n)
+    ref = dict(m1=pe.masked_probs(model, tok, seqs, 11, "cpu", batch_size=4), m3=pe.masked_probs(model, tok, seqs, [13, 11, 12], "cpu", batch_size=5),
+               un=pe.unmasked_probs(seqs, tok, model, "cpu", batch_size=4))
+    assert ref["m1"].shape == (n, 4) and ref["m3"].shape == (3 * n, 4) and ref["un"].shape == (n, 24 if n else 0, 4)
+    for r in range(ws):
+        got = np.load(tmp_path / f"q{r}.npz")
+        for k in ("m1", "m3", "un"):
+            if n:
+                np.testing.assert_allclose(got[k], ref[k], rtol=1e-6, atol=1e-7)     # batch composition differs -> BLAS summation order may
+            assert got[k].shape == ref[k].shape
+            np.testing.assert_array_equal(got[k], np.load(tmp_path / "q0.npz")[k])    # all ranks hold identical arrays
+
+
 @pytest.mark.gpu
 def test_rccl_all_gather_branch_single_rank():
     """the GPU branch of sharding.all_gather_rows (dist.all_gather_into_tensor over RCCL) executed once: world 1 on cuda:0.

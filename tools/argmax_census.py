@@ -160,8 +160,94 @@ def census_from_fixture(model, fixture, batch=None, out=print):
     return res
 
 
+def census_on_snapshot(snapshot, tsv=None, n_seeded=2048, n_emul=256, out=print, use_gpu=None, oracle_block=64):
+    """The census on a REAL snapshot directory (config.json + weights under the reference's key names) - tools/real_weights.sh step
+    (ii): the windows of the reference's example table (examples/example_snp.tsv -> tests/golden/example_snp.tsv, the rows
+    src/zero_shot_score.py:232 keeps) plus `n_seeded` seeded uniform windows, all masked at 255, through
+      the fp32 C oracle (every window) and its reference-order bf16 emulation (the first `n_emul` of each set),
+      the HIP engine as bf16 in its three operation orders, as fp32 and as fp32 + "f32_gemm_split" (when a ROCm device is present),
+    reporting per set: differing 4-way calls, max |dp|, the oracle margins of the differing windows, the margin histogram - on a
+    TRAINED model, whose margins are not the synthetic checkpoint's (profiles/r05_argmax_census_*.txt).  Returns the numbers."""
+    import json
+    import numpy as np
+    import pandas as pd
+    import torch
+    from oracle.c_oracle import COracle
+    from plantcaduceus_amd.checkpoint import load_state_dict
+    from plantcaduceus_amd.configuration_caduceus import config_from_dict
+    from plantcaduceus_amd.tokenization_caduceus import CaduceusTokenizer
+    cfg = config_from_dict(json.load(open(os.path.join(snapshot, "config.json"))))
+    sd = load_state_dict(snapshot)
+    tok = CaduceusTokenizer.from_pretrained(snapshot) if os.path.exists(os.path.join(snapshot, "vocab.json")) else CaduceusTokenizer()
+    sets = {}
+    tsv = tsv or os.path.join(ROOT, "tests", "golden", "example_snp.tsv")
+    if os.path.exists(tsv):
+        df = pd.read_csv(tsv, delimiter="\t")
+        df = df[df["ref"].isin(list("ACGT")) & df["alt"].isin(list("ACGT"))]
+        sets["example table (%d rows of %s)" % (len(df), os.path.basename(tsv))] = tok.encode_batch(df["sequences"].tolist(), mask_index=P).astype(np.int32)
+    if n_seeded > 0:
+        ids = np.random.default_rng(0).integers(3, 7, size=(n_seeded, 512)).astype(np.int32)
+        ids[:, P] = tok.mask_token_id
+        sets["%d seeded uniform windows (default_rng(0))" % n_seeded] = ids
+    gpu = torch.cuda.is_available() if use_gpu is None else bool(use_gpu)
+    out(f"== arg-max census on snapshot {snapshot}: d_model={cfg.d_model}, n_layer={cfg.n_layer}, mask index {P}; engine rows "
+        + ("on cuda:0" if gpu else "SKIPPED (no ROCm device: oracle-vs-oracle rows only)"))
+
+    def oracle(ids, **kw):
+        co = COracle(sd, cfg, blas=True, **kw)
+        return softmax4(np.concatenate([co.forward(ids[b0:b0 + oracle_block])[0][:, P, 3:7] for b0 in range(0, len(ids), oracle_block)], 0))
+
+    def hip(ids, dtype, **opts):
+        from plantcaduceus_amd.modeling_caduceus import CaduceusForMaskedLM
+        cfg.engine_options = dict(opts)
+        m = CaduceusForMaskedLM(cfg)
+        m.load_state_dict(sd, strict=False)
+        m.tie_weights()
+        m = m.to(dtype).to("cuda:0")
+        lg = np.concatenate([m(input_ids=torch.from_numpy(ids[b0:b0 + 1024]).to("cuda:0"), positions=[P]).logits[:, 0].float().cpu().numpy()
+                             for b0 in range(0, len(ids), 1024)], 0)
+        m.check_status()
+        del m
+        torch.cuda.empty_cache()
+        return softmax4(lg[:, 3:7])
+
+    res = {}
+    edges = [0, 1e-3, 2e-3, 5e-3, 1e-2, 2e-2, 5e-2, 1e-1, 0.5, 1.0]
+    for name, ids in sets.items():
+        t0 = time.time()
+        p32 = oracle(ids)
+        ne = min(n_emul, len(ids))
+        pref = oracle(ids[:ne], dtype=torch.bfloat16, emulate_bf16=True, ref_order=True) if ne else None
+        out(f"-- {name}: fp32 oracle + reference-order bf16 emulation of the first {ne}: {time.time() - t0:.0f} s")
+        h, _ = np.histogram(margins(p32), bins=edges)
+        out("   fp32 oracle's top-2 probability margin, windows per bin: " + ", ".join(f"[{edges[i]:g},{edges[i+1]:g}): {h[i]}" for i in range(len(h)))
+            + f"; median top probability {float(np.median(p32.max(1))):.3f}")
+        r = {"n": len(ids), "margin_hist": h.tolist(), "rows": {}}
+        rows = []
+        if pref is not None:
+            rows.append(("reference-order bf16 emulation vs fp32 oracle (no GPU)", compare(pref, p32[:ne])))
+        if gpu:
+            for mode, opts in MODES:
+                pb = hip(ids, torch.bfloat16, **opts)
+                rows.append((f"HIP bf16 {mode} vs fp32 oracle", compare(pb, p32)))
+                if pref is not None:
+                    rows.append((f"HIP bf16 {mode} vs reference-order emulation", compare(pb[:ne], pref)))
+            rows.append(("HIP fp32 vs fp32 oracle", compare(hip(ids, torch.float32), p32)))
+            rows.append(("HIP fp32 + f32_gemm_split vs fp32 oracle", compare(hip(ids, torch.float32, f32_gemm_split=1), p32)))
+        for what, c in rows:
+            out(f"   {what}: {len(c['flips'])} of {c['n']} calls differ, max |dp| {c['max_dp']:.3e}"
+                + (f"; oracle margins of the differing windows {[float(f'{m:.2e}') for m in c['flip_margins']]}" if len(c["flips"]) else ""))
+            r["rows"][what] = {"n": c["n"], "flips": len(c["flips"]), "max_dp": c["max_dp"]}
+        res[name] = r
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--snapshot", default=None, help="a real snapshot directory: census of the example table's windows + --n-seeded seeded windows "
+                    "on its (trained) weights against the fp32 oracle (tools/real_weights.sh step ii) instead of parts 1 and 2")
+    ap.add_argument("--tsv", default=None, help="with --snapshot: the table whose `sequences` are scored (default tests/golden/example_snp.tsv)")
+    ap.add_argument("--n-seeded", type=int, default=2048)
     ap.add_argument("--n", type=int, default=128)
     ap.add_argument("--n-emul", type=int, default=64)
     ap.add_argument("--n-stress", type=int, default=8)
@@ -170,6 +256,9 @@ def main():
                     "(three engine operation orders; no oracle run) instead of parts 1 and 2")
     ap.add_argument("--batch", type=int, default=0, help="with --fixture: windows per forward (0: all at once)")
     args = ap.parse_args()
+    if args.snapshot:
+        census_on_snapshot(args.snapshot, tsv=args.tsv, n_seeded=args.n_seeded, n_emul=args.n_emul if args.n_emul != 64 else 256)
+        return
     if args.fixture:
         census_from_fixture(args.model, args.fixture, batch=args.batch or None)
         return
