@@ -143,6 +143,14 @@ void   pcad_destroy(pcad_handle h);
  *                 batches; at most 512 for shorter windows: up to 8 windows of 512 bp at l32) the scan of every strand is cut into up to 8 (short windows: 16, of at least 32 steps) segments that run as
  *                 separate workgroups (zero-state pass, carry, real pass: ~1.8x the arithmetic for up to 8x the parallelism;
  *                 results equal up to fp32 rounding of the carried decay product);  0: one workgroup walks the whole strand.
+ *                 Launches with more waves than that but at most 3 584 per direction (3.5 per SIMD: 32 windows of 8 192 bp at the
+ *                 PlantCAD2 Medium / Large widths, up to 56 windows of 512 bp at l32) take the PAIR form instead (round 6): both
+ *                 directions of a layer run in one launch and walk half a strand per launch - forward rows [0, L/2) with reverse rows
+ *                 [L/2, L), then the other halves from the kept states, each adding what the other direction's first launch left and
+ *                 gating: twice the waves per launch, the same arithmetic, no extra pass (L % 64 == 0; never the last layer, whose
+ *                 walks "last_layer_shortcut" shortens).  Against the plain two-launch form the bf16 model's gate-once sum is rounded
+ *                 at the other direction's partial on half of the rows: equal to bf16 rounding of one addend (fp32: summation order;
+ *                 bf16 with "gate_each" / "reference_order" >= 1: bit-identical).  +13 % at 32 x 8 192 bp (Medium), +12 % at 16 x 512 bp.
  *                 The same switch governs the K-split of the fused conv + x_proj kernel for launches of at most 64 row tiles (up to 8
  *                 windows of 512 bp): several blocks per row tile each walk a share of the channels and a second tiny kernel adds
  *                 their partial x_proj sums in a fixed order (deterministic; another fp32 summation order than the unsplit walk).

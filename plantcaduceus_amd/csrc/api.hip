@@ -178,6 +178,7 @@ struct Workspace {
     float* bc[2];
     float *rstd, *ssq;   // norm-folded form: rstd [rows]; partial sums of squares [rows, D / 128]
     float* seg;      // segmented-scan scratch (long sequences with few strands), or nullptr
+    float* pair;     // state hand-over of the pair walks (kernels.hpp scan_pair_wanted), or nullptr
     float* cxp;      // K-split scratch of the fused conv + x_proj kernel (small launches), or nullptr
     size_t bytes;
 };
@@ -213,6 +214,8 @@ Workspace carve_workspace(const pcad_engine* e, void* base, int Bc, int L, int B
     w.ssq = (float*)c.take(rows * (Dp / 128) * 4);
     const size_t segb = e->segments ? scan_segment_bytes(2 * Bc, L, (int)E, 2 * Bpol) : 0;
     w.seg = segb ? (float*)c.take(segb) : nullptr;
+    const size_t pairb = e->segments && e->convx && scan_pair_wanted(2 * Bpol, L, (int)E) ? scan_pair_bytes(2 * Bc, (int)E) : 0;
+    w.pair = pairb ? (float*)c.take(pairb) : nullptr;
     // small launches: the conv + x_proj kernel splits its channel walk over several blocks per row tile ("scan_segments" 0 turns this
     // off together with the segmented scan: both trade a different fp32 summation order for parallelism on an otherwise empty chip)
     const size_t cxb = e->segments && e->convx ? convx_split_bytes(2 * Bc, L, (int)E, e->cfg.dtype, e->Rp, 2 * Bpol) : 0;
@@ -678,7 +681,23 @@ static int forward_impl(pcad_handle h, const int32_t* ids, int B, int L, const i
             }
             return launch_gemm_nt(ysrc, E, W.W_out, E, dst, D, rows, D, E, dt, dt, false, s, e->blocked);
         };
-        for (int d = 0; d < 2; ++d) {
+        // Pair walks (kernels.hpp scan_pair_wanted: few waves per launch - long windows in small batches): both directions in one
+        // launch, half a strand each, twice; chosen from the strands of the whole call like the segmented form
+        // (never the LAST layer: with a list of positions its walks are shortened plain walks - "last_layer_shortcut" - and the full
+        // layer must stay bit-identical to them on the evaluated rows)
+        const bool pair = c.w.pair && !strict && li + 1 < e->nl && e->convx && ((int64_t)rows + 16) * E * esz < ((int64_t)1 << 32) &&
+                          scan_pair_wanted(2 * B, L, E) && reps(PCAD_K_SCAN) == 1;
+        if (pair) {
+            const DirWeights &d0 = W.dir[0], &d1 = W.dir[1];
+            const ScanDirection f{c.w.xc[0], c.w.dtl[0], dts ? d0.Wdt_s : d0.Wdt, c.w.bc[0], d0.A2, d0.Dskip, d0.dt_bias};
+            const ScanDirection r{c.w.xc[1], c.w.dtl[1], dts ? d1.Wdt_s : d1.Wdt, c.w.bc[1], d1.A2, d1.Dskip, d1.dt_bias};
+            for (int ph = 1; ph <= 2; ++ph) {
+                ProfScope ps(e, PCAD_K_SCAN, s);
+                HIP_TRY(launch_scan_pair(f, r, c.w.zb, dts ? 2 * Rp : Rp, Rp, c.w.y, S, L, E, !e->gate_once, dt, s, c.w.pair,
+                                         ys_from_scan ? c.w.ys : nullptr, dts, ph));
+            }
+        }
+        for (int d = 0; d < 2 && !pair; ++d) {
             const DirWeights& dw = W.dir[d];
             // x_proj -> dt_low [rows, Rp] (model dtype, zero padded) and B_t | C_t [rows, 32] (fp32 side output)
             if (!(e->convx && ((int64_t)rows + 16) * E * esz < ((int64_t)1 << 32))) { ProfScope ps(e, PCAD_K_GEMM_X, s);

@@ -755,11 +755,13 @@ __global__ __launch_bounds__(GEMMQ_THREADS, 1) void gemm256q_kernel(const T* __r
     // (back to column 0 after 2 ksplit tiles), W reads hi, hi, lo (back to column 0 after ksplit tiles).  Against the concatenated
     // [hi | lo | hi] x [hi | hi | lo] form the producers write a third less, the operands take a third less memory and HBM traffic
     // (the second visit of a part is served by the L2 / Infinity Cache), and the in-tensor offsets allow 1.5x larger chunks.
+    // The memory K-tile index is derived from the (wave-uniform, scalar) cursor a_kt / w_kt at every use - a separately carried index
+    // was placed in a VGPR by the compiler and every LDS-DMA then ran in a waterfall loop (-15 % on the whole GEMM).
     constexpr bool KSPLIT = !std::is_same<T, OutT>::value;
-    int a_kx = 0, w_kx = 0;                           // K-tile INDEX in memory of the cursors (== a_kt / w_kt without the wrap)
-    const int a_wrap = KSPLIT && ksplit ? 2 * ksplit : -1, w_wrap = KSPLIT && ksplit ? ksplit : -1;
+    const int a_wrap = KSPLIT && ksplit ? 2 * ksplit : 0x7fffffff, w_wrap = KSPLIT && ksplit ? ksplit : 0x7fffffff;
     auto a_piece = [&](int sa, int p) __attribute__((always_inline)) {               // piece p of A(a_g) -> A stage sa
-        const uint32_t soff = a_base + (uint32_t)(KSPLIT ? a_kx : a_kt) * (a_blocked ? 1024u : (uint32_t)ROWB);
+        const int a_kx = KSPLIT ? (a_kt >= a_wrap ? a_kt - a_wrap : a_kt) : a_kt;
+        const uint32_t soff = a_base + (uint32_t)a_kx * (a_blocked ? 1024u : (uint32_t)ROWB);
         blds16(A, a_lo[p], soff, smem + sa * A2_BYTES + (wave * 64 + p * 8) * ROWB);
     };
     auto a_issue = [&](int sa) __attribute__((always_inline)) {
@@ -767,7 +769,8 @@ __global__ __launch_bounds__(GEMMQ_THREADS, 1) void gemm256q_kernel(const T* __r
         for (int p = 0; p < 8; ++p) a_piece(sa, p);
     };
     auto w_piece = [&](int sw, int p) __attribute__((always_inline)) {
-        const uint32_t soff = w_base + (uint32_t)(KSPLIT ? w_kx : w_kt) * (uint32_t)ROWB;
+        const int w_kx = KSPLIT ? (w_kt >= w_wrap ? w_kt - w_wrap : w_kt) : w_kt;
+        const uint32_t soff = w_base + (uint32_t)w_kx * (uint32_t)ROWB;
         blds16(W, w_lo[p], soff, smem + GEMM3_OFF_W + sw * W2_BYTES + (wave * 64 + p * 8) * ROWB);
     };
     auto w_issue = [&](int sw) __attribute__((always_inline)) {
@@ -777,7 +780,6 @@ __global__ __launch_bounds__(GEMMQ_THREADS, 1) void gemm256q_kernel(const T* __r
     auto a_advance = [&]() __attribute__((always_inline)) {
         if (a_g + 1 < G) {
             ++a_g;
-            if constexpr (KSPLIT) { ++a_kx; if (a_kt + 1 == a_wrap || a_kt + 1 == nkt) a_kx = 0; }
             if (++a_kt == nkt) {
                 a_kt = 0;
                 a_tile += gstride;
@@ -790,7 +792,6 @@ __global__ __launch_bounds__(GEMMQ_THREADS, 1) void gemm256q_kernel(const T* __r
     auto w_advance = [&]() __attribute__((always_inline)) {
         if (w_g + 1 < G) {
             ++w_g;
-            if constexpr (KSPLIT) { ++w_kx; if (w_kt + 1 == w_wrap || w_kt + 1 == nkt) w_kx = 0; }
             if (++w_kt == nkt) {
                 w_kt = 0;
                 w_tile += gstride;

@@ -175,6 +175,28 @@ inline size_t scan_segment_bytes(int S, int L, int E, int policy_S = 0) {
     return G > 1 ? (size_t)S * G * E * 17 * sizeof(float) : 0;        // [S][G][E][16] states + [S][G][E] delta sums
 }
 
+// "Pair" walks (launches with few waves - PlantCAD2's 8 192-bp windows in batches of a few dozen, 512-bp windows in batches of a few
+// dozen: at most 3.5 waves per SIMD; at 2 the VALU idles a third of the time): both directions of the layer in ONE launch, each
+// walking half of its strand per launch - launch 1: forward rows [0, L/2) and reverse rows [L/2, L) from zero states, outputs ungated
+// (or each gated, "gate_each"), end states kept; launch 2: the second halves from those states, each adding what the OTHER direction's
+// first launch left in y and gating.  Twice the waves per launch, the same arithmetic, no extra pass.  Against the plain two-launch
+// form the bf16 model's gate-once sum is rounded at the other direction's partial on half of the rows (y_rev stored, y_fwd added in
+// fp32, instead of the reverse): results of a pair walk and of a plain walk agree to bf16 rounding of one addend (fp32 model: to fp32
+// summation order), exactly as the segmented form does - and the form is chosen like it: from the strands of the whole pcad_forward
+// call, governed by "scan_segments".
+struct ScanDirection { const void *u, *dt_low, *Wdt; const float *bc, *A2, *Dskip, *dbias; };
+inline bool scan_pair_wanted(int S, int L, int E) {
+    const int64_t waves = (int64_t)S * (E / 64);
+    static const int64_t max_waves = [] { const char* v = dev_env("PCAD_PAIR_MAX_WAVES"); return v ? (int64_t)atoll(v) : (int64_t)3584; }();   // PCAD_DEV=1 A/B knob
+    return L % 64 == 0 && L >= 128 && waves > 0 && waves <= max_waves && scan_segments(S, L, E, nullptr) == 1;
+}
+inline size_t scan_pair_bytes(int S, int E) { return (size_t)2 * S * 2 * E * 16 * sizeof(float); }     // [dir][S][2][E][16] states
+// u / y / z blocked [S*L (8-row padded), E]; dt_low [S*L, lddt]; Wdt [E, Rp] (dt_split: bf16 [hi | lo] operands as in launch_scan);
+// A2 pre-scaled by log2(e); ws: scan_pair_bytes(S, E); ysplit (fp32 + f32_gemm_split): the gated output as out_proj's [hi | lo] operand.
+hipError_t launch_scan_pair(const ScanDirection& fwd, const ScanDirection& rev, const void* z, int64_t lddt, int Rp, void* y, int S, int L, int E,
+                            bool gate_each, int dt, hipStream_t s, float* ws, void* ysplit = nullptr, bool dt_split = false,
+                            int phases = 3);       // bit 0: the first-half launch, bit 1: the second-half launch
+
 // pack.hip --------------------------------------------------------------------------------------
 // rows (strand b, p_q) and (strand B + b, L - 1 - p_q) of a [2B*L, E] activation tensor (plain or blocked) -> out[(strand * P + q), E]
 hipError_t launch_gather_rows(const void* src, void* out, int B, int L, int E, Positions pos, int dt, bool blocked,

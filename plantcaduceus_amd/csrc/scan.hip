@@ -43,7 +43,16 @@ typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 
 constexpr int NSTATE = 16;
 constexpr int TB = 32;    // timesteps per delta tile
-constexpr int CH = 4;     // timesteps per prefetch chunk
+#ifndef PCAD_SCAN_CH
+#define PCAD_SCAN_CH 4
+#endif
+#ifndef PCAD_SCAN_OCC
+#define PCAD_SCAN_OCC 4
+#endif
+#ifndef PCAD_SCAN_OCC96
+#define PCAD_SCAN_OCC96 PCAD_SCAN_OCC
+#endif
+constexpr int CH = PCAD_SCAN_CH;     // timesteps per prefetch chunk (4 or 8: a chunk must not cross an 8-row block of the blocked layout)
 
 __device__ __forceinline__ float exp2_hw(float x) { return __builtin_amdgcn_exp2f(x); }
 
@@ -197,35 +206,42 @@ struct DeltaTileSplit {
 // SPLITY (fp32 engine with "f32_gemm_split", BLK8 only): the output is NOT written as fp32 rows but as out_proj's split-bf16
 // operand - ysplit, bf16 [rows8, 2E] blocked = [hi | lo] with hi = bf16(y), lo = bf16(y - hi) (pack.hip launch_split_rows'
 // format) - which saves the separate conversion pass over y (read 4E + write 4E bytes per row).
+// SEG = 3 / 4 (launch_scan_pair below; "pair" walks of launches with few waves): both directions of a layer run in ONE launch, each
+// walking HALF of its strand per launch.  SEG = 3: the first half of the walk from a zero state, WITH output, end state stored;
+// SEG = 4: the second half from that state (ACC / HASZ as in the plain walk: it adds the other direction's first-half output).
+// Same arithmetic as two plain launches - forward rows [0, L/2) then [L/2, L), reverse rows [L/2, L) then [0, L/2) - at twice the
+// waves per launch and no extra pass: what the first launch of a direction leaves in y is exactly what the second launch of the
+// OTHER direction accumulates onto.
 template <typename T, bool REV, int ACC, bool HASZ, bool FUSED, int PRE, bool BLK8, int SEG = 0, bool ZB = false, bool SPLITY = false>
-__global__ __launch_bounds__(64, 4) void scan_kernel(const T* __restrict__ u, const T* __restrict__ z, int64_t ldz,
-                                                  const T* __restrict__ dsrc, int64_t ldd,
-                                                  const T* __restrict__ Wdt, int Rp,
-                                                  const float* __restrict__ bc,
-                                                  const float* __restrict__ A2, float a_scale,
-                                                  const float* __restrict__ Dskip, const float* __restrict__ dbias,
-                                                  const T* yin, T* y, int L, int E, int uyb, int zblk, int G, int seg_blocks,
-                                                  float* __restrict__ seg_state, int Lw, bf16_t* __restrict__ ysplit, int dts) {
-    // delta slab: rows 1..TB hold the block's TB steps; rows 0 and TB + 1 are never-consumed landing rows for the one-step-ahead
-    // read at the block's ends, so that read needs no wrap (its address is a per-chunk base + a compile-time offset)
-    __shared__ float dvs[TB + 2][64];
+__device__ __forceinline__ void scan_body(float (*dvs)[64], const int block_id, const int num_blocks,
+                                          const T* __restrict__ u, const T* __restrict__ z, int64_t ldz,
+                                          const T* __restrict__ dsrc, int64_t ldd,
+                                          const T* __restrict__ Wdt, int Rp,
+                                          const float* __restrict__ bc,
+                                          const float* __restrict__ A2, float a_scale,
+                                          const float* __restrict__ Dskip, const float* __restrict__ dbias,
+                                          const T* yin, T* y, int L, int E, int uyb, int zblk, int G, int seg_blocks,
+                                          float* __restrict__ seg_state, int Lw, bf16_t* __restrict__ ysplit, int dts) {
+    // dvs - delta slab [TB + 2][64] in LDS: rows 1..TB hold the block's TB steps; rows 0 and TB + 1 are never-consumed landing rows
+    // for the one-step-ahead read at the block's ends, so that read needs no wrap (its address is a per-chunk base + a compile-time offset)
     const int lane = threadIdx.x;
     // 1-D grid of (strands x segments) x (E / 64) blocks in XCD-affine order: block b runs on XCD b % 8 (observed; speed only), so
     // the E / 64 channel blocks of strand-segment 8 q + x are the consecutive blocks j = b / 8 of XCD x = b % 8; a tail of fewer
     // than 8 strand-segments keeps the natural order
     const int ncb = E >> 6;
-    const int nss = (int)gridDim.x / ncb;             // strands x segments
+    const int nss = num_blocks / ncb;                 // strands x segments
     int ss, cb;
     {
-        const int b = (int)blockIdx.x, full = (nss & ~7) * ncb;
+        const int b = block_id, full = (nss & ~7) * ncb;
         if (b < full) { const int j = b >> 3, q = j / ncb; ss = q * 8 + (b & 7); cb = j - q * ncb; }
         else { const int r = b - full, q = r / ncb; ss = (nss & ~7) + q; cb = r - q * ncb; }
     }
     const int c0 = cb * 64;
     const int c = c0 + lane;
-    const int strand = SEG ? ss / G : ss;
-    const int seg = SEG ? ss - strand * G : 0;
-    const int nstrands = SEG ? nss / G : nss;
+    constexpr bool PAIR = SEG == 3 || SEG == 4;       // one block per strand: the segment is the launch's (first / second half)
+    const int strand = PAIR ? ss : (SEG ? ss / G : ss);
+    const int seg = PAIR ? (SEG == 4 ? 1 : 0) : (SEG ? ss - strand * G : 0);
+    const int nstrands = PAIR ? nss : (SEG ? nss / G : nss);
     const int64_t row0 = (int64_t)strand * L;
 
     f2 a2p[NSTATE / 2], hp[NSTATE / 2];
@@ -238,7 +254,7 @@ __global__ __launch_bounds__(64, 4) void scan_kernel(const T* __restrict__ u, co
     // seg_state: [strand][segment][E][16] states, then [strand][segment][E] delta sums (pass A output); pass B reads its initial
     // state from the same [strand][segment][E][16] block (rewritten in place by scan_carry_kernel)
     float* __restrict__ seg_h = seg_state + (((int64_t)strand * G + seg) * E + c) * NSTATE;
-    if constexpr (SEG == 2) {
+    if constexpr (SEG == 2 || SEG == 4) {
 #pragma unroll
         for (int p = 0; p < NSTATE / 2; p += 2) {
             const f32x4 v = *reinterpret_cast<const f32x4*>(seg_h + 2 * p);
@@ -383,14 +399,17 @@ __global__ __launch_bounds__(64, 4) void scan_kernel(const T* __restrict__ u, co
     DeltaPre<PRE ? PRE : 16> pre;
     if constexpr (PRE != 0) pre = delta_prefetch<PRE>((const bf16_t*)dsrc, ldd, row0, REV ? (L - (b_begin + 1) * TB) : b_begin * TB, L, lane);
 
-    // L2 prefetch of the NEXT block's B_t | C_t rows (32 x 128 bytes, contiguous) and - fp32 split dt_proj, whose operand is not held
-    // in registers - dt_low rows: one dword per 32-byte sector, values never used.  They are "consumed" by an empty asm at the top of the
-    // next block (a full 32-step walk later: long landed), which is what keeps the registers reserved until the loads have returned.
-    float pfb0 = 0.f, pfb1 = 0.f, pfd[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    // L2 prefetch of the NEXT block's B_t | C_t rows (32 x 128 bytes, contiguous): one dword per 32-byte sector, values never used.
+    // They are "consumed" by an empty asm at the top of the next block (a full 32-step walk later: long landed), which is what keeps
+    // the registers reserved until the loads have returned.
+    float pfb0 = 0.f, pfb1 = 0.f;
     const int b_end = SEG ? min(nblk, b_begin + seg_blocks) : nblk;
     for (int b = b_begin; b < b_end; ++b) {
         const int tb0 = REV ? (L - (b + 1) * TB) : b * TB;
-        if constexpr (FUSED) {
+#ifndef PCAD_SCAN_NOPF      // timing-only ablation: without the L2 prefetch
+        // bf16 instantiations only: in the fp32 kernels (no register headroom at 128 VGPRs: the prefetch registers spill, and the split
+        // dt_low rows need four more gather loads per block) it measured -10 % (3.30 -> 3.63 ms per launch, profiles/r06_scan_ablations.txt)
+        if constexpr (FUSED && sizeof(T) == 2) {
             asm volatile("" ::"v"(pfb0), "v"(pfb1));
             const int tbn = max(0, min(REV ? (L - (b + 2) * TB) : (b + 1) * TB, L - 1));          // first row of the next block in memory order (clamped)
             {
@@ -399,18 +418,9 @@ __global__ __launch_bounds__(64, 4) void scan_kernel(const T* __restrict__ u, co
                 pfb0 = *reinterpret_cast<const float*>(pb + min(tbn * (2 * NSTATE * 4) + lane * 32, lim));
                 pfb1 = *reinterpret_cast<const float*>(pb + min(tbn * (2 * NSTATE * 4) + (64 + lane) * 32, lim));
             }
-            if constexpr (std::is_same<T, float>::value && PRE == 0) {
-                if (dts) {
-                    asm volatile("" ::"v"(pfd[0]), "v"(pfd[1]), "v"(pfd[2]), "v"(pfd[3]), "v"(pfd[4]), "v"(pfd[5]));
-                    const int64_t rb = (int64_t)ldd * 2;                                           // bytes per dt_low row (bf16 [hi | lo | pad])
-                    const char* pd = reinterpret_cast<const char*>(dsrc) + row0 * rb;
-                    const int64_t lim = (int64_t)L * rb - 4;
-                    const int nsec = (int)((TB * rb + 2047) >> 11);                               // 64 lanes x 32 bytes per load
-#pragma unroll
-                    for (int q = 0; q < 6; ++q)
-                        if (q < nsec) pfd[q] = *reinterpret_cast<const float*>(pd + min((int64_t)tbn * rb + (int64_t)(q * 64 + lane) * 32, lim));
-                }
-            }
+        }
+#endif
+        if constexpr (FUSED) {
             f32x16 acc0, acc1;
 #pragma unroll
             for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
@@ -443,15 +453,27 @@ __global__ __launch_bounds__(64, 4) void scan_kernel(const T* __restrict__ u, co
         if constexpr (FUSED) dv_cur = dvs[REV ? TB : 1][lane];          // block row of the first walk step: 0 forward, TB - 1 reverse
         auto dv_base = [&](int s0) -> const float* { return &dvs[REV ? TB - CH - (s0 - s_begin) : (s0 - s_begin)][lane]; };
         auto run_step = [&](int s, int i, const float* dvp, uint32_t oy, int vy, T uraw, T zraw, T yraw, T draw, uint32_t oys) {
-            const float yv = step(s, i, dvp, Elem<T>::to_f32(uraw), HASZ ? Elem<T>::to_f32(zraw) : 0.f,
-                                  ACC != 0 ? Elem<T>::to_f32(yraw) : 0.f, draw);
+            const float yv0 = step(s, i, dvp, Elem<T>::to_f32(uraw), HASZ ? Elem<T>::to_f32(zraw) : 0.f,
+                                   ACC != 0 ? Elem<T>::to_f32(yraw) : 0.f, draw);
             if constexpr (SPLITY && SEG != 1) {
+                // y as the fp32 VALUE the plain walk would store (no contraction of the gate's multiply into the subtraction below):
+                // hi / lo are then exactly what pack.hip's split_rows_kernel makes of the stored y, and the last-layer shortcut
+                // (gathered fp32 rows -> split_rows) is bit-identical to the full layer
+                float yq = yv0;
+                asm volatile("" : "+v"(yq));
+                const float yv = yq;
                 const uint32_t pk = pack_bf16x2(yv, 0.f);                                  // hi = bf16(y)
                 const bf16_t hi = (bf16_t)(pk & 0xffffu);
                 const bf16_t lo = f32_to_bf16(yv - bf16lo_to_f32(pk));                       // lo = bf16(y - hi)
+#ifdef PCAD_SCAN_HOTSTORE  // timing-only ablation: every row store goes to the first 64 KiB of its tensor (results are garbage)
+                BufIO<bf16_t>::store(hi, ys_r, ys_voff(i), oys & 0xffffu);
+                BufIO<bf16_t>::store(lo, ys_r, ys_voff(i), (oys & 0xffffu) + ys_half);
+            } else if constexpr (SEG != 1) BufIO<T>::store(Elem<T>::from_f32(yv0), y_r, vy, oy & 0xffffu);
+#else
                 BufIO<bf16_t>::store(hi, ys_r, ys_voff(i), oys);
                 BufIO<bf16_t>::store(lo, ys_r, ys_voff(i), oys + ys_half);
-            } else if constexpr (SEG != 1) BufIO<T>::store(Elem<T>::from_f32(yv), y_r, vy, oy);
+            } else if constexpr (SEG != 1) BufIO<T>::store(Elem<T>::from_f32(yv0), y_r, vy, oy);
+#endif
         };
         auto run_chunk = [&](int s0, T (&uu)[CH], T (&zz)[CH], T (&yy)[CH], T (&dd)[CH]) {
             const float* dvp = dv_base(s0);
@@ -489,6 +511,60 @@ __global__ __launch_bounds__(64, 4) void scan_kernel(const T* __restrict__ u, co
             *reinterpret_cast<f32x4*>(seg_h + 2 * p) = f32x4{hp[p][0], hp[p][1], hp[p + 1][0], hp[p + 1][1]};
         seg_state[(int64_t)nstrands * G * E * NSTATE + ((int64_t)strand * G + seg) * E + c] = dsum;
     }
+    if constexpr (SEG == 3) {             // end state of the first half = initial state of the second (slot of segment 1)
+        float* __restrict__ nxt = seg_h + (int64_t)E * NSTATE;
+#pragma unroll
+        for (int p = 0; p < NSTATE / 2; p += 2)
+            *reinterpret_cast<f32x4*>(nxt + 2 * p) = f32x4{hp[p][0], hp[p][1], hp[p + 1][0], hp[p + 1][1]};
+    }
+}
+
+template <typename T, bool REV, int ACC, bool HASZ, bool FUSED, int PRE, bool BLK8, int SEG = 0, bool ZB = false, bool SPLITY = false>
+__global__ __launch_bounds__(64, PRE == 96 ? PCAD_SCAN_OCC96 : PCAD_SCAN_OCC) void scan_kernel(const T* __restrict__ u, const T* __restrict__ z, int64_t ldz,
+                                                  const T* __restrict__ dsrc, int64_t ldd,
+                                                  const T* __restrict__ Wdt, int Rp,
+                                                  const float* __restrict__ bc,
+                                                  const float* __restrict__ A2, float a_scale,
+                                                  const float* __restrict__ Dskip, const float* __restrict__ dbias,
+                                                  const T* yin, T* y, int L, int E, int uyb, int zblk, int G, int seg_blocks,
+                                                  float* __restrict__ seg_state, int Lw, bf16_t* __restrict__ ysplit, int dts) {
+    __shared__ float dvs[TB + 2][64];
+    scan_body<T, REV, ACC, HASZ, FUSED, PRE, BLK8, SEG, ZB, SPLITY>(dvs, (int)blockIdx.x, (int)gridDim.x, u, z, ldz, dsrc, ldd, Wdt, Rp, bc, A2, a_scale,
+                                                                    Dskip, dbias, yin, y, L, E, uyb, zblk, G, seg_blocks, seg_state, Lw, ysplit, dts);
+}
+
+// Both directions of one layer in ONE launch (engine layouts only: fused dt_proj, blocked u / y / z, L % 64 == 0): blocks [0, n) run
+// the forward body on direction 0's operands, blocks [n, 2n) the reverse body on direction 1's.  PHASE 3 / 4 = scan_body's SEG.
+template <typename T>
+struct ScanDirArgs {
+    const T* u;            // conv output of the direction (xc)
+    const T* dsrc;         // dt_low
+    const T* Wdt;
+    const float* bc;
+    const float* A2;
+    const float* Dskip;
+    const float* dbias;
+    float* seg_state;      // [S][2][E][16] fp32: slot (strand, 1) carries the state between the two launches
+};
+
+// (Every operand is its own __restrict__ kernel argument: B_t | C_t are fetched through the scalar unit only when the compiler can
+// prove that the kernel's stores do not clobber them - with the pointers inside a by-value struct it could not, the B | C rows
+// arrived through eight vector loads per step and the kernel ran 2.3x slower.)
+template <typename T, int ACC, bool HASZ, int PRE, int PHASE, bool SPLITY>
+__global__ __launch_bounds__(64, PRE == 96 ? PCAD_SCAN_OCC96 : PCAD_SCAN_OCC) void scan_pair_kernel(
+    const T* __restrict__ u0, const T* __restrict__ dsrc0, const T* __restrict__ Wdt0, const float* __restrict__ bc0, const float* __restrict__ A2_0,
+    const float* __restrict__ Dskip0, const float* __restrict__ dbias0, float* __restrict__ seg0,
+    const T* __restrict__ u1, const T* __restrict__ dsrc1, const T* __restrict__ Wdt1, const float* __restrict__ bc1, const float* __restrict__ A2_1,
+    const float* __restrict__ Dskip1, const float* __restrict__ dbias1, float* __restrict__ seg1,
+    const T* __restrict__ z, int64_t ldd, int Rp, float a_scale, T* y, int L, int E, int seg_blocks, bf16_t* __restrict__ ysplit, int dts) {
+    __shared__ float dvs[TB + 2][64];
+    const int half = (int)gridDim.x >> 1;
+    if ((int)blockIdx.x < half)
+        scan_body<T, false, ACC, HASZ, true, PRE, true, PHASE, HASZ, SPLITY>(dvs, (int)blockIdx.x, half, u0, z, (int64_t)E, dsrc0, ldd, Wdt0, Rp, bc0, A2_0, a_scale,
+                                                                             Dskip0, dbias0, y, y, L, E, 1, 1, 2, seg_blocks, seg0, L, ysplit, dts);
+    else
+        scan_body<T, true, ACC, HASZ, true, PRE, true, PHASE, HASZ, SPLITY>(dvs, (int)blockIdx.x - half, half, u1, z, (int64_t)E, dsrc1, ldd, Wdt1, Rp, bc1, A2_1, a_scale,
+                                                                            Dskip1, dbias1, y, y, L, E, 1, 1, 2, seg_blocks, seg1, L, ysplit, dts);
 }
 
 // Carry between the segments of a strand, in walk order: the state a segment starts from is
@@ -578,6 +654,51 @@ static hipError_t launch_scan_t(const void* u, const void* z, int64_t ldz, const
 #undef PCAD_WALK
 #undef PCAD_SCAN_ARGS
     return hipGetLastError();
+}
+
+template <typename T, int PRE>
+static hipError_t launch_scan_pair_t(const ScanDirection& f, const ScanDirection& r, const void* z, int64_t lddt, int Rp, void* y, int S, int L, int E,
+                                     bool gate_each, hipStream_t s, float* ws, void* ysplit, bool dt_split, int phases) {
+    const int dts = dt_split ? 1 : 0;
+    const int sb = (L / TB) / 2;                                          // blocks (of TB steps) per half: L % (2 TB) == 0
+    const size_t per_dir = (size_t)S * 2 * E * NSTATE;                   // floats
+    ScanDirArgs<T> d0{(const T*)f.u, (const T*)f.dt_low, (const T*)f.Wdt, f.bc, f.A2, f.Dskip, f.dbias, ws};
+    ScanDirArgs<T> d1{(const T*)r.u, (const T*)r.dt_low, (const T*)r.Wdt, r.bc, r.A2, r.Dskip, r.dbias, ws + per_dir};
+    dim3 grid((unsigned)((int64_t)2 * S * (E / 64))), block(64);
+#define PCAD_PAIR(ACCM, HZ, PH, SPY)                                                                                            \
+    hipLaunchKernelGGL((scan_pair_kernel<T, ACCM, HZ, PRE, PH, SPY>), grid, block, 0, s, d0.u, d0.dsrc, d0.Wdt, d0.bc, d0.A2, d0.Dskip, d0.dbias, \
+                       d0.seg_state, d1.u, d1.dsrc, d1.Wdt, d1.bc, d1.A2, d1.Dskip, d1.dbias, d1.seg_state, (const T*)z, lddt, Rp, 1.0f, (T*)y, L, E, sb, \
+                       (bf16_t*)ysplit, dts)
+    // first halves: forward rows [0, L/2), reverse rows [L/2, L) - ungated (or, "gate_each", each gated and rounded)
+    if (phases & 1) { if (gate_each) PCAD_PAIR(0, true, 3, false); else PCAD_PAIR(0, false, 3, false); }
+    if (!(phases & 2)) return hipGetLastError();
+    // second halves on top of the other direction's first-half output, gated
+    if constexpr (std::is_same<T, float>::value) {
+        if (ysplit) { if (gate_each) PCAD_PAIR(1, true, 4, true); else PCAD_PAIR(2, true, 4, true); return hipGetLastError(); }
+    } else if (ysplit) {
+        return hipErrorInvalidValue;
+    }
+    if (gate_each) PCAD_PAIR(1, true, 4, false); else PCAD_PAIR(2, true, 4, false);
+#undef PCAD_PAIR
+    return hipGetLastError();
+}
+
+hipError_t launch_scan_pair(const ScanDirection& fwd, const ScanDirection& rev, const void* z, int64_t lddt, int Rp, void* y, int S, int L, int E,
+                            bool gate_each, int dt, hipStream_t s, float* ws, void* ysplit, bool dt_split, int phases) {
+    if (S <= 0 || L <= 0) return hipSuccess;
+    if (!ws || !z || E % 64 || L % (2 * TB) || Rp <= 0 || Rp % 32) return hipErrorInvalidValue;
+    const int esz = dt == BF16 ? 2 : 4;
+    if ((E * esz) % 128 || ((int64_t)S * L + 7) / 8 * 8 * E * esz >= ((int64_t)1 << 32)) return hipErrorInvalidValue;      // blocked layouts, 32-bit offsets
+    if ((int64_t)L * E * 4 >= ((int64_t)1 << 31)) return hipErrorInvalidValue;
+    if (dt_split && !(dt == F32 && Rp <= 96 && lddt % 8 == 0 && lddt >= 2 * Rp)) return hipErrorInvalidValue;
+    if (ysplit && !(dt == F32 && ((int64_t)S * L + 7) / 8 * 8 * 2 * E * 2 < ((int64_t)1 << 32))) return hipErrorInvalidValue;
+    if (dt == BF16) {
+        if (lddt % 8) return hipErrorInvalidValue;
+        if (Rp == 64) return launch_scan_pair_t<bf16_t, 64>(fwd, rev, z, lddt, Rp, y, S, L, E, gate_each, s, ws, nullptr, false, phases);
+        if (Rp == 96) return launch_scan_pair_t<bf16_t, 96>(fwd, rev, z, lddt, Rp, y, S, L, E, gate_each, s, ws, nullptr, false, phases);
+        return hipErrorInvalidValue;
+    }
+    return launch_scan_pair_t<float, 0>(fwd, rev, z, lddt, Rp, y, S, L, E, gate_each, s, ws, ysplit, dt_split, phases);
 }
 
 hipError_t launch_scan(const void* u, const void* z, int64_t ldz, const void* delta, const void* dt_low, int64_t lddt,

@@ -87,12 +87,15 @@ def test_config5_l32_ism_sweep_one_window(l32, golden_dir):
     cols = [tok.get_vocab()[c] for c in "acgt"]
     with torch.inference_mode():
         for i, p in enumerate(sel):
-            # 16 copies of the window: a launch of more than 512 scan waves walks every strand in one piece, like the 512-row
-            # sweep does (a single window at 512 bp is cut into segments since round 4 - csrc/kernels.hpp::scan_segments -
-            # which equals the single walk to fp32 rounding, not bit for bit: checked just below)
-            rep = torch.from_numpy(np.repeat(ids[i:i + 1], 16, 0)).to(DEV)
+            # 64 copies of the window: a launch of more than 3 584 scan waves per direction takes the plain walk, like the 512-row
+            # sweep does (fewer waves take the pair form - round 6, csrc/kernels.hpp::scan_pair_wanted - or, at most 512 of them,
+            # the segmented form - round 4, scan_segments - which equal the plain walk to bf16 / fp32 rounding, not bit for bit:
+            # checked just below)
+            rep = torch.from_numpy(np.repeat(ids[i:i + 1], 64, 0)).to(DEV)
             want = torch.softmax(m(input_ids=rep, positions=[p]).logits[:, 0, cols].float(), 1).cpu().numpy()
-            assert np.array_equal(want[0], probs[p]) and np.array_equal(want[0], want[15]), p
+            assert np.array_equal(want[0], probs[p]) and np.array_equal(want[0], want[63]), p
+            mid = torch.softmax(m(input_ids=rep[:16], positions=[p]).logits[:, 0, cols].float(), 1).cpu().numpy()
+            assert np.abs(mid[0] - probs[p]).max() < 1e-2 and np.array_equal(mid[0], mid[15]), p     # 16 copies: the pair form
             one = torch.softmax(m(input_ids=rep[:1], positions=[p]).logits[:, 0, cols].float(), 1).cpu().numpy()[0]
             assert np.abs(one - probs[p]).max() < 1e-2, p              # the segmented single-window path: bf16 noise only
     # the oracle (bf16-emulating, reference order) on those 8 masked windows

@@ -274,6 +274,49 @@ def test_segmented_scan_equals_single_walk(dtype, D, L, B):
     assert torch.equal(c.logits, a.logits)
 
 
+@pytest.mark.parametrize("dtype,D,L,B,opts", [
+    (torch.float32, 256, 128, 5, {}), (torch.bfloat16, 256, 256, 40, {}), (torch.bfloat16, 1024, 512, 24, {}),
+    (torch.float32, 384, 192, 7, {"gate_each": 1}), (torch.bfloat16, 512, 2048, 28, {"reference_order": 1}),
+    (torch.float32, 256, 320, 40, {"f32_gemm_split": 1}), (torch.float32, 1024, 512, 20, {"f32_gemm_split": 1, "gate_each": 1}),
+    (torch.bfloat16, 1536, 1024, 8, {})])
+def test_pair_walk_equals_plain_walk(dtype, D, L, B, opts):
+    """launches with few scan waves (csrc/kernels.hpp::scan_pair_wanted: more than the segmented form's bound, at most 3 584 per
+    direction): both directions run in ONE launch and walk half a strand per launch - forward rows [0, L/2) + reverse rows
+    [L/2, L), then the second halves from the kept states on top of the other direction's partial.  Same function as the plain
+    two-launch walk (`scan_segments` = 0): fp32 to summation order (the y accumulation starts from the other direction's partial
+    on half of the rows), bf16 to the rounding of one addend; the bf16 model's "gate_each" (each direction gated and rounded,
+    then summed) is the same two rounded addends in either form: bit-identical (fp32: the gate's multiply is contracted into the
+    add, so which addend is the stored one shows in the last bit).  Also against the oracle, with the hand-over scratch poisoned; dt_rank
+    96 (D 1536) and the split-bf16 fp32 model (the second launch writes out_proj's [hi | lo] operand from BOTH directions)."""
+    from plantcaduceus_amd.engine import load_library
+    cfg = make_config("x", d_model=D, n_layer=2)
+    sd = synthetic_state_dict(cfg, seed=41)
+    ids = rand_ids(B, L, 9, mask=L // 2)
+    pos = [L // 2, 0, L - 1, L // 2 - 1]
+    a = build(cfg, sd, dtype, **opts)(input_ids=ids.to(DEV), output_hidden_states=True)
+    b = build(cfg, sd, dtype, scan_segments=0, **opts)(input_ids=ids.to(DEV), output_hidden_states=True)
+    la, lb = a.logits.float().cpu(), b.logits.float().cpu()
+    ha, hb = a.hidden_states[-1].float().cpu(), b.hidden_states[-1].float().cpu()
+    assert torch.isfinite(la).all()
+    if dtype == torch.bfloat16 and (opts.get("gate_each") or opts.get("reference_order")):
+        assert torch.equal(la, lb) and torch.equal(ha, hb)          # two bf16-rounded addends, summed: the same in either form
+    else:
+        tol = 5e-6 if dtype == torch.float32 else 2e-2
+        assert ((la - lb).abs().max() / lb.abs().max()).item() < tol
+        assert ((ha - hb).abs().max() / hb.abs().max()).item() < tol
+        assert not torch.equal(ha, hb) or dtype == torch.float32        # the pair form really ran (bf16: another rounding pattern)
+    if dtype == torch.float32:
+        ref = O.forward_strands(ids, O.params_from_state_dict(sd, cfg))
+        assert ((la - ref["logits"]).abs().max() / ref["logits"].abs().max()).item() < 1e-4
+        assert ((ha - ref["hidden"]).abs().max() / ref["hidden"].abs().max()).item() < 1e-4
+    c = build(cfg, sd, dtype, poison_workspace=1, **opts)(input_ids=ids.to(DEV), output_hidden_states=True)
+    assert torch.equal(c.logits.float().cpu(), la)
+    # the positions path (last-layer shortcut): the LAST layer never takes the pair form, so that its shortened plain walks stay
+    # bit-identical to the full layer on the evaluated rows
+    d = build(cfg, sd, dtype, **opts)(input_ids=ids.to(DEV), positions=pos)
+    assert torch.equal(d.logits.float().cpu(), la[:, pos])
+
+
 def test_maximum_chunk_bit_identical_to_small_chunks():
     """maximum sizes: at the l32 width one chunk holds up to 1023 windows = 1 047 552 token-rows, whose x / xc / y tensors are just
     under 4 GiB each, so the kernels' unsigned 32-bit byte offsets run to the top of their range.  Rows are independent, so the
