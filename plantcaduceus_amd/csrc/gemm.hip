@@ -56,6 +56,13 @@ constexpr int GEMM_THREADS = 512;
 #endif
 constexpr int walk = PCAD_WALK_CONST;
 
+// Wrap-around K cursor of the split-bf16 GEMMs (K = 3 Ko, operands stored [hi | lo], nk = Ko / 64 K-tiles per part): the memory
+// K-tile of logical K-tile kt - three passes over K.  (Measured and removed, profiles/r06_f32_split_ab.txt: the three products of one
+// Ko-tile on consecutive K-tiles, kt = 3 k + part, so that the second use of a tile would hit the L2 - in_proj 7.3 -> 7.9 ms,
+// out_proj 3.35 -> 3.77 ms per 350 208-row launch: re-requesting a tile one or two K-tiles after its first request is slower than
+// streaming it again 16-32 K-tiles later.)
+__device__ __forceinline__ int ksplit_a(int kt, int nk) { return kt >= 2 * nk ? kt - 2 * nk : kt; }      // A: hi, lo, hi
+__device__ __forceinline__ int ksplit_w(int kt, int nk) { return kt >= nk ? kt - nk : kt; }              // W: hi, hi, lo
 __device__ __forceinline__ int key_a(int r) { return (r >> 1) & 7; }
 __device__ __forceinline__ int key_w(int r) { return (((r >> 4) & 3) << 1) | ((r >> 1) & 1); }
 
@@ -140,8 +147,8 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_kernel(const T* __res
     auto stage = [&](int kt, int st) {
         char* as = smem + st * STAGE_BYTES + (wave * 32) * ROWB;
         char* ws = smem + st * STAGE_BYTES + A_BYTES + (wave * 16) * ROWB;
-        const int kta = ksplit && kt >= 2 * ksplit ? kt - 2 * ksplit : kt;      // A: hi, lo, hi
-        const int ktw = ksplit && kt >= ksplit ? kt - ksplit : kt;              // W: hi, hi, lo
+        const int kta = ksplit ? ksplit_a(kt, ksplit) : kt;
+        const int ktw = ksplit ? ksplit_w(kt, ksplit) : kt;
         const int64_t ko = (int64_t)ktw * ROWB;
         const int64_t koa = a_blocked ? (int64_t)kta * 1024 : (int64_t)kta * ROWB;     // blocked A: consecutive k-pieces are 1 KiB apart
 #pragma unroll
@@ -398,7 +405,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm256r_kernel(const T* __re
     int w_tile = blockIdx.x, w_kt = 0, w_g = 0;
     auto a_piece = [&](int sa, int p) {               // piece p of A(a_g) -> A stage sa
         if (a_g < G) {
-            const int kta = ksplit && a_kt >= 2 * ksplit ? a_kt - 2 * ksplit : a_kt;      // wrap-around K cursor (A: hi, lo, hi)
+            const int kta = ksplit ? ksplit_a(a_kt, ksplit) : a_kt;                       // wrap-around K cursor
             const int64_t koa = a_blocked ? (int64_t)kta * 1024 : (int64_t)kta * ROWB;
             glds16(pa[p] + koa, smem + sa * A2_BYTES + (wave * 32 + p * 8) * ROWB);
         }
@@ -415,7 +422,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm256r_kernel(const T* __re
     };
     auto w_pieces = [&](int sw, int p0) {             // pieces p0, p0 + 1 of W(w_g) -> W stage sw
         if (w_g < G) {
-            const int64_t ko = (int64_t)(ksplit && w_kt >= ksplit ? w_kt - ksplit : w_kt) * ROWB;   // W: hi, hi, lo
+            const int64_t ko = (int64_t)(ksplit ? ksplit_w(w_kt, ksplit) : w_kt) * ROWB;
             glds16(pw[p0] + ko, smem + GEMM3_OFF_W + sw * W2_BYTES + (wave * 32 + p0 * 8) * ROWB);
             glds16(pw[p0 + 1] + ko, smem + GEMM3_OFF_W + sw * W2_BYTES + (wave * 32 + (p0 + 1) * 8) * ROWB);
         }
@@ -758,9 +765,8 @@ __global__ __launch_bounds__(GEMMQ_THREADS, 1) void gemm256q_kernel(const T* __r
     // The memory K-tile index is derived from the (wave-uniform, scalar) cursor a_kt / w_kt at every use - a separately carried index
     // was placed in a VGPR by the compiler and every LDS-DMA then ran in a waterfall loop (-15 % on the whole GEMM).
     constexpr bool KSPLIT = !std::is_same<T, OutT>::value;
-    const int a_wrap = KSPLIT && ksplit ? 2 * ksplit : 0x7fffffff, w_wrap = KSPLIT && ksplit ? ksplit : 0x7fffffff;
     auto a_piece = [&](int sa, int p) __attribute__((always_inline)) {               // piece p of A(a_g) -> A stage sa
-        const int a_kx = KSPLIT ? (a_kt >= a_wrap ? a_kt - a_wrap : a_kt) : a_kt;
+        const int a_kx = KSPLIT && ksplit ? ksplit_a(a_kt, ksplit) : a_kt;
         const uint32_t soff = a_base + (uint32_t)a_kx * (a_blocked ? 1024u : (uint32_t)ROWB);
         blds16(A, a_lo[p], soff, smem + sa * A2_BYTES + (wave * 64 + p * 8) * ROWB);
     };
@@ -769,7 +775,7 @@ __global__ __launch_bounds__(GEMMQ_THREADS, 1) void gemm256q_kernel(const T* __r
         for (int p = 0; p < 8; ++p) a_piece(sa, p);
     };
     auto w_piece = [&](int sw, int p) __attribute__((always_inline)) {
-        const int w_kx = KSPLIT ? (w_kt >= w_wrap ? w_kt - w_wrap : w_kt) : w_kt;
+        const int w_kx = KSPLIT && ksplit ? ksplit_w(w_kt, ksplit) : w_kt;
         const uint32_t soff = w_base + (uint32_t)w_kx * (uint32_t)ROWB;
         blds16(W, w_lo[p], soff, smem + GEMM3_OFF_W + sw * W2_BYTES + (wave * 64 + p * 8) * ROWB);
     };
