@@ -559,11 +559,13 @@ static int forward_impl(pcad_handle h, const int32_t* ids, int B, int L, const i
     // (hidden_states[i] are the mixer outputs h, which the folded form never materialises).
     // Decided ONCE per forward - every chunk folds or none does - so that a result never depends on how the batch was cut
     // into chunks (an uneven split of odd-length windows could otherwise give one chunk whole 256-row tiles and another not).
-    if (fold_wanted(e) && !e->fold_packed) {
-        if (e->norm_fold == 1)
-            return fail(PCAD_ERR_INVALID, "pcad_forward: \"norm_fold\" 1 was set after pcad_bind_weights; the folded form's weight copies are "
-                                          "packed at bind time - set the option before pcad_weight_arena_bytes / pcad_bind_weights");
-    }
+    // (also when the fold is only the DEFAULT of this model - a bf16 engine bound under "norm_fold" 0 / "reference_order" >= 1 and switched
+    // back afterwards: running unfolded would silently cost 4.5 % and differ from a freshly bound engine; like "f32_gemm_split" it is refused)
+    if (fold_wanted(e) && !e->fold_packed)
+        return fail(PCAD_ERR_INVALID, "pcad_forward: the norm-folded layer form (\"norm_fold\" %s) was enabled after pcad_bind_weights, under options that "
+                                      "did not ask for it; its weight copies are packed at bind time - set \"norm_fold\" / \"reference_order\" before "
+                                      "pcad_weight_arena_bytes / pcad_bind_weights (turning the form OFF afterwards is always possible)",
+                    e->norm_fold == 1 ? "1" : "default");
     if (split_wanted(e) && !e->split_packed)
         return fail(PCAD_ERR_INVALID, "pcad_forward: \"f32_gemm_split\" 1 was set after pcad_bind_weights; the split weight copies are packed at "
                                       "bind time - set the option before pcad_weight_arena_bytes / pcad_bind_weights");

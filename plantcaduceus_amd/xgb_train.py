@@ -137,8 +137,18 @@ def main(argv: Optional[Sequence[str]] = None):
         if sharding.rank0_decides(not os.path.exists(model_json), args.device):
             sharding.shutdown()
             raise FileNotFoundError(f"{model_json} not found: -test_only evaluates a classifier trained by an earlier run")
+        # a malformed JSON also fails now, not after the embeddings - on EVERY rank: only rank 0 parses the file, its verdict is
+        # broadcast (a rank 0 that raised alone would leave the others waiting in load_model / the all-gathers until torchrun's
+        # watchdog tears them down)
+        err = None
         if rank == 0:
-            XGBJsonClassifier().load_model(model_json)        # a malformed JSON also fails now, not after the embeddings
+            try:
+                XGBJsonClassifier().load_model(model_json)
+            except Exception as ex:                             # any reader failure: bad JSON, missing keys, unsupported booster
+                err = ex
+        if sharding.rank0_decides(err is not None, args.device):
+            sharding.shutdown()
+            raise ValueError(f"{model_json} is not a classifier this evaluator reads" + (f": {err!r}" if err is not None else " (rank 0 reported the error)"))
     model, tokenizer = load_model_and_tokenizer(args.model, args.device)
 
     def embed(seqs):

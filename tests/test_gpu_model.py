@@ -498,6 +498,23 @@ def test_options_that_need_bind_time_copies_are_refused_afterwards():
     m2._engine().set_option("f32_gemm_split", 0)                 # off again: the plain fp32 GEMMs, bit-identical to a plain engine
     assert torch.equal(m2(input_ids=ids).logits.cpu(), ref)
     assert ((a - ref).abs().max() / ref.abs().max()).item() < 1e-5
+    # the bf16 model's DEFAULT form is the folded one: bound under "reference_order" 1 (no folded copies packed) and switched back to
+    # the default afterwards, the forward is refused as well instead of silently running unfolded; an engine bound in
+    # the default form may be switched to the reference order and back at will (its copies exist)
+    ids256 = rand_ids(2, 128, 3).to(DEV)                         # whole 256-row tiles: the folded form engages
+    mb = build(cfg, sd, torch.bfloat16, reference_order=1)
+    r1 = mb(input_ids=ids256).logits.cpu()
+    mb._engine().set_option("reference_order", 0)
+    with pytest.raises(RuntimeError, match="pcad_bind_weights"):
+        mb(input_ids=ids256)
+    mb._engine().set_option("reference_order", 1)
+    assert torch.equal(mb(input_ids=ids256).logits.cpu(), r1)
+    md = build(cfg, sd, torch.bfloat16)
+    d0 = md(input_ids=ids256).logits.cpu()
+    md._engine().set_option("reference_order", 1)
+    assert torch.equal(md(input_ids=ids256).logits.cpu(), r1)
+    md._engine().set_option("reference_order", 0)
+    assert torch.equal(md(input_ids=ids256).logits.cpu(), d0) and not torch.equal(d0, r1)
 
 
 def test_workspace_limit_bounds_the_allocation_without_changing_results():

@@ -250,6 +250,12 @@ def test_train_cli_plumbing(tmp_path, monkeypatch, golden_dir):
     np.testing.assert_allclose(np.load(out / "seed_7_te_predictions.npz")["predictions"], want, rtol=1e-6)
     with pytest.raises(FileNotFoundError):
         xgb_train.main(["-test", str(paths["te"]), "-model", "unused", "-output", str(tmp_path / "empty"), "-device", "cpu", "-test_only"])
+    # a classifier file that does not parse fails before any forward, on every rank (rank 0 parses, the verdict is broadcast)
+    bad = tmp_path / "bad"
+    bad.mkdir()
+    (bad / "seed_42_XGBoost.json").write_text("{ not json")
+    with pytest.raises(ValueError, match="not a classifier"):
+        xgb_train.main(["-test", str(paths["te"]), "-model", "unused", "-output", str(bad), "-device", "cpu", "-test_only"])
 
 
 def test_train_cli_metrics_follow_sklearn():

@@ -66,10 +66,9 @@ for case in range(n):
     ok = e_l < tol and e_h < tol and bool(torch.isfinite(lg).all())
     pos = sorted(set(int(p) for p in rng.integers(0, L, size=min(L, 3))))
     outp = m(input_ids=ids.to("cuda:0"), output_hidden_states=True, positions=pos)
-    if split:    # the last-layer shortcut projects the gathered rows with the plain fp32 GEMM, the full layer with the split one
-        ok = ok and ((outp.logits.cpu() - lg[:, pos]).abs().max() / scale).item() < 2e-5
-    else:
-        ok = ok and torch.equal(outp.logits.cpu(), lg[:, pos]) and torch.equal(outp.hidden_states[-1].float().cpu(), hid[:, pos])
+    # the last-layer shortcut is bit-identical to the full layer in every configuration (round 6: also with f32_gemm_split, whose
+    # gathered rows now go through the same split-bf16 product; the pair walks never take the last layer)
+    ok = ok and torch.equal(outp.logits.cpu(), lg[:, pos]) and torch.equal(outp.hidden_states[-1].float().cpu(), hid[:, pos])
     if not ok:
         bad += 1
     print(f"case {case:3d} D={D:3d} nl={nl} R={cfg.dt_rank:2d} B={B} L={L:3d} {'bf16' if bf16 else 'fp32'}  logits {e_l:.2e} hidden {e_h:.2e}  {'ok' if ok else 'FAIL'}"
