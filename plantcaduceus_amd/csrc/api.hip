@@ -726,10 +726,19 @@ static int forward_impl(pcad_handle h, const int32_t* ids, int B, int L, const i
             // through u, the second small output to xz (dead since the scans).
             if (last_short) {
                 ProfScope ps(e, PCAD_K_HEAD, s);
+                // the gathered rows of one direction (in u) through the tied out_proj: the same product as the full-size launch
+                // (split-bf16 with "f32_gemm_split": bit-identical rows)
+                auto out_proj_rows = [&](void* dst) -> hipError_t {
+                    if (sp) {
+                        if (hipError_t er = launch_split_rows((const float*)c.w.u, E, c.w.ys, (int64_t)S * P, E, false, false, s)) return er;
+                        return launch_gemm_nt(c.w.ys, 2 * E, W.W_out_s, 2 * E, dst, D, (int64_t)S * P, D, 3 * E, BF16, F32, false, s, false, E / 64);
+                    }
+                    return launch_gemm_nt(c.w.u, E, W.W_out, E, dst, D, (int64_t)S * P, D, E, dt, dt, false, s, false);
+                };
                 HIP_TRY(launch_gather_rows(c.w.y, c.w.u, c.Bc, L, E, pos, dt, e->blocked, s));
-                HIP_TRY(launch_gemm_nt(c.w.u, E, W.W_out, E, c.w.h, D, (int64_t)S * P, D, E, dt, dt, false, s, false));
+                HIP_TRY(out_proj_rows(c.w.h));
                 HIP_TRY(launch_gather_rows(y_rev, c.w.u, c.Bc, L, E, pos, dt, e->blocked, s));
-                HIP_TRY(launch_gemm_nt(c.w.u, E, W.W_out, E, c.w.xz, D, (int64_t)S * P, D, E, dt, dt, false, s, false));
+                HIP_TRY(out_proj_rows(c.w.xz));
                 HIP_TRY(launch_add_round(c.w.h, c.w.xz, (int64_t)S * P * D, dt, s));
                 return PCAD_OK;
             }

@@ -72,3 +72,30 @@ def test_audit_fails_loudly_on_unknown_config_keys_and_untied_weights(tmp_path):
     text = " | ".join(rep["problems"])
     assert "missing tensors" in text and "does not read" in text
     assert np.isfinite(1.0)
+
+
+@pytest.mark.gpu
+def test_census_engine_rows_on_a_synthetic_snapshot(tmp_path, golden_dir):
+    """the GPU half of step (ii): on a ROCm device the census adds the engine rows (bf16 in its three operation orders, fp32,
+    fp32 + f32_gemm_split) against the fp32 oracle; on a (small, well-conditioned) synthetic snapshot the fp32 engines make
+    exactly the oracle's calls."""
+    import importlib.util
+    from plantcaduceus_amd.checkpoint import make_synthetic_checkpoint
+    snap = str(tmp_path / "snap")
+    make_synthetic_checkpoint(snap, "x", seed=11, stress=False, d_model=128, n_layer=2)
+    tsv = tmp_path / "few.tsv"
+    pd.read_csv(os.path.join(golden_dir, "example_snp.tsv"), delimiter="\t").iloc[:9].to_csv(tsv, sep="\t", index=False)
+    spec = importlib.util.spec_from_file_location("argmax_census", os.path.join(ROOT, "tools", "argmax_census.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    lines = []
+    res = mod.census_on_snapshot(snap, tsv=str(tsv), n_seeded=16, n_emul=8, out=lines.append)
+    print("\n".join(lines))
+    assert len(res) == 2
+    for v in res.values():
+        rows = v["rows"]
+        assert "HIP fp32 vs fp32 oracle" in rows and "HIP fp32 + f32_gemm_split vs fp32 oracle" in rows
+        assert rows["HIP fp32 vs fp32 oracle"]["flips"] == 0 and rows["HIP fp32 + f32_gemm_split vs fp32 oracle"]["flips"] == 0
+        assert rows["HIP fp32 + f32_gemm_split vs fp32 oracle"]["max_dp"] < 1e-4
+        assert sum(1 for k in rows if k.startswith("HIP bf16")) >= 3
+        assert all(r["max_dp"] < 5e-2 for r in rows.values())
