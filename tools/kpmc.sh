@@ -10,7 +10,7 @@ P2="SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VME
 P3="SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_MFMA SQ_INSTS_SMEM SQ_VALU_MFMA_BUSY_CYCLES"
 i=0
 for P in "$P1" "$P2" "$P3"; do i=$((i+1))
-  timeout 400 rocprofv3 --kernel-trace --pmc $P --output-format csv -d "$OUT/p$i" -o p -- python3 "$ROOT/bench.py" --steps 1 --warmup 1 --cpu-seqs 0 --no-profile $ARGS > "$OUT/p$i.log" 2>&1
+  timeout 400 rocprofv3 --kernel-trace --pmc $P --output-format csv -d "$OUT/p$i" -o p -- python3 "$ROOT/bench.py" --steps 1 --warmup 1 --cpu-seqs 0 --no-parity-leg --no-profile $ARGS > "$OUT/p$i.log" 2>&1
   f=$(find "$OUT/p$i" -name "*counter_collection.csv" | head -1); [ -n "$f" ] && cp "$f" "$OUT/p$i.csv"; rm -rf "$OUT/p$i"
 done
 python3 - <<PY | tee "$ROOT/gpurun_out/kpmc_$TAG.txt"
