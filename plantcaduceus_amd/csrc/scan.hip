@@ -170,6 +170,38 @@ template <> struct DeltaTile<float> {
 // wrap-around cursor of the split GEMMs (gemm.hip): (a_hi, w_hi), (a_lo, w_hi), (a_hi, w_lo) - three bf16 products per fp32 product
 // on v_mfma_f32_32x32x16_bf16, 3 R' / 16 x 2 MFMAs per 32-step tile instead of R' / 2 x 2 fp32 ones (4x slower each).
 struct DeltaTileSplit {
+    // R' = 64 (every PlantCaduceus size): every operand chunk is loaded ONCE - a_hi, a_lo, w_hi up front (16 x 16 bytes per lane), then
+    // w_lo - and the three products run from registers in the same part-major order as the generic walk below (identical results).
+    // The generic walk re-requests a_hi and w_hi for their second product; with 16 waves per CU streaming rows through the 32 KiB L1
+    // those re-reads miss it: 1 135 L1 -> L2 read requests per 32-step tile and wave against 128 for the walk's own rows
+    // (profiles/r06_kpmcm_scan_f32_split.txt), which also tripled the latency of the per-step scalar B | C loads.
+    static __device__ __forceinline__ void run64(const bf16_t* __restrict__ arow, const bf16_t* __restrict__ b0, const bf16_t* __restrict__ b1,
+                                                 f32x16& acc0, f32x16& acc1) {
+        constexpr int NK = 4, RP = 64;
+        u32x4 ah[NK], al[NK], w0[NK], w1[NK];
+#pragma unroll
+        for (int k = 0; k < NK; ++k) {
+            ah[k] = *reinterpret_cast<const u32x4*>(arow + k * 16);
+            al[k] = *reinterpret_cast<const u32x4*>(arow + RP + k * 16);
+            w0[k] = *reinterpret_cast<const u32x4*>(b0 + k * 16);
+            w1[k] = *reinterpret_cast<const u32x4*>(b1 + k * 16);
+        }
+        auto mm = [&](const u32x4& a, const u32x4& x0, const u32x4& x1) {
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, x0), acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, x1), acc1, 0, 0, 0);
+        };
+#pragma unroll
+        for (int k = 0; k < NK; ++k) mm(ah[k], w0[k], w1[k]);          // a_hi w_hi
+#pragma unroll
+        for (int k = 0; k < NK; ++k) mm(al[k], w0[k], w1[k]);          // a_lo w_hi
+#pragma unroll
+        for (int k = 0; k < NK; ++k) {
+            w0[k] = *reinterpret_cast<const u32x4*>(b0 + RP + k * 16);
+            w1[k] = *reinterpret_cast<const u32x4*>(b1 + RP + k * 16);
+        }
+#pragma unroll
+        for (int k = 0; k < NK; ++k) mm(ah[k], w0[k], w1[k]);          // a_hi w_lo
+    }
     static __device__ __forceinline__ void run(const bf16_t* __restrict__ dtl, int64_t lddt, int64_t row_base, int t0,
                                                int L, const bf16_t* __restrict__ Wdt, int c0, int Rp, int lane,
                                                f32x16& acc0, f32x16& acc1) {
@@ -177,6 +209,9 @@ struct DeltaTileSplit {
         const bf16_t* arow = dtl + (row_base + tr) * lddt + (lane >> 5) * 8;
         const bf16_t* b0 = Wdt + (int64_t)(c0 + (lane & 31)) * 2 * Rp + (lane >> 5) * 8;
         const bf16_t* b1 = b0 + (int64_t)32 * 2 * Rp;
+#ifndef PCAD_SCAN_TILE_GENERIC      // timing-only A/B: the generic three-pass walk for R' = 64 too
+        if (Rp == 64) { run64(arow, b0, b1, acc0, acc1); return; }
+#endif
 #pragma unroll
         for (int part = 0; part < 3; ++part) {
             const bf16_t* ap = arow + (part == 1 ? Rp : 0);
@@ -407,9 +442,9 @@ __device__ __forceinline__ void scan_body(float (*dvs)[64], const int block_id, 
     for (int b = b_begin; b < b_end; ++b) {
         const int tb0 = REV ? (L - (b + 1) * TB) : b * TB;
 #ifndef PCAD_SCAN_NOPF      // timing-only ablation: without the L2 prefetch
-        // bf16 instantiations only: in the fp32 kernels (no register headroom at 128 VGPRs: the prefetch registers spill, and the split
-        // dt_low rows need four more gather loads per block) it measured -10 % (3.30 -> 3.63 ms per launch, profiles/r06_scan_ablations.txt)
-        if constexpr (FUSED && sizeof(T) == 2) {
+        // (B | C rows only: also prefetching the fp32 split model's dt_low rows - six more gather loads and registers per block at the
+        // 128-VGPR cap - cost its scans 10 %, 3.30 -> 3.63 ms per launch; with the B | C rows alone they gain 1 %: profiles/r06_f32_split_ab.txt)
+        if constexpr (FUSED) {
             asm volatile("" ::"v"(pfb0), "v"(pfb1));
             const int tbn = max(0, min(REV ? (L - (b + 2) * TB) : (b + 1) * TB, L - 1));          // first row of the next block in memory order (clamped)
             {
