@@ -540,6 +540,10 @@ def main():
         elif os.environ.get("PCAD_DEV") == "1" and os.environ.get("PCAD_CHUNK_SEQS"):
             chunk_max = int(os.environ["PCAD_CHUNK_SEQS"])
         nchunks = -(-B // chunk_max)
+        if not args.chunk_seqs and "workspace_limit_mb" not in opts:       # api.hip chunk_for: whole rounds of the persistent GEMMs
+            whole = lambda m: (2 * (-(-B // m)) * L) % 16384 == 0          # noqa: E731
+            if not whole(nchunks):
+                nchunks = next((m for m in range(nchunks + 1, min(2 * nchunks, B) + 1) if whole(m)), nchunks)
         chunk = -(-B // nchunks)                                  # even split, as pcad_forward does
         rows = 2 * chunk * L
         work = algorithmic_work(cfg, rows, esz)

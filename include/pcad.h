@@ -86,7 +86,9 @@ void   pcad_destroy(pcad_handle h);
 /* Options (call before pcad_workspace_bytes / pcad_forward):
  *   "chunk_seqs"  windows per pass through the layer stack (0 = default: as many as the kernels' unsigned 32-bit in-tensor
  *                 offsets allow, (2^32 - 2 MiB) / (d_inner * elem) token-rows = 1 023 windows of 512 bp at l32 bf16, the batch
- *                 split evenly into the fewest such chunks).  Results do not depend on it (rows are independent) - bit for bit
+ *                 split evenly into the fewest such chunks - or into up to twice as many when that makes the chunk's token-rows a
+ *                 multiple of 16 384, i.e. whole rounds of the persistent GEMMs: the fp32 model's 1 024 windows run as 4 x 256, not
+ *                 3 x 342).  Results do not depend on it (rows are independent) - bit for bit
  *                 (the small-launch forms of "scan_segments" are chosen for the whole batch of the call, not per chunk)
  *                 whenever every chunking runs the same layer form, which holds for window lengths that are multiples of 128
  *                 (every shipped use); for other lengths "norm_fold" engages per chunk (whole 256-row tiles only), so two

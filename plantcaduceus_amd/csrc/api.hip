@@ -486,7 +486,18 @@ static int chunk_for(const pcad_engine* e, int B, int L) {
         }
         cap = lo;                                     // one window always runs, whatever the limit
     }
-    const int64_t n = (B + cap - 1) / cap;
+    int64_t n = (B + cap - 1) / cap;
+    // Whole rounds of the persistent GEMMs: a chunk whose token-rows are a multiple of 16 384 (64 m-tiles of 256 rows) gives every CU
+    // the same number of output tiles and every XCD whole groups of the tile walk.  When the fewest-chunks split misses that (the fp32
+    // model's 1 024-window batch: 3 chunks of 342 windows = 1 368 m-tiles) and a split into up to twice as many chunks hits it
+    // (4 x 256 windows), take that one: +1.6 % on the fp32 + f32_gemm_split model (profiles/r06_f32_split_ab.txt r06v).  Never when
+    // the caller set "chunk_seqs" / "workspace_limit_mb"; results do not depend on the chunking.
+    if (e->chunk == 0 && e->ws_limit == 0) {
+        auto whole = [&](int64_t m) { const int64_t c = (B + m - 1) / m; return (2 * c * (int64_t)L) % 16384 == 0; };
+        if (!whole(n))
+            for (int64_t m = n + 1; m <= 2 * n && m <= B; ++m)
+                if (whole(m)) { n = m; break; }
+    }
     return (int)((B + n - 1) / n);
 }
 

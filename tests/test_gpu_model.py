@@ -325,7 +325,7 @@ def test_maximum_chunk_bit_identical_to_small_chunks():
     sd = synthetic_state_dict(cfg, seed=8)
     ids = rand_ids(1023, 512, 77, mask=255)
     pos = [255, 0, 511]
-    big = build(cfg, sd, torch.bfloat16)
+    big = build(cfg, sd, torch.bfloat16, chunk_seqs=1023)        # (the default would cut 1 023 windows into 512 + 511: whole GEMM rounds)
     a = big(input_ids=ids[:512].to(DEV), output_hidden_states=True, positions=pos)       # one chunk of 512 windows
     b = big(input_ids=ids.to(DEV), output_hidden_states=True, positions=pos)             # ONE chunk of 1023 windows
     la, ha = a.logits.cpu(), a.hidden_states[-1].float().cpu()
