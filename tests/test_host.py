@@ -78,6 +78,34 @@ def test_two_handles_share_no_state(lib):
     lib.pcad_destroy(a)
 
 
+def test_chunking_prefers_whole_gemm_rounds(lib):
+    """round 6: a batch is cut into the fewest chunks the 32-bit in-tensor offsets allow - or into up to twice as many when that makes
+    a chunk's token-rows a multiple of 16 384 (whole rounds of the persistent GEMMs).  Read off pcad_workspace_bytes (one chunk's
+    slab): the fp32 + f32_gemm_split model's 1 024 windows run as 4 x 256 (not 3 x 342), the bf16 model's as 2 x 512 as before; an
+    explicit "chunk_seqs" / "workspace_limit_mb" is never overridden; the split operands no longer shrink the chunk cap."""
+    def mk(dtype, **opts):
+        c = engine.PcadConfig(d_model=1024, n_layer=2, d_state=16, d_conv=4, expand=2, dt_rank=64, vocab=8, eps=1e-5, dtype=dtype,
+                              residual_in_fp32=1, complement=(C.c_int32 * 8)(0, 1, 2, 6, 5, 4, 3, 7))
+        h = C.c_void_p()
+        assert lib.pcad_create(C.byref(c), C.byref(h)) == 0
+        for k, v in opts.items():
+            assert lib.pcad_set_option(h, k.encode(), v) == 0
+        return h
+    ws = lambda h, B: lib.pcad_workspace_bytes(h, B, 512)       # noqa: E731
+    f = mk(0, f32_gemm_split=1)
+    assert ws(f, 1024) == ws(mk(0, f32_gemm_split=1, chunk_seqs=256), 1024)          # 4 x 256, chosen by the policy
+    assert ws(f, 1024) < ws(mk(0, f32_gemm_split=1, chunk_seqs=342), 1024)           # an explicit 342 is honoured (3 chunks)
+    assert ws(mk(0, f32_gemm_split=1, chunk_seqs=511), 1024) == ws(mk(0, f32_gemm_split=1, chunk_seqs=342), 1024)   # cap 511 -> 3 even chunks of 342
+    assert ws(mk(0, f32_gemm_split=1, chunk_seqs=511), 511) > ws(f, 342)             # 511 windows fit ONE chunk of the split model (cap = the fp32 model's own)
+    assert ws(mk(0), 1024) == ws(mk(0, chunk_seqs=256), 1024)                        # plain fp32 model: same cap, same choice
+    b = mk(1)
+    assert ws(b, 1024) == ws(mk(1, chunk_seqs=512), 1024)                            # bf16: 2 x 512 as before
+    assert ws(b, 1023) == ws(mk(1, chunk_seqs=512), 1023)                            # 1 023 windows: 512 + 511 (whole rounds) instead of one chunk
+    assert ws(b, 1000) == ws(mk(1, chunk_seqs=1000), 1000)                           # no split within 2x gives whole rounds: stays one chunk
+    lim = mk(1, workspace_limit_mb=4096)
+    assert ws(lim, 1024) <= 4096 << 20
+
+
 def test_fold_copies_are_carved_only_when_the_fold_can_engage(lib):
     """the norm-folded form's extra weight copies (second in_proj weight per layer, layer-0 table, padded out_proj) cost
     arena only for handles whose options ask for the fold when the arena is sized: bf16 default yes; bf16 with "norm_fold" 0 or
