@@ -31,6 +31,11 @@ import sys
 import time
 
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL needs it on this platform
+# cpu_baseline leg only (nothing on the GPU path uses OpenMP or a BLAS): the port alternates OpenMP loops with library sgemm calls, and
+# by default each runtime's idle workers SPIN after their region (OpenBLAS for ~2^26 cycles) - on the other runtime's cores, and against
+# the container's CFS quota (16 CPUs on the GPU boxes of this pool).  Both are read when the runtimes load, i.e. before numpy / torch.
+os.environ.setdefault("OPENBLAS_THREAD_TIMEOUT", "4")
+os.environ.setdefault("OMP_WAIT_POLICY", "passive")
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
@@ -54,8 +59,43 @@ CPU_BUDGET_S = 30.0                        # warm-up + timed runs of the CPU bas
 PARITY_STEPS, PARITY_WARMUP = 3, 1         # the parity_config leg (fp32 model with f32_gemm_split) of the default run
 
 
-def host_peak_from_cpuinfo(cpuinfo: str, max_khz=None):
+def cpu_quota_from_text(cpu_max: str = "", cfs_quota_us: str = "", cfs_period_us: str = ""):
+    """CPUs a container's CFS bandwidth limit allows (cgroup v2 cpu.max "<quota> <period>" | "max <period>"; cgroup v1
+    cpu.cfs_quota_us / cpu.cfs_period_us, -1 = unlimited) or None when there is no limit."""
+    try:
+        if cpu_max.strip():
+            q, _, p = cpu_max.strip().partition(" ")
+            return None if q == "max" else float(q) / float(p or 100000)
+        if cfs_quota_us.strip() and cfs_period_us.strip():
+            q, p = float(cfs_quota_us), float(cfs_period_us)
+            return None if q <= 0 or p <= 0 else q / p
+    except ValueError:
+        pass
+    return None
+
+
+def host_cpu_budget():
+    """What this PROCESS may use of the host: {"affinity": CPUs in its mask, "cpu_quota": CFS quota in CPUs or None, "usable_cpus"}.
+    The GPU boxes of this pool show 256 CPUs and a quota of 16: a 128-thread team there is throttled as a group to 16 CPUs' worth
+    (profiles/r06_host_probe.txt), so the CPU baseline runs - and is priced - on usable_cpus."""
+    def rd(path):
+        try:
+            return open(path).read()
+        except OSError:
+            return ""
+    quota = cpu_quota_from_text(rd("/sys/fs/cgroup/cpu.max"), rd("/sys/fs/cgroup/cpu/cpu.cfs_quota_us"), rd("/sys/fs/cgroup/cpu/cpu.cfs_period_us"))
+    try:
+        aff = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        aff = os.cpu_count() or 1
+    usable = aff if quota is None else max(1, min(aff, int(quota + 0.999)))
+    return {"affinity": aff, "cpu_quota": quota, "usable_cpus": usable}
+
+
+def host_peak_from_cpuinfo(cpuinfo: str, max_khz=None, usable_cpus=None):
     """Nominal fp32 peak of the host from /proc/cpuinfo text: physical cores x FMA lanes x 2 flop x 2 FMA ports x clock.
+    usable_cpus (host_cpu_budget): the estimate is for min(physical cores, usable_cpus) cores - what the process can be scheduled on -
+    with the whole machine's figure beside it.
     Lanes from the ISA flags (avx512f: 16, avx2/fma: 8, else 4 without FMA -> 1 flop per lane and port); clock = max_khz
     (cpufreq's cpuinfo_max_freq) when given, else the largest 'cpu MHz' line, else the 'model name ... @ x.xxGHz' figure.
     An ESTIMATE for orientation (real chips clock down under AVX-512 and may have one 512-bit port): the CPU baseline is
@@ -99,12 +139,14 @@ def host_peak_from_cpuinfo(cpuinfo: str, max_khz=None):
     else:
         ghz, src = 2.0, "assumed"
     ports = 2
-    gflops = ncores * lanes * fma * ports * ghz
-    return {"physical_cores": ncores, "threads": threads or ncores, "isa": isa, "clock_GHz": round(ghz, 3), "clock_source": src,
-            "flop_per_cycle_per_core": lanes * fma * ports, "host_peak_gflops_est": gflops}
+    used = ncores if not usable_cpus else max(1, min(ncores, int(usable_cpus)))
+    gflops = used * lanes * fma * ports * ghz
+    return {"physical_cores": ncores, "threads": threads or ncores, "usable_cores": used, "isa": isa, "clock_GHz": round(ghz, 3), "clock_source": src,
+            "flop_per_cycle_per_core": lanes * fma * ports, "host_peak_gflops_est": gflops,
+            "whole_host_peak_gflops_est": ncores * lanes * fma * ports * ghz}
 
 
-def host_peak_estimate():
+def host_peak_estimate(usable_cpus=None):
     try:
         txt = open("/proc/cpuinfo").read()
     except OSError:
@@ -114,7 +156,7 @@ def host_peak_estimate():
         khz = float(open("/sys/devices/system/cpu/cpu0/cpufreq/cpuinfo_max_freq").read())
     except (OSError, ValueError):
         pass
-    return host_peak_from_cpuinfo(txt, khz)
+    return host_peak_from_cpuinfo(txt, khz, usable_cpus)
 
 
 def parse():
@@ -635,7 +677,9 @@ def main():
         if ncpu != 0:
             try:
                 from oracle.c_oracle import COracle
-                co = COracle(sd, cfg, blas=True)
+                budget = host_cpu_budget()
+                hp = host_peak_estimate(budget["usable_cpus"])
+                co = COracle(sd, cfg, blas=True, threads=hp["usable_cores"])     # one thread per core the process may use
                 threads = co.threads
                 if ncpu < 0:
                     ncpu = min(B, CPU_MIN_SEQS)
@@ -654,7 +698,7 @@ def main():
                     times.append(time.perf_counter() - t1)
                 import statistics
                 tc, tmed = min(times), statistics.median(times)
-                hp = host_peak_estimate()
+                hp.update(budget)
                 gf = fl_seq * ncpu / tc / 1e9
                 res["cpu_baseline"] = {"value": ncpu / tc, "unit": "sequences/s", "cores": threads, "kind": "port",
                                        "value_median": ncpu / tmed, "repeats": len(times), "run_s": [round(t, 2) for t in times],
@@ -664,13 +708,17 @@ def main():
                                        "frac_of_host_peak": gf / hp["host_peak_gflops_est"],
                                        "host": hp,
                                        "sample": "%d of the same synthetic %d-bp windows, PlantCaduceus_%s fp32, oracle/c "
-                                                 "(C + OpenMP norm/conv/scan on all cores, the four projections through the "
-                                                 "host BLAS sgemm via numpy): one 1-window warm-up run, then %d timed run(s) inside a "
-                                                 "%.0f s budget; value = best (%.1f s), value_median = median.  A scalar-source port: "
-                                                 "%.0f GFLOP/s = %.1f %% of this host's nominal fp32 peak (%d cores x %d flop/cycle x "
-                                                 "%.2f GHz = %.0f GFLOP/s, an estimate) - a stated baseline, not a tuned CPU implementation"
-                                                 % (ncpu, L, args.model, len(times), CPU_BUDGET_S, tc, gf, 100.0 * gf / hp["host_peak_gflops_est"],
-                                                    hp["physical_cores"], hp["flop_per_cycle_per_core"], hp["clock_GHz"], hp["host_peak_gflops_est"])}
+                                                 "(C + OpenMP norm/conv/scan, the four projections through the host BLAS sgemm via numpy; "
+                                                 "%d threads = the cores this process may use: %d CPUs visible, CFS quota %s): one 1-window "
+                                                 "warm-up run, then %d timed run(s) inside a %.0f s budget; value = best (%.1f s), "
+                                                 "value_median = median.  A scalar-source port: %.0f GFLOP/s = %.1f %% of the nominal fp32 "
+                                                 "peak of those cores (%d cores x %d flop/cycle x %.2f GHz = %.0f GFLOP/s, an estimate; the "
+                                                 "whole %d-core machine: %.0f) - a stated baseline, not a tuned CPU implementation"
+                                                 % (ncpu, L, args.model, threads, budget["affinity"],
+                                                    "none" if budget["cpu_quota"] is None else "%.1f CPUs" % budget["cpu_quota"],
+                                                    len(times), CPU_BUDGET_S, tc, gf, 100.0 * gf / hp["host_peak_gflops_est"],
+                                                    hp["usable_cores"], hp["flop_per_cycle_per_core"], hp["clock_GHz"], hp["host_peak_gflops_est"],
+                                                    hp["physical_cores"], hp["whole_host_peak_gflops_est"])}
                 # cross-check while we are here: GPU result vs the CPU port on the sample
                 gp = out[:ncpu].float().cpu().numpy()
                 if args.workload == "embed":

@@ -57,6 +57,8 @@ def _lib():
     lib.oracle_forward.restype = C.c_int
     lib.oracle_forward.argtypes = [C.POINTER(OracleModel), C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
     lib.oracle_num_threads.restype = C.c_int
+    lib.omp_set_num_threads.restype = None          # libgomp's, reached through the library's own dependency (dlsym on its handle)
+    lib.omp_set_num_threads.argtypes = [C.c_int]
     lib.oracle_set_gemm.restype = None
     lib.oracle_set_gemm.argtypes = [C.c_void_p]
     return lib
@@ -74,6 +76,19 @@ def _blas_gemm(A, lda, W, K, Cp, ldc, M, N):
     np.matmul(a, w.T, out=c)
 
 
+@GEMM_FN
+def _torch_gemm(A, lda, W, K, Cp, ldc, M, N):
+    """the same product through torch.mm (the ATen CPU GEMM: MKL / oneDNN / its own OpenBLAS, whichever this torch build carries)."""
+    import torch
+    a = torch.from_numpy(np.ctypeslib.as_array(A, shape=(M, lda)))[:, :K]
+    w = torch.from_numpy(np.ctypeslib.as_array(W, shape=(N, K)))
+    c = torch.from_numpy(np.ctypeslib.as_array(Cp, shape=(M, ldc)))[:, :N]
+    if c.is_contiguous():
+        torch.mm(a, w.t(), out=c)
+    else:
+        c.copy_(torch.mm(a, w.t()))
+
+
 class COracle:
     """fp32 C/OpenMP forward from a reference-named state dict (values rounded through `dtype` first,
     emulating from_pretrained(torch_dtype=...); arithmetic is always fp32).  emulate_bf16=True additionally rounds
@@ -84,10 +99,17 @@ class COracle:
     both orders each direction's scan output is gated by SiLU(z) and rounded separately, as the reference's two
     selective_scan_fn calls do."""
 
-    def __init__(self, state_dict, config, dtype=None, emulate_bf16=False, ref_order=False, blas=False):
+    def __init__(self, state_dict, config, dtype=None, emulate_bf16=False, ref_order=False, blas=False, threads=None):
         import torch
         self.lib = _lib()
-        self.blas = bool(blas)     # the four projections through the host BLAS (numpy) instead of the plain-C GEMM
+        # threads: team size of the OpenMP loops AND of the library GEMM (None: each runtime's own default).  bench.py passes the CPUs the
+        # process may actually use (cgroup quota), since a team above the quota is throttled and spinning waiters burn the quota.
+        # Process-wide (omp_set_num_threads of the calling thread): later COracle objects of the process inherit it
+        self.nthreads = int(threads) if threads else None
+        if self.nthreads:
+            self.lib.omp_set_num_threads(self.nthreads)
+        # the four projections through a host library GEMM instead of the plain-C one: True / "numpy" = numpy's sgemm, "torch" = torch.mm
+        self.blas = {False: None, None: None, True: _blas_gemm, "numpy": _blas_gemm, "torch": _torch_gemm}[blas]
         self.config = config
         self._keep = []
 
@@ -131,11 +153,20 @@ class COracle:
         B, L = ids.shape
         logits = np.empty((B, L, 8), dtype=np.float32) if want_logits else None
         hidden = np.empty((B, L, 2 * self.config.d_model), dtype=np.float32) if want_hidden else None
-        self.lib.oracle_set_gemm(C.cast(_blas_gemm, C.c_void_p) if self.blas else None)
+        self.lib.oracle_set_gemm(C.cast(self.blas, C.c_void_p) if self.blas else None)
+        import contextlib
+        limit = contextlib.nullcontext()
+        if self.nthreads and self.blas is _blas_gemm:
+            import threadpoolctl
+            limit = threadpoolctl.threadpool_limits(limits=self.nthreads, user_api="blas")
+        elif self.nthreads and self.blas is _torch_gemm:
+            import torch
+            torch.set_num_threads(self.nthreads)
         try:
-            rc = self.lib.oracle_forward(C.byref(self.model), ids.ctypes.data, B, L,
-                                         logits.ctypes.data if want_logits else None,
-                                         hidden.ctypes.data if want_hidden else None)
+            with limit:
+                rc = self.lib.oracle_forward(C.byref(self.model), ids.ctypes.data, B, L,
+                                             logits.ctypes.data if want_logits else None,
+                                             hidden.ctypes.data if want_hidden else None)
         finally:
             self.lib.oracle_set_gemm(None)
         if rc != 0:

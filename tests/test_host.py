@@ -335,6 +335,26 @@ def test_bench_host_peak_estimate_arithmetic():
     live = bench.host_peak_estimate()                      # this host: finite, positive, consistent with its own fields
     assert live["host_peak_gflops_est"] > 0
     assert abs(live["host_peak_gflops_est"] - live["physical_cores"] * live["flop_per_cycle_per_core"] * live["clock_GHz"]) < 0.1 * live["host_peak_gflops_est"]
+    # a container limited to fewer CPUs than the machine has is priced on those: 2 of the 4 cores -> 320 of 640
+    hq = bench.host_peak_from_cpuinfo(txt, max_khz=2.5e6, usable_cpus=2)
+    assert hq["usable_cores"] == 2 and abs(hq["host_peak_gflops_est"] - 320.0) < 1e-9 and abs(hq["whole_host_peak_gflops_est"] - 640.0) < 1e-9
+    assert bench.host_peak_from_cpuinfo(txt, max_khz=2.5e6, usable_cpus=64)["usable_cores"] == 4        # never more than the machine
+
+
+def test_bench_cpu_budget_reads_the_cgroup_quota():
+    """cpu_baseline runs on, and is priced against, the CPUs the process may actually use: the GPU boxes of this pool show 256 CPUs
+    under a CFS quota of 16 ("1600000 100000" in cpu.max), where a team of 128 spinning threads is throttled as a group
+    (profiles/r06_host_probe.txt: 0.8 -> 2.8 windows/s with a 16-thread team and passive waiting)."""
+    import bench
+    assert bench.cpu_quota_from_text("1600000 100000\n") == 16.0
+    assert bench.cpu_quota_from_text("max 100000\n") is None
+    assert bench.cpu_quota_from_text("150000 100000") == 1.5
+    assert bench.cpu_quota_from_text("", "400000", "100000") == 4.0                 # cgroup v1
+    assert bench.cpu_quota_from_text("", "-1", "100000") is None
+    assert bench.cpu_quota_from_text("", "", "") is None and bench.cpu_quota_from_text("garbage here") is None
+    b = bench.host_cpu_budget()
+    assert 1 <= b["usable_cpus"] <= b["affinity"] and (b["cpu_quota"] is None or b["usable_cpus"] <= int(b["cpu_quota"] + 0.999))
+    assert os.environ["OMP_WAIT_POLICY"] and os.environ["OPENBLAS_THREAD_TIMEOUT"]      # set by bench before any runtime loads
 
 
 def test_effective_batch_keeps_an_explicit_batch_size():
