@@ -9,6 +9,17 @@ if ROOT not in sys.path:
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
+# The checkers (oracle/: torch CPU ops, C + OpenMP loops, library sgemm) take most of the suite's time.  Importing bench (stdlib-only
+# at import) sets the passive-waiting defaults for OpenBLAS / OpenMP workers before either runtime loads; and where the container's CFS
+# quota is below the CPUs it shows (the GPU boxes of this pool: 16 of 256 - profiles/r06_host_probe.txt) the thread teams are sized to
+# the quota instead of being throttled as a group.  The engine under test is not involved: nothing on the GPU path uses these runtimes.
+import bench  # noqa: E402
+
+_budget = bench.host_cpu_budget()
+if _budget["cpu_quota"] is not None and _budget["usable_cpus"] < _budget["affinity"]:
+    for _k in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
+        os.environ.setdefault(_k, str(_budget["usable_cpus"]))
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
