@@ -25,6 +25,25 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+@pytest.fixture(scope="session", autouse=True)
+def _checker_threads_fit_the_cpu_quota():
+    """Runtime twin of the environment defaults above, for a process whose OpenMP / BLAS runtimes were loaded before this file ran
+    (a sitecustomize hook, a plugin): limit the already-loaded pools to the CPUs the quota allows."""
+    limits = None
+    if _budget["cpu_quota"] is not None and _budget["usable_cpus"] < _budget["affinity"]:
+        try:
+            import numpy  # noqa: F401  (loads the BLAS so that it can be limited)
+            import threadpoolctl
+            import torch
+            torch.set_num_threads(_budget["usable_cpus"])
+            limits = threadpoolctl.threadpool_limits(limits=_budget["usable_cpus"])
+        except Exception:      # a missing helper only costs time
+            limits = None
+    yield
+    if limits is not None:
+        limits.restore_original_limits()
+
+
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
