@@ -44,7 +44,7 @@ py("profiles/kernel_stats.py", f"{G}/kernel_stats.csv", f"profiles/{tag}_kernel_
 py("profiles/pmc_summary.py", G, f"profiles/{tag}_pmc_traffic.json")
 if os.path.exists(f"{G}/kernel_stats_f32_split.csv"):
     py("profiles/kernel_stats.py", f"{G}/kernel_stats_f32_split.csv", f"profiles/{tag}_kernel_stats_f32_split.txt",
-       "fp32 model with f32_gemm_split (the parity configuration): bench.py --dtype f32 --opt f32_gemm_split=1 --steps 3 --warmup 1 (1024 windows per step as 3 chunks of 342)")
+       "fp32 model with f32_gemm_split (the parity configuration): bench.py --dtype f32 --opt f32_gemm_split=1 --steps 3 --warmup 1 (1024 windows per step as 4 chunks of 256)")
     cp(f"{G}/bench_f32_split_under_rocprof.json", f"{tag}_bench_f32_split_under_rocprof.json")
 
 # ---- item 2: 8 192 bp vs 512 bp per token, PlantCAD2 Medium / Large -------------------------------------------------------
