@@ -64,6 +64,38 @@ def _lib():
     return lib
 
 
+def usable_cpus(read=None, affinity=None):
+    """CPUs this process may actually use: its affinity mask, capped by the container's CFS quota (cgroup v2 cpu.max / v1
+    cpu.cfs_quota_us).  The GPU boxes of this pool show 256 CPUs under a quota of 16; a larger team is throttled as a group and its
+    spinning waiters burn the quota (profiles/r06_host_probe.txt: 0.8 -> 2.8 windows/s at l32).  None when there is no quota."""
+    def rd(path):
+        if read is not None:           # tests: a dict of file contents
+            return read.get(path, "").strip()
+        try:
+            return open(path).read().strip()
+        except OSError:
+            return ""
+    quota = None
+    try:
+        v2 = rd("/sys/fs/cgroup/cpu.max").split()
+        if len(v2) == 2 and v2[0] != "max":
+            quota = float(v2[0]) / float(v2[1])
+        elif not v2:
+            q, p = rd("/sys/fs/cgroup/cpu/cpu.cfs_quota_us"), rd("/sys/fs/cgroup/cpu/cpu.cfs_period_us")
+            if q and p and float(q) > 0 and float(p) > 0:
+                quota = float(q) / float(p)
+    except ValueError:
+        quota = None
+    if quota is None:
+        return None
+    try:
+        aff = affinity or len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        aff = os.cpu_count() or 1
+    n = max(1, min(aff, int(quota + 0.999)))
+    return n if n < aff else None
+
+
 GEMM_FN = C.CFUNCTYPE(None, FP, C.c_int, FP, C.c_int, FP, C.c_int, C.c_int, C.c_int)
 
 
@@ -102,10 +134,10 @@ class COracle:
     def __init__(self, state_dict, config, dtype=None, emulate_bf16=False, ref_order=False, blas=False, threads=None):
         import torch
         self.lib = _lib()
-        # threads: team size of the OpenMP loops AND of the library GEMM (None: each runtime's own default).  bench.py passes the CPUs the
-        # process may actually use (cgroup quota), since a team above the quota is throttled and spinning waiters burn the quota.
+        # threads: team size of the OpenMP loops AND of the library GEMM.  None: each runtime's own default, unless the container has a
+        # CPU quota below the CPUs it shows - then the quota (usable_cpus), since a team above it is throttled and spinning waiters burn it.
         # Process-wide (omp_set_num_threads of the calling thread): later COracle objects of the process inherit it
-        self.nthreads = int(threads) if threads else None
+        self.nthreads = int(threads) if threads else usable_cpus()
         if self.nthreads:
             self.lib.omp_set_num_threads(self.nthreads)
         # the four projections through a host library GEMM instead of the plain-C one: True / "numpy" = numpy's sgemm, "torch" = torch.mm

@@ -224,3 +224,18 @@ def test_census_helpers_count_calls_and_margins():
     np.testing.assert_allclose(ac.margins(q), [0.10, 0.01, 0.10])
     np.testing.assert_allclose(ac.softmax4(np.log(q)), q, rtol=1e-12)
     assert ac.compare(p[:2], q)["n"] == 2                      # the shorter run decides
+
+
+def test_c_oracle_team_follows_the_cpu_quota():
+    """oracle/c_oracle.py sizes its OpenMP / BLAS teams to the container's CFS quota when that is below the CPUs it shows (the GPU
+    boxes of this pool: cpu.max "1600000 100000" under 256 CPUs - a 128-thread team there ran 3.5x slower, profiles/r06_host_probe.txt);
+    no quota, or a quota at or above the affinity mask, leaves the runtimes' defaults alone."""
+    from oracle.c_oracle import usable_cpus
+    v2, q1, p1 = "/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "/sys/fs/cgroup/cpu/cpu.cfs_period_us"
+    assert usable_cpus({v2: "1600000 100000\n"}, affinity=256) == 16
+    assert usable_cpus({v2: "150000 100000"}, affinity=8) == 2
+    assert usable_cpus({v2: "max 100000"}, affinity=256) is None
+    assert usable_cpus({v2: "1600000 100000"}, affinity=8) is None          # quota above what the process sees
+    assert usable_cpus({q1: "400000", p1: "100000"}, affinity=64) == 4     # cgroup v1
+    assert usable_cpus({q1: "-1", p1: "100000"}, affinity=64) is None
+    assert usable_cpus({}, affinity=64) is None and usable_cpus({v2: "junk words"}, affinity=64) is None
