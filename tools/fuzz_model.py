@@ -8,6 +8,9 @@ from oracle import caduceus_oracle as O
 from plantcaduceus_amd.checkpoint import make_config, synthetic_state_dict
 from plantcaduceus_amd.modeling_caduceus import CaduceusForMaskedLM
 
+from oracle.c_oracle import usable_cpus
+if usable_cpus():                       # container CPU quota below the visible CPUs: a larger torch team is throttled as a group
+    torch.set_num_threads(usable_cpus())
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 # "fold" as a third argument: geometries on which the norm-folded layer form engages (d_model % 256 == 0, 2 B L % 256 == 0), the
